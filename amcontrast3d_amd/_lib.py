@@ -1,0 +1,65 @@
+"""ctypes binding of libamc3d_hip.so (C-ABI: include/amc3d.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent,
+importing the operators raises.  The product path never routes through oracle/.
+"""
+import ctypes
+import os
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+_SO = os.path.join(_CSRC, "libamc3d_hip.so")
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/amc3d.h declares
+SIGNATURES = {
+    "amc3d_version": (ctypes.c_char_p, []),
+    "amc3d_last_error": (ctypes.c_char_p, []),
+    "amc3d_ball_query": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "amc3d_group_points": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "amc3d_group_points_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "amc3d_gather_points": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "amc3d_gather_points_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "amc3d_furthest_point_sampling": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "amc3d_three_nn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_three_interpolate": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_three_interpolate_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_knnquery_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "amc3d_knnquery": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+}
+
+
+def build(force=False):
+    """Compile the HIP sources for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", _CSRC, "-j8"] + (["-B"] if force else [])
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("building libamc3d_hip.so failed:\n" + proc.stdout)
+    return _SO
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library and bind every declared symbol (raises if any is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise ImportError(
+            f"{_SO} not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C {_CSRC}`); there is no CPU fallback")
+    lib = ctypes.CDLL(_SO)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f"{what} failed (hipError {status}): {load().amc3d_last_error().decode()}")

@@ -1,0 +1,142 @@
+"""Adaptive-margin contrastive head over per-stage point embeddings.
+
+Drop-in for openpoints/AMContrast3D/MarginContrast.py:
+    AmbiguityHead   :15-52    per-stage ambiguity a_i only (used by the ++ variant)
+    ContrastHead    :56-273   per stage: 24-NN (self dropped) -> neighbour labels ->
+                              positive mask -> a_i -> cosine similarity -> soft-NN loss
+                              with margin m_i = mu * a_i + nu on the positive pairs
+
+Only the configuration the shipped configs select is implemented
+(dist_cos + contrast_softnn_margin, cfgs/*/AMContrast3D-AA.yaml:6-30); the other
+similarity / loss variants of the reference are unreachable from its configs.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from openpoints.cpp.pointops.functions import pointops
+from .AEF.ambiguity import ambiguity_function
+from .AEF.function import _eps
+from .AEF.utils import fetch_pxo, get_ftype, get_subscene_label_CBL
+
+
+def _posmask_cnt(labels, neighbor_label):
+    """same arg-max class as the anchor -> (m, k) bool (MarginContrast.py:111-115)"""
+    return torch.argmax(torch.unsqueeze(labels, -2), -1) == torch.argmax(neighbor_label, -1)
+
+
+def _stage_neighbourhood(n, i, stageACE_list, target, nstride, num_classes, ignore_index, nsample, ftype):
+    p, features, o = fetch_pxo(n, i, stageACE_list, ftype)
+    labels = get_subscene_label_CBL(n, i, stageACE_list, target, nstride, num_classes, ignore_index)
+    neighbor_idx, _ = pointops.knnquery(nsample, p, p, o, o)
+    neighbor_idx = neighbor_idx[..., 1:].contiguous()  # drop the self match
+    m, k = neighbor_idx.shape
+    flat = neighbor_idx.view(-1).long()
+    neighbor_label = labels[flat, :].view(m, k, labels.shape[1])
+    posmask = _posmask_cnt(labels, neighbor_label)
+    return p, features, neighbor_idx, flat, posmask, k
+
+
+class AmbiguityHead(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.nstride = torch.tensor([4, 4, 4, 4])
+        self.ftype = get_ftype('latent')[0]
+        self.posmask_func = _posmask_cnt
+        self.main = self.point_ambiguity
+
+    def posmask_cnt(self, labels, neighbor_label):
+        return _posmask_cnt(labels, neighbor_label)
+
+    def point_ambiguity(self, n, i, stageACE_list, target, num_classes, ignore_index, ambiguity_args):
+        p, _, neighbor_idx, _, posmask, k = _stage_neighbourhood(
+            n, i, stageACE_list, target, self.nstride, num_classes, ignore_index, ambiguity_args.nsample, self.ftype)
+        a, _ = ambiguity_function(p, posmask, k, neighbor_idx, ambiguity_args.cctype, ambiguity_args.ccbeta,
+                                  ambiguity_args.vis, ambiguity_args.nu)
+        return a
+
+    def forward(self, target, stageACE_list, num_classes, ignore_index, ambiguity_args):
+        return [self.main(ambiguity_args.stages, i, stageACE_list, target, num_classes, ignore_index, ambiguity_args)
+                for i in range(ambiguity_args.stages_num)]
+
+
+class ContrastHead(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.nstride = torch.tensor([4, 4, 4, 4])
+        self.stages = [('up', 0), ('up', 1), ('up', 2), ('up', 3)]
+        self.ftype = get_ftype('latent')[0]
+        self.project = None
+        self.dist_func = self.dist_cos
+        self.contrast_func = self.contrast_softnn_margin
+        self.posmask_func = self.posmask_cnt
+        self.main_contrast = self.point_contrast_margin
+
+    def dist_cos(self, features, neighbor_feature):
+        """(m,C), (m,k,C) -> cosine similarity (m,k)"""
+        return F.cosine_similarity(torch.unsqueeze(features, -2), neighbor_feature, dim=2)
+
+    def posmask_cnt(self, labels, neighbor_label):
+        return _posmask_cnt(labels, neighbor_label)
+
+    def contrast_softnn_margin(self, dist, posmask, ambiguity, ambiguity_args, invalid_mask=None):
+        """-log( sum_+ e^{s'} / sum e^{s'} + eps ), s' = (s - m_i)/T on positives, s/T on negatives
+        (MarginContrast.py:117-174)."""
+        if ambiguity_args.margin == 'constant':
+            margin = ambiguity_args.nu
+        elif ambiguity_args.margin == 'adaptive':
+            margin = ambiguity_args.mu * torch.unsqueeze(ambiguity, -1) + ambiguity_args.nu
+        elif ambiguity_args.margin == 'learned':
+            u = torch.mean(dist * ~posmask, 1)
+            v = torch.mean(dist * posmask, 1)
+            margin = (torch.unsqueeze(u, -1) - 1) * torch.unsqueeze(ambiguity, -1) + torch.unsqueeze(v, -1)
+
+        if ambiguity_args.db == '-m':
+            dist = (dist - margin) * posmask + dist * ~posmask
+        elif ambiguity_args.db == '+m':
+            dist = dist * posmask + (dist + margin) * ~posmask
+        else:
+            dist = dist * posmask + dist * ~posmask
+
+        if ambiguity_args.temperature is not None:
+            dist = dist / ambiguity_args.temperature
+        exp = torch.exp(dist)
+        if invalid_mask is not None:
+            exp = exp * (1 - invalid_mask)
+
+        pos = torch.sum(exp * posmask, axis=-1)
+        neg = torch.sum(exp * (1 - posmask.int()), axis=-1)
+        pos_neg = torch.sum(exp, axis=-1)
+        if ambiguity_args.supervisedCL == 'Method1':
+            loss = pos / pos_neg + _eps
+        elif ambiguity_args.supervisedCL == 'Method2':
+            loss = (exp * posmask) / (exp * posmask + neg.unsqueeze(-1)) + _eps
+            loss = torch.sum(loss, axis=-1) / (torch.sum(posmask.int(), axis=-1) + _eps)
+        return -torch.log(loss)
+
+    def point_contrast_margin(self, n, i, stageACE_list, target, num_classes, ignore_index, ambiguity_args):
+        p, features, neighbor_idx, flat, posmask, k = _stage_neighbourhood(
+            n, i, stageACE_list, target, self.nstride, num_classes, ignore_index, ambiguity_args.nsample, self.ftype)
+        m = neighbor_idx.shape[0]
+        neighbor_feature = features[flat, :].view(m, k, features.shape[1])
+
+        ambiguity_soft, _ = ambiguity_function(p, posmask, k, neighbor_idx, ambiguity_args.cctype,
+                                               ambiguity_args.ccbeta, ambiguity_args.vis, ambiguity_args.nu)
+        target_ai = torch.clone(ambiguity_soft)
+        output_ai = stageACE_list['ambiguity'][i].flatten() if 'ambiguity' in stageACE_list.keys() else None
+
+        # anchors that enter the loss: everything but the perfectly consistent points (a == 0)
+        keep = torch.logical_and(0 < ambiguity_soft, ambiguity_soft <= 1)
+        dist = self.dist_func(features[keep], neighbor_feature[keep])
+        loss = self.contrast_func(dist, posmask[keep], ambiguity_soft[keep], ambiguity_args)
+        return torch.mean(loss), output_ai, target_ai
+
+    def forward(self, output, target, stageACE_list, num_classes, ignore_index, ambiguity_args):
+        loss_sum = 0
+        target_ai_list = []
+        for i in range(ambiguity_args.stages_num):
+            loss, _, target_ai = self.main_contrast(ambiguity_args.stages, i, stageACE_list, target, num_classes,
+                                                    ignore_index, ambiguity_args)
+            loss_sum += loss
+            target_ai_list.append(target_ai)
+        return loss_sum, torch.cat(target_ai_list), target_ai_list

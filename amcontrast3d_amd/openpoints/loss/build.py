@@ -1,0 +1,38 @@
+"""LOSS registry and the cross-entropy + adaptive-margin-contrast criterion.
+
+Drop-in for openpoints/loss/build.py: ``LOSS`` (:9-12), ``CrossEntropyAce`` (:324-346),
+``build_criterion_from_cfg`` (:348-357).
+"""
+import torch
+from torch.nn import BCEWithLogitsLoss, CrossEntropyLoss
+
+from openpoints.AMContrast3D.MarginContrast import ContrastHead
+from openpoints.utils import registry
+
+LOSS = registry.Registry('loss')
+LOSS.register_module(name='CrossEntropy', module=CrossEntropyLoss)
+LOSS.register_module(name='CrossEntropyLoss', module=CrossEntropyLoss)
+LOSS.register_module(name='BCEWithLogitsLoss', module=BCEWithLogitsLoss)
+
+
+@LOSS.register_module()
+class CrossEntropyAce(torch.nn.Module):
+    """w1 * CE(logits, target) + w2 * sum_stage contrast(stage).  Like the reference, the
+    constructor accepts and ignores label_smoothing / weight / ignore_index (build.py:326-329)."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.creterion = CrossEntropyLoss()  # attribute name as in the reference
+        self.contrast_head = ContrastHead()
+
+    def forward(self, logit, target, stageACE_list, num_classes, ignore_index, ambiguity_args):
+        logit = logit.transpose(1, 2).reshape(-1, logit.shape[1])  # (B,ncls,N) -> (B*N,ncls)
+        target = target.flatten()
+        ce = self.creterion(logit, target)
+        contrast, _, _ = self.contrast_head(logit, target, stageACE_list, num_classes, ignore_index, ambiguity_args)
+        return ambiguity_args.w1 * ce + ambiguity_args.w2 * contrast
+
+
+def build_criterion_from_cfg(cfg, **kwargs):
+    """Build the criterion named by ``cfg.NAME``."""
+    return LOSS.build(cfg, **kwargs)

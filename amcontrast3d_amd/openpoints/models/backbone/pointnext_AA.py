@@ -1,0 +1,364 @@
+"""PointNeXt encoder/decoder with the AMContrast3D stage bookkeeping.
+
+Drop-in for openpoints/models/backbone/pointnext_AA.py: same registered class
+names, constructor keywords, attribute names, module nesting (hence state-dict
+keys) and return structures:
+
+    LocalAggregation                 pointnext_AA.py:22-73
+    SetAbstraction                   :76-170
+    FeaturePropogation               :173-226   (spelling kept: it is in checkpoints' class paths)
+    InvResMLP / ResBlock             :229-308
+    PointNextEncoder_AMContrast3D    :311-471
+    PointNextDecoder_AMContrast3D    :475-527
+
+All neighbour search, sampling, grouping and interpolation runs on the gfx950
+kernels in amcontrast3d_amd (no torch fallback).
+"""
+import logging
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from ..build import MODELS
+from ..layers import (CHANNEL_MAP, create_act, create_convblock1d, create_convblock2d, create_grouper,
+                      furthest_point_sample, get_aggregation_feautres, random_sample, three_interpolation)
+
+
+def get_reduction_fn(reduction):
+    reduction = 'mean' if reduction.lower() == 'avg' else reduction
+    assert reduction in ['sum', 'max', 'mean']
+    if reduction == 'max':
+        return lambda x: torch.max(x, dim=-1, keepdim=False)[0]
+    if reduction == 'mean':
+        return lambda x: torch.mean(x, dim=-1, keepdim=False)
+    return lambda x: torch.sum(x, dim=-1, keepdim=False)
+
+
+class LocalAggregation(nn.Module):
+    """Grouped MLP over the neighbourhood of every point of one set, then pooling."""
+
+    def __init__(self, channels: List[int], norm_args={'norm': 'bn1d'}, act_args={'act': 'relu'},
+                 group_args={'NAME': 'ballquery', 'radius': 0.1, 'nsample': 16}, conv_args=None,
+                 feature_type='dp_fj', reduction='max', last_act=True, **kwargs):
+        super().__init__()
+        if kwargs:
+            logging.warning(f"kwargs: {kwargs} are not used in {__class__.__name__}")
+        channels[0] = CHANNEL_MAP[feature_type](channels[0])
+        last = len(channels) - 2
+        self.convs = nn.Sequential(*[
+            create_convblock2d(channels[i], channels[i + 1], norm_args=norm_args,
+                               act_args=None if (i == last and not last_act) else act_args, **(conv_args or {}))
+            for i in range(len(channels) - 1)])
+        self.grouper = create_grouper(group_args)
+        self.reduction = reduction.lower()
+        self.pool = get_reduction_fn(self.reduction)
+        self.feature_type = feature_type
+
+    def forward(self, pf):
+        p, f = pf
+        dp, fj = self.grouper(p, p, f)
+        fj = get_aggregation_feautres(p, dp, f, fj, self.feature_type)
+        return self.pool(self.convs(fj))
+
+
+class SetAbstraction(nn.Module):
+    """FPS -> ball-query grouping -> grouped MLP -> max over the neighbourhood
+    (-> + skip connection, ReLU).  With ``is_head`` it is the point-wise stem MLP."""
+
+    def __init__(self, in_channels, out_channels, layers=1, stride=1,
+                 group_args={'NAME': 'ballquery', 'radius': 0.1, 'nsample': 16},
+                 norm_args={'norm': 'bn1d'}, act_args={'act': 'relu'}, conv_args=None, sampler='fps',
+                 feature_type='dp_fj', use_res=False, is_head=False, **kwargs):
+        super().__init__()
+        self.stride = stride
+        self.is_head = is_head
+        self.all_aggr = not is_head and stride == 1
+        self.use_res = use_res and not self.all_aggr and not self.is_head
+        self.feature_type = feature_type
+
+        mid = out_channels // 2 if stride > 1 else out_channels
+        channels = [in_channels] + [mid] * (layers - 1) + [out_channels]
+        if not is_head:
+            channels[0] = CHANNEL_MAP[feature_type](channels[0])
+
+        if self.use_res:
+            self.skipconv = create_convblock1d(in_channels, channels[-1], norm_args=None, act_args=None) \
+                if in_channels != channels[-1] else nn.Identity()
+            self.act = create_act(act_args)
+
+        make = create_convblock1d if is_head else create_convblock2d
+        last = len(channels) - 2
+        self.convs = nn.Sequential(*[
+            make(channels[i], channels[i + 1], norm_args=None if is_head else norm_args,
+                 act_args=None if (i == last and (self.use_res or is_head)) else act_args, **(conv_args or {}))
+            for i in range(len(channels) - 1)])
+
+        if not is_head:
+            if self.all_aggr:
+                group_args.nsample = None
+                group_args.radius = None
+            self.grouper = create_grouper(group_args)
+            self.pool = lambda x: torch.max(x, dim=-1, keepdim=False)[0]
+            if sampler.lower() == 'fps':
+                self.sample_fn = furthest_point_sample
+            elif sampler.lower() == 'random':
+                self.sample_fn = random_sample
+
+    def forward(self, pf):
+        p, f = pf
+        if self.is_head:
+            return p, self.convs(f)
+        if not self.all_aggr:
+            idx = self.sample_fn(p, p.shape[1] // self.stride).long()
+            new_p = torch.gather(p, 1, idx.unsqueeze(-1).expand(-1, -1, 3))
+        else:
+            new_p = p
+        fi = None
+        if self.use_res or 'df' in self.feature_type:
+            fi = torch.gather(f, -1, idx.unsqueeze(1).expand(-1, f.shape[1], -1))
+            if self.use_res:
+                identity = self.skipconv(fi)
+        dp, fj = self.grouper(new_p, p, f)
+        fj = get_aggregation_feautres(new_p, dp, fi, fj, feature_type=self.feature_type)
+        f = self.pool(self.convs(fj))
+        if self.use_res:
+            f = self.act(f + identity)
+        return new_p, f
+
+
+class FeaturePropogation(nn.Module):
+    """PointNet++ feature propagation: 3-NN inverse-distance interpolation of the
+    coarse features onto the fine set, concat with the skip features, point-wise MLP."""
+
+    def __init__(self, mlp, upsample=True, norm_args={'norm': 'bn1d'}, act_args={'act': 'relu'}):
+        super().__init__()
+        if not upsample:
+            self.linear2 = nn.Sequential(nn.Linear(mlp[0], mlp[1]), nn.ReLU(inplace=True))
+            mlp[1] *= 2
+            self.linear1 = nn.Sequential(*[
+                create_convblock1d(mlp[i], mlp[i + 1], norm_args=norm_args, act_args=act_args)
+                for i in range(1, len(mlp) - 1)])
+        else:
+            self.convs = nn.Sequential(*[
+                create_convblock1d(mlp[i], mlp[i + 1], norm_args=norm_args, act_args=act_args)
+                for i in range(len(mlp) - 1)])
+        self.pool = lambda x: torch.mean(x, dim=-1, keepdim=False)
+
+    def forward(self, pf1, pf2=None):
+        if pf2 is None:  # global branch (not used by the segmentation decoder)
+            _, f = pf1
+            g = self.linear2(self.pool(f))
+            return self.linear1(torch.cat((f, g.unsqueeze(-1).expand(-1, -1, f.shape[-1])), dim=1))
+        p1, f1 = pf1
+        p2, f2 = pf2
+        up = three_interpolation(p1, p2, f2)
+        return self.convs(up if f1 is None else torch.cat((f1, up), dim=1))
+
+
+class InvResMLP(nn.Module):
+    """LocalAggregation (C->C) + point-wise C->expansion*C->C with a residual."""
+
+    def __init__(self, in_channels, norm_args=None, act_args=None,
+                 aggr_args={'feature_type': 'dp_fj', "reduction": 'max'}, group_args={'NAME': 'ballquery'},
+                 conv_args=None, expansion=1, use_res=True, num_posconvs=2, less_act=False, **kwargs):
+        super().__init__()
+        self.use_res = use_res
+        mid_channels = int(in_channels * expansion)
+        self.convs = LocalAggregation([in_channels, in_channels], norm_args=norm_args,
+                                      act_args=act_args if num_posconvs > 0 else None, group_args=group_args,
+                                      conv_args=conv_args, **aggr_args, **kwargs)
+        if num_posconvs < 1:
+            channels = []
+        elif num_posconvs == 1:
+            channels = [in_channels, in_channels]
+        else:
+            channels = [in_channels, mid_channels, in_channels]
+        last = len(channels) - 2
+        self.pwconv = nn.Sequential(*[
+            create_convblock1d(channels[i], channels[i + 1], norm_args=norm_args,
+                               act_args=act_args if (i != last and not less_act) else None, **(conv_args or {}))
+            for i in range(len(channels) - 1)])
+        self.act = create_act(act_args)
+
+    def forward(self, pf):
+        p, f = pf
+        identity = f
+        f = self.pwconv(self.convs([p, f]))
+        if f.shape[-1] == identity.shape[-1] and self.use_res:
+            f += identity
+        return [p, self.act(f)]
+
+
+class ResBlock(nn.Module):
+    def __init__(self, in_channels, norm_args=None, act_args=None,
+                 aggr_args={'feature_type': 'dp_fj', "reduction": 'max'}, group_args={'NAME': 'ballquery'},
+                 conv_args=None, expansion=1, use_res=True, **kwargs):
+        super().__init__()
+        self.use_res = use_res
+        mid_channels = in_channels * expansion
+        self.convs = LocalAggregation([in_channels, in_channels, mid_channels, in_channels], norm_args=norm_args,
+                                      act_args=None, group_args=group_args, conv_args=conv_args, **aggr_args,
+                                      **kwargs)
+        self.act = create_act(act_args)
+
+    def forward(self, pf):
+        p, f = pf
+        identity = f
+        f = self.convs([p, f])
+        if f.shape[-1] == identity.shape[-1] and self.use_res:
+            f += identity
+        return [p, self.act(f)]
+
+
+_BLOCKS = {'InvResMLP': InvResMLP, 'ResBlock': ResBlock}
+
+
+@MODELS.register_module()
+class PointNextEncoder_AMContrast3D(nn.Module):
+    def __init__(self, in_channels: int = 4, width: int = 32, blocks: List[int] = [1, 4, 7, 4, 4],
+                 strides: List[int] = [4, 4, 4, 4], block='InvResMLP', nsample=32, radius=0.1,
+                 aggr_args: dict = {'feature_type': 'dp_fj', "reduction": 'max'},
+                 group_args: dict = {'NAME': 'ballquery'}, sa_layers: int = 1, sa_use_res: bool = False,
+                 **kwargs):
+        super().__init__()
+        if isinstance(block, str):
+            block = _BLOCKS[block]
+        self.blocks = blocks
+        self.strides = strides
+        self.in_channels = in_channels
+        self.aggr_args = aggr_args
+        self.norm_args = kwargs.get('norm_args', {'norm': 'bn'})
+        self.act_args = kwargs.get('act_args', {'act': 'relu'})
+        self.conv_args = kwargs.get('conv_args', None)
+        self.sampler = kwargs.get('sampler', 'fps')
+        self.expansion = kwargs.get('expansion', 4)
+        self.sa_layers = sa_layers
+        self.sa_use_res = sa_use_res
+        self.use_res = kwargs.get('use_res', True)
+        radius_scaling = kwargs.get('radius_scaling', 2)
+        nsample_scaling = kwargs.get('nsample_scaling', 1)
+
+        self.radii = self._to_full_list(radius, radius_scaling)
+        self.nsample = self._to_full_list(nsample, nsample_scaling)
+        logging.info(f'radius: {self.radii},\n nsample: {self.nsample}')
+
+        channels = []  # width doubles at every strided stage
+        for stride in strides:
+            if stride != 1:
+                width *= 2
+            channels.append(width)
+
+        stages = []
+        for i in range(len(blocks)):
+            # like the reference, the caller's group_args object is written to (pointnext_AA.py:362-363)
+            group_args.radius = self.radii[i]
+            group_args.nsample = self.nsample[i]
+            stages.append(self._make_enc(block, channels[i], blocks[i], stride=strides[i], group_args=group_args,
+                                         is_head=i == 0 and strides[i] == 1))
+        self.encoder = nn.Sequential(*stages)
+        self.out_channels = channels[-1]
+        self.channel_list = channels
+
+    def _to_full_list(self, param, param_scaling=1):
+        """One value per block of every stage (pointnext_AA.py:374-392)."""
+        out = []
+        if isinstance(param, List):
+            for i, value in enumerate(param):
+                value = [value] if not isinstance(value, List) else value
+                if len(value) != self.blocks[i]:
+                    value += [value[-1]] * (self.blocks[i] - len(value))
+                out.append(value)
+        else:
+            for i, stride in enumerate(self.strides):
+                if stride == 1:
+                    out.append([param] * self.blocks[i])
+                else:
+                    out.append([param] + [param * param_scaling] * (self.blocks[i] - 1))
+                    param *= param_scaling
+        return out
+
+    def _make_enc(self, block, channels, blocks, stride, group_args, is_head=False):
+        radii, nsample = group_args.radius, group_args.nsample
+        group_args.radius, group_args.nsample = radii[0], nsample[0]
+        layers = [SetAbstraction(self.in_channels, channels, self.sa_layers if not is_head else 1, stride,
+                                 group_args=group_args, sampler=self.sampler, norm_args=self.norm_args,
+                                 act_args=self.act_args, conv_args=self.conv_args, is_head=is_head,
+                                 use_res=self.sa_use_res, **self.aggr_args)]
+        self.in_channels = channels
+        for i in range(1, blocks):
+            group_args.radius, group_args.nsample = radii[i], nsample[i]
+            layers.append(block(self.in_channels, aggr_args=self.aggr_args, norm_args=self.norm_args,
+                                act_args=self.act_args, group_args=group_args, conv_args=self.conv_args,
+                                expansion=self.expansion, use_res=self.use_res))
+        return nn.Sequential(*layers)
+
+    def forward_cls_feat(self, p0, f0=None):
+        if hasattr(p0, 'keys'):
+            p0, f0 = p0['pos'], p0.get('x', None)
+        if f0 is None:
+            f0 = p0.clone().transpose(1, 2).contiguous()
+        for stage in self.encoder:
+            p0, f0 = stage([p0, f0])
+        return f0.squeeze(-1)
+
+    def forward_seg_feat_ACE(self, p0, f0=None):
+        """-> p[6], f[6], stageACE_list = {'inputs', 'down', 'up'}; 'down' and 'up' are the SAME list of
+        per-stage dicts {p_out (B*n,3), f_out (B*n,C), offset int32 [B*n]} (pointnext_AA.py:439-467)."""
+        stageACE_list = {'inputs': p0}
+        if hasattr(p0, 'keys'):
+            p0, f0 = p0['pos'], p0.get('x', None)
+        if f0 is None:
+            f0 = p0.clone().transpose(1, 2).contiguous()
+        p, f, down = [p0], [f0], []
+        for i, stage in enumerate(self.encoder):
+            _p, _f = stage([p[-1], f[-1]])
+            p.append(_p)
+            f.append(_f)
+            if i != len(self.encoder) - 1:
+                flat_p = torch.flatten(_p, start_dim=0, end_dim=1)
+                flat_f = torch.flatten(_f.transpose(1, 2), start_dim=0, end_dim=1)
+                # the whole flattened batch is ONE segment: neighbours are searched across samples
+                offset = torch.tensor([flat_p.shape[0]], dtype=torch.int32, device=flat_p.device)
+                down.append({'p_out': flat_p, 'f_out': flat_f, 'offset': offset})
+        stageACE_list['down'] = down
+        stageACE_list['up'] = down  # decoder overwrites ['f_out'] in place
+        return p, f, stageACE_list
+
+    def forward(self, p0, f0=None):
+        return self.forward_seg_feat_ACE(p0, f0)
+
+
+@MODELS.register_module()
+class PointNextDecoder_AMContrast3D(nn.Module):
+    def __init__(self, encoder_channel_list: List[int], decoder_layers: int = 2, decoder_stages: int = 4,
+                 **kwargs):
+        super().__init__()
+        self.decoder_layers = decoder_layers
+        self.in_channels = encoder_channel_list[-1]
+        skip_channels = encoder_channel_list[:-1]
+        if len(skip_channels) < decoder_stages:
+            skip_channels.insert(0, kwargs.get('in_channels', 3))
+        fp_channels = encoder_channel_list[:decoder_stages]
+        n = len(fp_channels)
+        stages = [None] * n
+        for i in range(-1, -n - 1, -1):  # coarse to fine: in_channels chains through
+            stages[i] = self._make_dec(skip_channels[i], fp_channels[i])
+        self.decoder = nn.Sequential(*stages)
+        self.out_channels = fp_channels[-n]
+
+    def _make_dec(self, skip_channels, fp_channels):
+        mlp = [skip_channels + self.in_channels] + [fp_channels] * self.decoder_layers
+        self.in_channels = fp_channels
+        return nn.Sequential(FeaturePropogation(mlp))
+
+    def forward_then_ACE(self, p, f, stageACE_list):
+        for i in range(-1, -len(self.decoder) - 1, -1):
+            f[i - 1] = self.decoder[i][1:](
+                [p[i], self.decoder[i][0]([p[i - 1], f[i - 1]], [p[i], f[i]])])[1]
+            # decoder embedding of this resolution, (B*n, C) rows, for the contrastive loss
+            stageACE_list['up'][i]['f_out'] = torch.flatten(f[i - 1].transpose(1, 2), start_dim=0, end_dim=1)
+        return f[-len(self.decoder) - 1].squeeze(-1), stageACE_list
+
+    def forward(self, p, f, stageACE_list):
+        return self.forward_then_ACE(p, f, stageACE_list)

@@ -1,0 +1,116 @@
+"""1x1-conv / norm / activation block factories.
+
+Same call signatures and module nesting as the reference
+(models/layers/conv.py:8-102, norm.py:57-97, activation.py:5-51) so that
+state-dict keys are identical: a block is ``nn.Sequential(conv[, norm][, act])``
+-> ``<block>.0.weight`` (conv), ``<block>.1.{weight,bias,running_mean,...}`` (norm);
+the conv has no bias when a norm follows it.
+"""
+import copy
+
+import torch.nn as nn
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d that defaults to a 1x1 kernel when only (cin, cout) are given."""
+
+    def __init__(self, *args, **kwargs):
+        if len(args) == 2 and 'kernel_size' not in kwargs:
+            args = (*args, (1, 1))
+        super().__init__(*args, **kwargs)
+
+
+class Conv1d(nn.Conv1d):
+    """nn.Conv1d that defaults to kernel size 1 when only (cin, cout) are given."""
+
+    def __init__(self, *args, **kwargs):
+        if len(args) == 2 and 'kernel_size' not in kwargs:
+            args = (*args, 1)
+        super().__init__(*args, **kwargs)
+
+
+_NORMS = {
+    'bn1d': nn.BatchNorm1d, 'bn2d': nn.BatchNorm2d, 'bn': nn.BatchNorm2d,
+    'in1d': nn.InstanceNorm1d, 'in2d': nn.InstanceNorm2d,
+    'gn': nn.GroupNorm, 'syncbn': nn.SyncBatchNorm, 'ln': nn.LayerNorm,
+}
+
+_ACTS = {
+    'silu': nn.SiLU, 'swish': nn.SiLU, 'mish': nn.Mish, 'relu': nn.ReLU, 'relu6': nn.ReLU6,
+    'leaky_relu': nn.LeakyReLU, 'leakyrelu': nn.LeakyReLU, 'elu': nn.ELU, 'prelu': nn.PReLU,
+    'celu': nn.CELU, 'selu': nn.SELU, 'gelu': nn.GELU, 'sigmoid': nn.Sigmoid, 'tanh': nn.Tanh,
+    'hard_sigmoid': nn.Hardsigmoid, 'hard_swish': nn.Hardswish,
+}
+
+
+def create_norm(norm_args, channels, dimension=None):
+    """norm.py:74-97: 'bn' + dimension '1d'/'2d' -> BatchNorm1d/2d; extra keys are ctor kwargs."""
+    if norm_args is None:
+        return None
+    if isinstance(norm_args, dict):
+        kwargs = copy.deepcopy(dict(norm_args))
+        norm = kwargs.pop('norm', None)
+    else:
+        norm, kwargs = norm_args, {}
+    if norm is None:
+        return None
+    if isinstance(norm, str):
+        norm = norm.lower()
+        if dimension is not None:
+            dimension = str(dimension).lower()
+            if dimension not in norm:
+                norm += dimension
+        assert norm in _NORMS, f"input {norm} is not supported"
+        norm = _NORMS[norm]
+    return norm(channels, **kwargs)
+
+
+def create_act(act_args):
+    """activation.py:25-51: in-place by default (except gelu/sigmoid)."""
+    if act_args is None:
+        return None
+    act_args = {'act': act_args} if isinstance(act_args, str) else copy.deepcopy(dict(act_args))
+    act = act_args.pop('act', None)
+    if act is None:
+        return None
+    if isinstance(act, str):
+        act = act.lower()
+        assert act in _ACTS, f"input {act} is not supported"
+        layer = _ACTS[act]
+    inplace = act_args.pop('inplace', True)
+    if act in ('gelu', 'sigmoid'):
+        return layer(**act_args)
+    return layer(inplace=inplace, **act_args)
+
+
+def _convblock(conv_cls, dim, args, norm_args, act_args, order, kwargs):
+    cin, cout = args[0], args[1]
+    bias = kwargs.pop('bias', True)
+    if order not in ('conv-norm-act', 'norm-act-conv', 'conv-act-norm'):
+        raise NotImplementedError(f"{order} is not supported")
+    norm = create_norm(norm_args, cin if order == 'norm-act-conv' else cout, dimension=dim)
+    if norm is not None:
+        bias = False
+    conv = conv_cls(*args, bias=bias, **kwargs)
+    act = create_act(act_args)
+    parts = {'conv': conv, 'norm': norm, 'act': act if act_args is not None else None}
+    return nn.Sequential(*[parts[k] for k in order.split('-') if parts[k] is not None])
+
+
+def create_convblock2d(*args, norm_args=None, act_args=None, order='conv-norm-act', **kwargs):
+    return _convblock(Conv2d, '2d', args, norm_args, act_args, order, kwargs)
+
+
+def create_convblock1d(*args, norm_args=None, act_args=None, order='conv-norm-act', **kwargs):
+    return _convblock(Conv1d, '1d', args, norm_args, act_args, order, kwargs)
+
+
+# input width of the first grouped conv for each neighbourhood feature recipe
+# (models/layers/local_aggregation.py:13-29)
+CHANNEL_MAP = {
+    'fj': lambda x: x, 'df': lambda x: x, 'assa': lambda x: x * 3, 'assa_dp': lambda x: x * 3 + 3,
+    'dp_fj': lambda x: 3 + x, 'pj': lambda x: x, 'dp': lambda x: 3, 'pi_dp': lambda x: x + 3,
+    'pj_dp': lambda x: x + 3, 'dp_fj_df': lambda x: x * 2 + 3, 'dp_fi_df': lambda x: x * 2 + 3,
+    'pi_dp_fj_df': lambda x: x * 2 + 6, 'pj_dp_fj_df': lambda x: x * 2 + 6, 'pj_dp_df': lambda x: x + 6,
+    'dp_df': lambda x: x + 3,
+}

@@ -1,0 +1,86 @@
+"""Segmentation wrapper and head.
+
+Drop-in for openpoints/models/segmentation/base_seg.py:
+    BaseSeg_AMContrast3D   :97-126   encoder -> decoder -> head, returns (logits, stageACE_list)
+    SegHead                :207-267  Conv1d+BN+ReLU(+Dropout) ... Conv1d, optional global max/avg concat
+"""
+import copy
+import logging
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from ..build import MODELS, build_model_from_cfg
+from ..layers import create_convblock1d
+
+
+@MODELS.register_module()
+class BaseSeg_AMContrast3D(nn.Module):
+    def __init__(self, encoder_args=None, decoder_args=None, cls_args=None, **kwargs):
+        super().__init__()
+        self.encoder = build_model_from_cfg(encoder_args)
+        if decoder_args is not None:
+            merged = copy.deepcopy(encoder_args)  # decoder sees the encoder's kwargs too (base_seg.py:103-106)
+            merged.update(decoder_args)
+            merged.encoder_channel_list = self.encoder.channel_list if hasattr(self.encoder, 'channel_list') else None
+            self.decoder = build_model_from_cfg(merged)
+        else:
+            self.decoder = None
+
+        if cls_args is not None:
+            if hasattr(self.decoder, 'out_channels'):
+                in_channels = self.decoder.out_channels
+            elif hasattr(self.encoder, 'out_channels'):
+                in_channels = self.encoder.out_channels
+            else:
+                in_channels = cls_args.get('in_channels', None)
+            cls_args.in_channels = in_channels  # written back into the caller's cfg, as the reference does
+            self.head = build_model_from_cfg(cls_args)
+        else:
+            self.head = None
+
+    def forward(self, data):
+        p, f, stageACE_list = self.encoder.forward(data)
+        f, stageACE_list = self.decoder.forward(p, f, stageACE_list)
+        return self.head(f), stageACE_list
+
+
+@MODELS.register_module()
+class SegHead(nn.Module):
+    def __init__(self, num_classes, in_channels, mlps=None, norm_args={'norm': 'bn1d'}, act_args={'act': 'relu'},
+                 dropout=0.5, global_feat=None, **kwargs):
+        super().__init__()
+        if kwargs:
+            logging.warning(f"kwargs: {kwargs} are not used in {__class__.__name__}")
+        if global_feat is not None:
+            self.global_feat = global_feat.split(',')
+            in_channels *= len(self.global_feat) + 1
+        else:
+            self.global_feat = None
+
+        if mlps is None:
+            mlps = [in_channels, in_channels] + [num_classes]
+        else:
+            if not isinstance(mlps, List):
+                mlps = [mlps]
+            mlps = [in_channels] + mlps + [num_classes]
+        heads = []
+        for i in range(len(mlps) - 2):
+            heads.append(create_convblock1d(mlps[i], mlps[i + 1], norm_args=norm_args, act_args=act_args))
+            if dropout:
+                heads.append(nn.Dropout(dropout))
+        heads.append(create_convblock1d(mlps[-2], mlps[-1], act_args=None))
+        self.head = nn.Sequential(*heads)
+
+    def forward(self, end_points):
+        if self.global_feat is not None:
+            g = []
+            for kind in self.global_feat:
+                if 'max' in kind:
+                    g.append(torch.max(end_points, dim=-1, keepdim=True)[0])
+                elif kind in ['avg', 'mean']:
+                    g.append(torch.mean(end_points, dim=-1, keepdim=True))
+            g = torch.cat(g, dim=1).expand(-1, -1, end_points.shape[-1])
+            end_points = torch.cat((end_points, g), dim=1)
+        return self.head(end_points)

@@ -1,0 +1,251 @@
+"""Point operators on MI355X: torch.autograd front-ends over the C-ABI (include/amc3d.h).
+
+These mirror, name for name, the reference's Python wrappers of its CUDA
+extensions (argument meaning, dtypes, shapes, contiguity asserts, outputs):
+
+    ball_query, grouping_operation, gather_operation   openpoints/models/layers/group.py:76-203
+    furthest_point_sample                               openpoints/models/layers/subsample.py:76-106
+    three_nn, three_interpolate, three_interpolation    openpoints/models/layers/upsampling.py:11-102
+    knnquery                                            openpoints/cpp/pointops/functions/pointops.py:32-56
+
+PyTorch is only plumbing here (device memory, the current HIP stream, autograd
+bookkeeping); every operator runs a hand-written gfx950 kernel.  CPU tensors are
+rejected: there is no fallback path.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise RuntimeError("amcontrast3d_amd operators run on the GPU only (got a %s tensor); "
+                               "there is no CPU fallback" % t.device)
+
+
+class BallQuery(Function):
+    @staticmethod
+    def forward(ctx, radius, nsample, xyz, new_xyz):
+        """xyz (B,N,3) support, new_xyz (B,npoint,3) centres -> idx (B,npoint,nsample) int32"""
+        assert new_xyz.is_contiguous()
+        assert xyz.is_contiguous()
+        _need_gpu(xyz, new_xyz)
+        B, N, _ = xyz.size()
+        npoint = new_xyz.size(1)
+        idx = torch.empty(B, npoint, nsample, dtype=torch.int32, device=xyz.device)
+        with torch.cuda.device(xyz.device):
+            _lib.check(_lib.load().amc3d_ball_query(B, N, npoint, float(radius), int(nsample), _ptr(new_xyz),
+                                                    _ptr(xyz), _ptr(idx), _stream(xyz)), "ball_query")
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None
+
+
+ball_query = BallQuery.apply
+
+
+class GroupingOperation(Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, features, idx):
+        """features (B,C,N), idx (B,npoint,nsample) int32 -> (B,C,npoint,nsample)"""
+        assert features.is_contiguous()
+        assert idx.is_contiguous()
+        _need_gpu(features, idx)
+        B, nfeatures, nsample = idx.size()
+        _, C, N = features.size()
+        output = torch.empty(B, C, nfeatures, nsample, dtype=torch.float32, device=features.device)
+        with torch.cuda.device(features.device):
+            _lib.check(_lib.load().amc3d_group_points(B, C, N, nfeatures, nsample, _ptr(features), _ptr(idx),
+                                                      _ptr(output), _stream(features)), "group_points")
+        ctx.for_backwards = (idx, N)
+        return output
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, grad_out):
+        idx, N = ctx.for_backwards
+        B, C, npoint, nsample = grad_out.size()
+        grad_features = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
+        grad_out_data = grad_out.detach().contiguous()
+        with torch.cuda.device(grad_out.device):
+            _lib.check(_lib.load().amc3d_group_points_grad(B, C, N, npoint, nsample, _ptr(grad_out_data), _ptr(idx),
+                                                           _ptr(grad_features), _stream(grad_out)), "group_points_grad")
+        return grad_features, None
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class GatherOperation(Function):
+    @staticmethod
+    def forward(ctx, features, idx):
+        """features (B,C,N), idx (B,npoint) int32 -> (B,C,npoint)"""
+        assert features.is_contiguous()
+        assert idx.is_contiguous()
+        _need_gpu(features, idx)
+        B, npoint = idx.size()
+        _, C, N = features.size()
+        output = torch.empty(B, C, npoint, dtype=torch.float32, device=features.device)
+        with torch.cuda.device(features.device):
+            _lib.check(_lib.load().amc3d_gather_points(B, C, N, npoint, _ptr(features), _ptr(idx), _ptr(output),
+                                                       _stream(features)), "gather_points")
+        ctx.for_backwards = (idx, C, N)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, C, N = ctx.for_backwards
+        B, npoint = idx.size()
+        grad_features = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
+        grad_out_data = grad_out.detach().contiguous()
+        with torch.cuda.device(grad_out.device):
+            _lib.check(_lib.load().amc3d_gather_points_grad(B, C, N, npoint, _ptr(grad_out_data), _ptr(idx),
+                                                            _ptr(grad_features), _stream(grad_out)), "gather_points_grad")
+        return grad_features, None
+
+
+gather_operation = GatherOperation.apply
+
+
+class FurthestPointSampling(Function):
+    @staticmethod
+    def forward(ctx, xyz, npoint):
+        """xyz (B,N,3) -> (B,npoint) int32, first index 0"""
+        assert xyz.is_contiguous()
+        _need_gpu(xyz)
+        B, N, _ = xyz.size()
+        output = torch.empty(B, npoint, dtype=torch.int32, device=xyz.device)
+        # the reference's (B,N) scratch of running minima (filled with 1e10) stays on chip
+        # for N <= 24576; larger clouds get the buffer
+        temp = None
+        if N > 24576:
+            temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
+        with torch.cuda.device(xyz.device):
+            _lib.check(_lib.load().amc3d_furthest_point_sampling(B, N, int(npoint), _ptr(xyz),
+                                                                 _ptr(temp) if temp is not None else None,
+                                                                 _ptr(output), _stream(xyz)), "furthest_point_sampling")
+        ctx.mark_non_differentiable(output)
+        return output
+
+    @staticmethod
+    def backward(xyz, a=None):
+        return None, None
+
+
+furthest_point_sample = FurthestPointSampling.apply
+
+
+class ThreeNN(Function):
+    @staticmethod
+    def forward(ctx, unknown, known):
+        """unknown (B,N,3), known (B,M,3) -> dist (B,N,3) (euclidean, not squared), idx (B,N,3) int32"""
+        assert unknown.is_contiguous()
+        assert known.is_contiguous()
+        _need_gpu(unknown, known)
+        B, N, _ = unknown.size()
+        m = known.size(1)
+        dist2 = torch.empty(B, N, 3, dtype=torch.float32, device=unknown.device)
+        idx = torch.empty(B, N, 3, dtype=torch.int32, device=unknown.device)
+        with torch.cuda.device(unknown.device):
+            _lib.check(_lib.load().amc3d_three_nn(B, N, m, _ptr(unknown), _ptr(known), _ptr(dist2), _ptr(idx),
+                                                  _stream(unknown)), "three_nn")
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, features, idx, weight):
+        """features (B,C,M), idx (B,n,3) int32, weight (B,n,3) -> (B,C,n)"""
+        assert features.is_contiguous()
+        assert idx.is_contiguous()
+        assert weight.is_contiguous()
+        _need_gpu(features, idx, weight)
+        B, c, m = features.size()
+        n = idx.size(1)
+        ctx.three_interpolate_for_backward = (idx, weight, m)
+        output = torch.empty(B, c, n, dtype=torch.float32, device=features.device)
+        with torch.cuda.device(features.device):
+            _lib.check(_lib.load().amc3d_three_interpolate(B, c, m, n, _ptr(features), _ptr(idx), _ptr(weight),
+                                                           _ptr(output), _stream(features)), "three_interpolate")
+        return output
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, grad_out):
+        idx, weight, m = ctx.three_interpolate_for_backward
+        B, c, n = grad_out.size()
+        grad_features = torch.zeros(B, c, m, dtype=torch.float32, device=grad_out.device)
+        grad_out_data = grad_out.detach().contiguous()
+        with torch.cuda.device(grad_out.device):
+            _lib.check(_lib.load().amc3d_three_interpolate_grad(B, c, n, m, _ptr(grad_out_data), _ptr(idx),
+                                                                _ptr(weight), _ptr(grad_features),
+                                                                _stream(grad_out)), "three_interpolate_grad")
+        return grad_features, None, None
+
+
+three_interpolate = ThreeInterpolate.apply
+
+
+def three_interpolation(unknown_xyz, known_xyz, know_feat):
+    """Inverse-distance 3-NN interpolation (upsampling.py:92-102)."""
+    dist, idx = three_nn(unknown_xyz, known_xyz)
+    dist_recip = 1.0 / (dist + 1e-8)
+    norm = torch.sum(dist_recip, dim=2, keepdim=True)
+    weight = dist_recip / norm
+    return three_interpolate(know_feat, idx, weight)
+
+
+class KNNQuery(Function):
+    @staticmethod
+    def forward(ctx, nsample, xyz, new_xyz, offset, new_offset):
+        """xyz (n,3), new_xyz (m,3), offset/new_offset (b) int32 cumulative ends
+        -> idx (m,nsample) int32, dist (m,nsample) (euclidean)"""
+        if new_xyz is None:
+            new_xyz = xyz
+        assert xyz.is_contiguous() and new_xyz.is_contiguous()
+        _need_gpu(xyz, new_xyz, offset, new_offset)
+        nsample = int(nsample)
+        n, m, nb = xyz.shape[0], new_xyz.shape[0], offset.shape[0]
+        idx = torch.empty(m, nsample, dtype=torch.int32, device=xyz.device)
+        dist2 = torch.empty(m, nsample, dtype=torch.float32, device=xyz.device)
+        lib = _lib.load()
+        wbytes = int(lib.amc3d_knnquery_workspace_bytes(n, m, nsample, nb))
+        work = torch.empty(wbytes, dtype=torch.uint8, device=xyz.device)
+        with torch.cuda.device(xyz.device):
+            _lib.check(lib.amc3d_knnquery(m, nsample, n, nb, _ptr(xyz), _ptr(new_xyz), _ptr(offset.contiguous()),
+                                          _ptr(new_offset.contiguous()), _ptr(idx), _ptr(dist2), _ptr(work), wbytes,
+                                          _stream(xyz)), "knnquery")
+        ctx.mark_non_differentiable(idx)
+        return idx, torch.sqrt(dist2)
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None, None, None, None
+
+
+knnquery = KNNQuery.apply

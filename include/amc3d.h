@@ -1,0 +1,116 @@
+/*
+ * amc3d.h -- C-ABI of libamc3d_hip.so, the MI355X (gfx950) implementation of the
+ * native point operators on AMContrast3D's training hot path.
+ *
+ * Drop-in boundary.  The reference binds its native layer through two pybind11
+ * modules whose entry points take torch tensors and forward raw data pointers:
+ *     pointnet2_batch_cuda  openpoints/cpp/pointnet2_batch/src/pointnet2_api.cpp:10-24
+ *     pointops_cuda         openpoints/cpp/pointops/src/pointops_api.cpp:13-25
+ * Each function below replaces the launcher behind one of those entry points
+ * and keeps its argument order; tensors become plain device pointers and every
+ * call gains a trailing `stream` (a hipStream_t passed as void*; NULL = the
+ * null stream).  No torch type appears in any signature.  INTEGRATION.md shows
+ * the ctypes stub that rebinds the reference's Python wrappers onto this ABI.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in `_host`;
+ *   - float = IEEE fp32, indices = int32, layouts exactly as in the reference
+ *     (dense row-major, batch first);
+ *   - return value: 0 on success, otherwise the hipError_t of the failed
+ *     launch/argument check (the reference prints and exit(-1)s instead:
+ *     ball_query_gpu.cu:68-71); nothing is thrown, nothing is allocated, and
+ *     no call synchronises the device -- they are graph-capturable;
+ *   - functions that need scratch memory take a caller-owned `workspace`
+ *     whose size is reported by the matching *_workspace_bytes() query.
+ *   - distances are evaluated exactly as the reference writes them, in fp32,
+ *     left to right and without FMA contraction: ((dx*dx + dy*dy) + dz*dz).
+ */
+#ifndef AMC3D_H
+#define AMC3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* library identification: "amc3d-hip gfx950 <abi-version>" */
+const char *amc3d_version(void);
+/* text of the last error on this thread ("" if none) */
+const char *amc3d_last_error(void);
+
+/* ---- pointnet2_batch surface ------------------------------------------------ */
+
+/* replaces ball_query_wrapper_fast -> ball_query_kernel_launcher_fast
+ * (pointnet2_batch/src/ball_query.cpp:29-39, ball_query_gpu.cu:54-73).
+ * new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample): the first `nsample`
+ * support indices (ascending) with d2 < radius*radius, padded with the first
+ * hit; a row with no hit is written as zeros (the reference relies on the
+ * caller's zero-fill, group.py:194). */
+int amc3d_ball_query(int b, int n, int m, float radius, int nsample,
+                     const float *new_xyz, const float *xyz, int *idx, void *stream);
+
+/* replaces group_points_wrapper_fast (group_points.cpp, group_points_gpu.cu:53-92):
+ * points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample) */
+int amc3d_group_points(int b, int c, int n, int npoints, int nsample,
+                       const float *points, const int *idx, float *out, void *stream);
+
+/* replaces group_points_grad_wrapper_fast (group_points_gpu.cu:14-50):
+ * grad_points (b,c,n) += scatter(grad_out (b,c,npoints,nsample)); the caller
+ * zero-initialises grad_points (group.py:111). */
+int amc3d_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                            const float *grad_out, const int *idx, float *grad_points, void *stream);
+
+/* replaces gather_points_wrapper_fast / gather_points_grad_wrapper_fast
+ * (sampling_gpu.cu:15-90): points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */
+int amc3d_gather_points(int b, int c, int n, int npoints,
+                        const float *points, const int *idx, float *out, void *stream);
+int amc3d_gather_points_grad(int b, int c, int n, int npoints,
+                             const float *grad_out, const int *idx, float *grad_points, void *stream);
+
+/* replaces furthest_point_sampling_wrapper (sampling.cpp, sampling_gpu.cu:100-260):
+ * dataset (b,n,3) -> idxs (b,m), idxs[:,0] = 0.  `temp` (b,n) is the reference's
+ * running-min-distance scratch (the caller fills it with 1e10, subsample.py:95);
+ * it may be NULL: this implementation keeps the running minimum on chip and only
+ * writes it back when a buffer is given.  Ties resolve exactly as the
+ * reference's block-strided scan + shared-memory tree does for its block size
+ * opt_n_threads(n) (cuda_utils.h:10-14). */
+int amc3d_furthest_point_sampling(int b, int n, int m, const float *dataset,
+                                  float *temp, int *idxs, void *stream);
+
+/* replaces three_nn_wrapper_fast (interpolate_gpu.cu:16-81):
+ * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) squared distances, idx (b,n,3) */
+int amc3d_three_nn(int b, int n, int m, const float *unknown, const float *known,
+                   float *dist2, int *idx, void *stream);
+
+/* replaces three_interpolate_wrapper_fast (interpolate_gpu.cu:84-124):
+ * points (b,c,m), idx/weight (b,n,3) -> out (b,c,n) */
+int amc3d_three_interpolate(int b, int c, int m, int n, const float *points,
+                            const int *idx, const float *weight, float *out, void *stream);
+
+/* replaces three_interpolate_grad_wrapper_fast (interpolate_gpu.cu:127-169):
+ * grad_points (b,c,m) += ...; caller zero-initialises (upsampling.py:82). */
+int amc3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                                 const int *idx, const float *weight, float *grad_points, void *stream);
+
+/* ---- pointops surface --------------------------------------------------------- */
+
+/* replaces knnquery_cuda -> knnquery_cuda_launcher
+ * (pointops/src/knnquery/knnquery_cuda.cpp:7-16, knnquery_cuda_kernel.cu:65-108).
+ * xyz (n,3) support, new_xyz (m,3) queries, offset / new_offset: cumulative
+ * segment ends (nbatch entries each; the reference does not pass nbatch, it
+ * walks new_offset until it exceeds the query id -- pass it here).
+ * -> idx (m,nsample), dist2 (m,nsample) squared distances, ascending.
+ * nsample <= 100 (the reference's per-thread heap is float[100]).
+ * Results equal the reference's max-heap + heap-sort including how equal
+ * distances are ordered. */
+size_t amc3d_knnquery_workspace_bytes(int n, int m, int nsample, int nbatch);
+int amc3d_knnquery(int m, int nsample, int n, int nbatch, const float *xyz, const float *new_xyz,
+                   const int *offset, const int *new_offset, int *idx, float *dist2,
+                   void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMC3D_H */

@@ -1,0 +1,212 @@
+"""ORACLE -- generates tests/golden/*.npz by RUNNING THE REFERENCE (build container only).
+
+    python oracle/gen_golden.py            # rewrites every fixture
+
+The reference's own Python layer -- openpoints.models (BaseSeg_AMContrast3D, PointNeXt
+encoder/decoder, SegHead), openpoints.models.layers (QueryAndGroup, three_interpolation,
+furthest_point_sample, ...), openpoints.loss.CrossEntropyAce and
+openpoints.AMContrast3D (ContrastHead, ambiguity_function, get_subscene_label_CBL) -- is
+imported read-only from /root/reference (oracle/refshim.py) and executed on the CPU with
+the C restatement of its CUDA kernels (oracle/pointops_ref.c) underneath.  What is stored
+are inputs and the reference's outputs: data, never code.  The fixtures pin
+  * the oracle's model/loss restatement (oracle/model_ref.py)   [tests, CPU]
+  * the product (amcontrast3d_amd + HIP kernels)                [tests, GPU]
+The native kernels themselves cannot be run from the reference (CUDA only); their
+restatement is pinned by the brute-force cross-checks in tests/test_oracle_ops.py.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from oracle import refshim  # noqa: E402
+
+refshim.load_reference()
+
+from openpoints.loss import build_criterion_from_cfg  # noqa: E402  (reference)
+from openpoints.models import build_model_from_cfg  # noqa: E402  (reference)
+from openpoints.models.layers import (furthest_point_sample, three_interpolation, three_nn)  # noqa: E402
+from openpoints.models.layers.group import QueryAndGroup, ball_query, grouping_operation  # noqa: E402
+from openpoints.cpp.pointops.functions import pointops  # noqa: E402
+from openpoints.utils import EasyConfig  # noqa: E402
+from openpoints.AMContrast3D.AEF.ambiguity import ambiguity_function  # noqa: E402
+
+from amcontrast3d_amd import configs, synthetic  # noqa: E402  (plain dict/numpy helpers only)
+
+torch.set_num_threads(8)
+
+
+def cfg_of(d):
+    c = EasyConfig()
+    c.update(d)
+    return c
+
+
+def tensor_batch(batch):
+    return {"pos": torch.from_numpy(batch["pos"]), "x": torch.from_numpy(batch["x"]), "y": torch.from_numpy(batch["y"])}
+
+
+def param_checksums(model):
+    return {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in model.state_dict().items()
+            if v.dtype.is_floating_point}
+
+
+def run_model_case(name, variant, B, N, num_classes=13, in_channels=4, dataset="s3dis", ignore_index=None,
+                   ignore_frac=0.0, store_weights=False, grad_keys=(), voxel_size=0.04, **model_kw):
+    """One forward + loss + backward of the reference; everything a parity test needs goes in the .npz."""
+    torch.manual_seed(0)
+    mcfg = cfg_of(configs.model_cfg(variant, num_classes=num_classes, in_channels=in_channels, dropout=0, **model_kw))
+    model = build_model_from_cfg(mcfg)
+    model.train()
+    criterion = build_criterion_from_cfg(cfg_of(configs.criterion_cfg()))
+    aargs = cfg_of(configs.ambiguity_args(dataset))
+
+    nb = synthetic.make_batch(B, N, first_id=100, num_classes=num_classes, ignore_frac=ignore_frac,
+                              voxel_size=voxel_size)
+    if in_channels == 7:  # ScanNet feature_keys 'pos,x,heights' (cfgs/scannet/default.yaml:21)
+        nb["x"] = np.ascontiguousarray(np.concatenate([nb["pos"].transpose(0, 2, 1), nb["x"]], 1))
+    data = tensor_batch(nb)
+    target = data["y"]
+
+    out = {"pos": nb["pos"], "x": nb["x"], "y": nb["y"]}
+    sums = param_checksums(model)
+    if store_weights:
+        for k, v in model.state_dict().items():
+            out["w/" + k] = v.numpy().copy()
+
+    logits, stage = model(data)
+    loss = criterion(logits, target, stage, num_classes, ignore_index, aargs)
+    loss.backward()
+
+    out["logits"] = logits.detach().numpy()
+    out["loss"] = np.float64(loss.item())
+    ce = torch.nn.CrossEntropyLoss()(logits.transpose(1, 2).reshape(-1, logits.shape[1]), target.flatten())
+    out["loss_ce"] = np.float64(ce.item())
+    head = criterion.contrast_head
+    for i in range(aargs.stages_num):
+        li, _, ai = head.main_contrast(aargs.stages, i, stage, target.flatten(), num_classes, ignore_index, aargs)
+        out[f"contrast/{i}"] = np.float64(li.item())
+        out[f"ambiguity/{i}"] = ai.detach().numpy()
+        out[f"p_out/{i}"] = stage["up"][i]["p_out"].detach().numpy()
+        out[f"f_out/{i}"] = stage["up"][i]["f_out"].detach().numpy()
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    out["grad_abs_sum"] = np.float64(sum(float(g.double().abs().sum()) for g in grads.values()))
+    for k in grad_keys:
+        out["g/" + k] = grads[k].numpy().copy()
+    gn = {k: float(g.double().norm()) for k, g in grads.items()}
+    meta = {"variant": variant, "B": B, "N": N, "num_classes": num_classes, "in_channels": in_channels,
+            "dataset": dataset, "ignore_index": ignore_index, "ignore_frac": ignore_frac, "voxel_size": voxel_size,
+            "model_kw": model_kw,
+            "param_checksums": sums, "grad_norms": gn, "torch": torch.__version__}
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={loss.item():.6f} ce={ce.item():.6f} "
+          + " ".join(f"c{i}={out[f'contrast/{i}']:.5f}" for i in range(aargs.stages_num)),
+          f"({os.path.getsize(os.path.join(OUT, name + '.npz')) / 1e6:.2f} MB)")
+
+
+def run_ops_case():
+    """The reference's Python wrappers on small clouds, including tie-heavy ones."""
+    rng = np.random.default_rng(7)
+    out = {}
+    # -- clouds: a synthetic room crop, an integer lattice (many exact distance ties), duplicates --
+    room = synthetic.make_batch(2, 512, first_id=7)["pos"]
+    lattice = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij"), -1).reshape(-1, 3)
+    lattice = np.stack([lattice[rng.permutation(512)] for _ in range(2)]).astype(np.float32) * 0.25
+    dup = room.copy()
+    dup[:, 256:] = dup[:, :256]  # every point appears twice
+    for tag, cloud, radius in (("room", room, 0.2), ("lattice", lattice, 0.5), ("dup", dup, 0.2)):
+        xyz = torch.from_numpy(np.ascontiguousarray(cloud))
+        B, N, _ = xyz.shape
+        out[f"{tag}/xyz"] = cloud
+        fidx = furthest_point_sample(xyz, N // 4)
+        out[f"{tag}/fps"] = fidx.numpy()
+        new_xyz = torch.gather(xyz, 1, fidx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        out[f"{tag}/ball"] = ball_query(radius, 32, xyz, new_xyz).numpy()
+        out[f"{tag}/ball_radius"] = np.float32(radius)
+        feats = torch.from_numpy(rng.standard_normal((B, 5, N)).astype(np.float32))
+        out[f"{tag}/feats"] = feats.numpy()
+        dp, fj = QueryAndGroup(radius, 32, normalize_dp=True)(new_xyz, xyz, feats)
+        out[f"{tag}/group_dp"] = dp.numpy()
+        out[f"{tag}/group_fj"] = fj.numpy()
+        d, i3 = three_nn(xyz, new_xyz)
+        out[f"{tag}/three_nn_dist"] = d.numpy()
+        out[f"{tag}/three_nn_idx"] = i3.numpy()
+        cf = torch.from_numpy(rng.standard_normal((B, 5, N // 4)).astype(np.float32))
+        out[f"{tag}/coarse_feats"] = cf.numpy()
+        out[f"{tag}/interp"] = three_interpolation(xyz, new_xyz, cf).numpy()
+        # k-NN over the flattened batch as ONE segment (pointnext_AA.py:459-462) and as B segments
+        flat = xyz.reshape(-1, 3).contiguous()
+        one = torch.tensor([B * N], dtype=torch.int32)
+        per = torch.tensor([N * (b + 1) for b in range(B)], dtype=torch.int32)
+        for seg_tag, off in (("one", one), ("per", per)):
+            idx, dist = pointops.knnquery(24, flat, flat, off, off)
+            out[f"{tag}/knn24_{seg_tag}_idx"] = idx.numpy()
+            out[f"{tag}/knn24_{seg_tag}_dist"] = dist.numpy()
+        q = new_xyz.reshape(-1, 3).contiguous()
+        qone = torch.tensor([q.shape[0]], dtype=torch.int32)
+        idx, dist = pointops.knnquery(64, flat, q, one, qone)
+        out[f"{tag}/knn64_idx"] = idx.numpy()
+        out[f"{tag}/knn64_dist"] = dist.numpy()
+    # -- grouping gradient (atomics in the reference; ascending order in the restatement) --
+    xyz = torch.from_numpy(np.ascontiguousarray(room))
+    fidx = furthest_point_sample(xyz, 128)
+    new_xyz = torch.gather(xyz, 1, fidx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    idx = ball_query(0.2, 32, xyz, new_xyz)
+    feats = torch.from_numpy(rng.standard_normal((2, 6, 512)).astype(np.float32)).requires_grad_(True)
+    g = torch.from_numpy(rng.standard_normal((2, 6, 128, 32)).astype(np.float32))
+    grouping_operation(feats, idx).backward(g)
+    out["grad/feats"], out["grad/g"], out["grad/idx"] = feats.detach().numpy(), g.numpy(), idx.numpy()
+    out["grad/group_grad"] = feats.grad.numpy()
+    # -- ambiguity function on a labelled room (reference loop :32-35 included) --
+    sc = synthetic.make_scene(3, 3000)
+    p = torch.from_numpy(sc["pos"])
+    lab = torch.from_numpy(sc["y"])
+    off = torch.tensor([3000], dtype=torch.int32)
+    nidx, _ = pointops.knnquery(24, p, p, off, off)
+    nidx = nidx[:, 1:].contiguous()
+    posmask = lab[:, None] == lab[nidx.long()]
+    a, shares = ambiguity_function(p, posmask, 23, nidx, "Method2", 0.04, False, 0.5)
+    out["amb/p"], out["amb/label"], out["amb/nidx"] = sc["pos"], sc["y"], nidx.numpy()
+    out["amb/a"] = a.numpy()
+    out["amb/shares"] = np.array(shares, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "ops_small.npz"), **out)
+    print("ops_small:", len(out), "arrays,", os.path.getsize(os.path.join(OUT, "ops_small.npz")) / 1e6, "MB")
+
+
+def run_state_keys():
+    keys = {}
+    for variant in ("S", "B", "L", "XL"):
+        model = build_model_from_cfg(cfg_of(configs.model_cfg(variant)))
+        keys[variant] = {k: list(v.shape) for k, v in model.state_dict().items()}
+        keys[variant + "_nparams"] = sum(p.numel() for p in model.parameters())
+    sc = build_model_from_cfg(cfg_of(configs.model_cfg("S", num_classes=20, in_channels=7, global_feat="max")))
+    keys["S_scannet"] = {k: list(v.shape) for k, v in sc.state_dict().items()}
+    with open(os.path.join(OUT, "state_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+    print("state_keys:", {k: (v if isinstance(v, int) else len(v)) for k, v in keys.items()})
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    run_state_keys()
+    run_ops_case()
+    G = ["encoder.encoder.0.0.convs.0.0.weight", "encoder.encoder.1.0.convs.0.0.weight",
+         "encoder.encoder.4.0.convs.1.1.weight", "decoder.decoder.0.0.convs.0.0.weight", "head.head.1.0.weight"]
+    # PointNeXt-S, seed-0 init (weights re-created from the seed; checksums stored)
+    run_model_case("model_S_b2_n2048", "S", 2, 2048, grad_keys=G)
+    # BASELINE config 1 shape: S, B=2, N=4096
+    run_model_case("model_S_b2_n4096", "S", 2, 4096, grad_keys=G[:2])
+    # narrow model with InvResMLP blocks and stored weights (independent of RNG streams)
+    run_model_case("model_w8_blocks_b2_n1024", "L", 2, 1024, width=8, blocks=[1, 2, 2, 1, 1], store_weights=True,
+                   grad_keys=["encoder.encoder.1.1.convs.convs.0.0.weight", "encoder.encoder.2.1.pwconv.1.0.weight"])
+    # ScanNet-shaped: 20 classes + ignore_index -100, 7 input channels, global max feature in the head
+    run_model_case("model_S_scannet_b2_n2048", "S", 2, 2048, num_classes=20, in_channels=7, dataset="scannet",
+                   ignore_index=-100, ignore_frac=0.05, voxel_size=0.02, global_feat="max", grad_keys=G[:1])
