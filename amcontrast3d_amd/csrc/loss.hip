@@ -1,0 +1,378 @@
+// Adaptive-margin contrastive loss kernels for gfx950.
+//
+// The reference evaluates this part of the path as a few dozen torch ops per stage plus a Python
+// loop (AMContrast3D/MarginContrast.py:220-259, AEF/ambiguity.py:11-93, AEF/utils.py:11-43),
+// materialising (m,23,ncls) and (m,23,C) neighbour tensors.  Here it is five kernels per stage
+// that read the stage's xyz / labels / embeddings through the k-NN index and write per-point
+// scalars; nothing of size m*k*C is ever stored.
+//
+// Arithmetic follows the reference's CPU evaluation where it is sensitive:
+//  * squared distances for d+/d- use the expanded form of AEF/function.py:18-39,
+//    ((-2*(x x' + y y' + z z')) + |p|^2) + |p'|^2 in fp32 without FMA and in that order --
+//    the form cancels catastrophically for close points (relative error up to 1e-1), and the
+//    ambiguity a_i is a steep function of it, so a "more accurate" distance would NOT match;
+//  * cosine similarity is sum_c (f_i[c]/max(|f_i|,eps)) * (f_j[c]/max(|f_j|,eps)), the form
+//    torch 2.x's F.cosine_similarity evaluates (MarginContrast.py:77-79).
+#include "common.h"
+
+namespace amc {
+
+// ---------------------------------------------------------------------------------------------
+// Sub-sampled stage labels: arg-max of the mean one-hot label of the kr nearest full-resolution
+// points (AEF/utils.py:29-41) followed by the arg-max of MarginContrast.py:111-113 -- i.e. the
+// majority class, lowest class id on equal counts.  One wavefront per point; lanes hold the
+// neighbours' classes, one __ballot per class counts them.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vote_labels_kernel(int m, int kr, int ncls, const int *__restrict__ labels0,
+                                                          const int *__restrict__ nbr, int *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= m) return;
+    int c0 = -1, c1 = -1;  // kr <= 128
+    if (lane < kr) c0 = labels0[nbr[(size_t)q * kr + lane]];
+    if (lane + 64 < kr) c1 = labels0[nbr[(size_t)q * kr + lane + 64]];
+    int best = -1, bestc = 0;
+    for (int c = 0; c < ncls; ++c) {
+        const int cnt = (int)__popcll(__ballot(c0 == c)) + (int)__popcll(__ballot(c1 == c));
+        if (cnt > best) { best = cnt; bestc = c; }
+    }
+    if (lane == 0) out[q] = bestc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Neighbourhood statistics of every point (MarginContrast.py:228-231, ambiguity.py:12,18-21,26-39):
+// n+ = #neighbours of the same class, d+/d- = summed "squared distances" to the same-/other-class
+// neighbours, and the global max of n+ (ambiguity.py:13 divides by it).
+// nbr points at the first kept column of the (m, nbr_stride) k-NN index (the self match in
+// column 0 is skipped by the caller's pointer offset, MarginContrast.py:225-226).
+// ---------------------------------------------------------------------------------------------
+// posmask[i,j] = (class of neighbour j) == (class of i)   (MarginContrast.py:111-115, 228-230)
+__global__ void posmask_kernel(int m, int k, int nbr_stride, const int *__restrict__ labels,
+                               const int *__restrict__ nbr, unsigned char *__restrict__ posmask)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)m * k) return;
+    const int i = (int)(t / k), j = (int)(t - (size_t)i * k);
+    posmask[t] = labels[nbr[(size_t)i * nbr_stride + j]] == labels[i] ? 1 : 0;
+}
+
+// mode: 1 = constant distance 5 (cctype Method1), 2 = "squared distance" (Method2), 3 = its root (Method3)
+__global__ __launch_bounds__(256) void ambiguity_stats_kernel(int m, int k, int nbr_stride, int mode,
+                                                              const float *__restrict__ p,
+                                                              const unsigned char *__restrict__ posmask,
+                                                              const int *__restrict__ nbr, int *__restrict__ n_pos,
+                                                              float *__restrict__ d_pos, float *__restrict__ d_neg,
+                                                              int *__restrict__ max_npos)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int np = 0;
+    if (i < m) {
+        const float px = p[(size_t)i * 3], py = p[(size_t)i * 3 + 1], pz = p[(size_t)i * 3 + 2];
+        const float ss = __fadd_rn(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py)), __fmul_rn(pz, pz));
+        float dp = 0.f, dn = 0.f;
+        for (int j = 0; j < k; ++j) {
+            const int nb = nbr[(size_t)i * nbr_stride + j];
+            const float qx = p[(size_t)nb * 3], qy = p[(size_t)nb * 3 + 1], qz = p[(size_t)nb * 3 + 2];
+            const float dot = __fadd_rn(__fadd_rn(__fmul_rn(px, qx), __fmul_rn(py, qy)), __fmul_rn(pz, qz));
+            const float sd = __fadd_rn(__fadd_rn(__fmul_rn(qx, qx), __fmul_rn(qy, qy)), __fmul_rn(qz, qz));
+            float dd = __fadd_rn(__fadd_rn(__fmul_rn(-2.f, dot), ss), sd);
+            if (mode == 3) dd = sqrtf(__fadd_rn(fabsf(dd), 1e-12f));  // ambiguity.py:49
+            const bool pos = posmask[(size_t)i * k + j] != 0;
+            np += pos ? 1 : 0;
+            dp = __fadd_rn(dp, pos ? dd : 0.f);
+            dn = __fadd_rn(dn, pos ? 0.f : dd);
+        }
+        n_pos[i] = np;
+        d_pos[i] = mode == 1 ? 5.f : dp;  // ambiguity.py:24-25
+        d_neg[i] = mode == 1 ? 5.f : dn;
+    }
+    // wave max, then one atomic per wave
+    int w = np;
+    for (int s = 32; s >= 1; s >>= 1) w = max(w, __shfl_xor(w, s, 64));
+    if ((threadIdx.x & 63) == 0 && w > 0) atomicMax(max_npos, w);
+}
+
+// a_i (ambiguity.py:13-14, 56-61, 71): |n+ - max|/max; for 0 < n+ < max:
+// 1 / (1 + e^(beta * (n+/d+ - n-/d-)))  with e = fp32(math.e) raised by pow as torch does
+__global__ void ambiguity_kernel(int m, int k, float beta, const int *__restrict__ n_pos,
+                                 const float *__restrict__ d_pos, const float *__restrict__ d_neg,
+                                 const int *__restrict__ max_npos, float *__restrict__ a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int top = *max_npos;
+    const int np = n_pos[i];
+    float v = __fdiv_rn((float)abs(np - top), (float)top);
+    if (0 < np && np < top) {
+        const float cc = __fsub_rn(__fdiv_rn((float)np, d_pos[i]), __fdiv_rn((float)(k - np), d_neg[i]));
+        v = __fdiv_rn(1.f, __fadd_rn(1.f, powf(2.718281828459045f, __fmul_rn(beta, cc))));
+    }
+    a[i] = v;
+}
+
+// max(||f_i||_2, eps) per row (F.cosine_similarity's clamp_min(eps), eps = 1e-8)
+__global__ __launch_bounds__(256) void row_norm_kernel(int m, int C, const float *__restrict__ f,
+                                                       float *__restrict__ norm)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= m) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float v = f[(size_t)i * C + c];
+        s += v * v;
+    }
+    for (int sft = 32; sft >= 1; sft >>= 1) s += __shfl_xor(s, sft, 64);
+    if (lane == 0) norm[i] = fmaxf(sqrtf(s), 1e-8f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Contrast forward (MarginContrast.py:250-257, 117-174 with margin 'adaptive', db '-m', Method1):
+// 32 lanes per anchor, lane j owns neighbour j (k <= 32 per round); the anchor row is a broadcast
+// load, the neighbour row a per-lane 16-byte stream that stays in L1 across the channel loop.
+// Writes the cosine similarities (for the backward) and the per-anchor loss; anchors outside
+// 0 < a <= 1 (perfectly consistent neighbourhoods) contribute nothing.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void contrast_forward_kernel(
+    int m, int C, int k, int nbr_stride, const float *__restrict__ f, const float *__restrict__ norm,
+    const int *__restrict__ nbr, const unsigned char *__restrict__ posmask, const float *__restrict__ a, float mu,
+    float nu, float temperature, float *__restrict__ sim, float *__restrict__ loss_pt)
+{
+    const int sub = threadIdx.x & 31;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (i >= m) return;
+    const float ai = a[i];
+    const bool sel = 0.f < ai && ai <= 1.f;
+    if (!sel) {
+        if (sub == 0) loss_pt[i] = 0.f;
+        return;
+    }
+    const float ni = norm[i];
+    const float margin = __fadd_rn(__fmul_rn(mu, ai), nu);
+    const float *fi = f + (size_t)i * C;
+    float psum = 0.f, tsum = 0.f;
+    for (int j0 = 0; j0 < k; j0 += 32) {
+        const int j = j0 + sub;
+        float e = 0.f;
+        bool pos = false;
+        if (j < k) {
+            const int nb = nbr[(size_t)i * nbr_stride + j];
+            const float nj = norm[nb];
+            const float *fj = f + (size_t)nb * C;
+            float acc = 0.f;
+            if ((C & 3) == 0) {
+                for (int c = 0; c < C; c += 4) {
+                    const float4 u = *reinterpret_cast<const float4 *>(fi + c);
+                    const float4 v = *reinterpret_cast<const float4 *>(fj + c);
+                    acc += __fdiv_rn(u.x, ni) * __fdiv_rn(v.x, nj);
+                    acc += __fdiv_rn(u.y, ni) * __fdiv_rn(v.y, nj);
+                    acc += __fdiv_rn(u.z, ni) * __fdiv_rn(v.z, nj);
+                    acc += __fdiv_rn(u.w, ni) * __fdiv_rn(v.w, nj);
+                }
+            } else {
+                for (int c = 0; c < C; ++c) acc += __fdiv_rn(fi[c], ni) * __fdiv_rn(fj[c], nj);
+            }
+            sim[(size_t)i * k + j] = acc;
+            pos = posmask[(size_t)i * k + j] != 0;
+            const float s = pos ? __fsub_rn(acc, margin) : acc;
+            e = expf(__fdiv_rn(s, temperature));
+        }
+        psum += pos ? e : 0.f;
+        tsum += e;
+    }
+    for (int s = 16; s >= 1; s >>= 1) {
+        psum += __shfl_xor(psum, s, 64);
+        tsum += __shfl_xor(tsum, s, 64);
+    }
+    if (sub == 0) loss_pt[i] = -logf(__fadd_rn(__fdiv_rn(psum, tsum), 1e-12f));
+}
+
+// mean of loss_pt over the selected anchors, deterministically (one workgroup, fixed order):
+// out[0] = sum / count, out[1] = count.  torch.mean of an empty selection is NaN in the
+// reference; so is 0/0 here.
+__global__ __launch_bounds__(1024) void masked_mean_kernel(int m, const float *__restrict__ loss_pt,
+                                                           const float *__restrict__ a, float *__restrict__ out)
+{
+    __shared__ double s_sum[16];
+    __shared__ int s_cnt[16];
+    double sum = 0.0;
+    int cnt = 0;
+    for (int i = threadIdx.x; i < m; i += 1024) {
+        const float ai = a[i];
+        if (0.f < ai && ai <= 1.f) { sum += (double)loss_pt[i]; cnt += 1; }
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        sum += __shfl_xor(sum, s, 64);
+        cnt += __shfl_xor(cnt, s, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = sum; s_cnt[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        int c = 0;
+        for (int w = 0; w < 16; ++w) { t += s_sum[w]; c += s_cnt[w]; }
+        out[0] = (float)(t / (double)c);
+        out[1] = (float)c;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Contrast backward: d(mean loss)/d f.  LPA lanes per anchor, lane owns channels c, c+LPA, ...;
+// neighbours are walked one at a time so every atomic wave-instruction adds LPA contiguous floats
+// of one row (the shape global float atomics run at full rate for).
+//   l = -log(r + eps), r = P/S, e_j = exp(s'_j / T):  dl/ds_j = -(e_j (pos_j S - P)) / ((r+eps) S^2 T)
+//   ds_j/df_i = (fhat_j - s_j fhat_i)/|f_i|,  ds_j/df_j = (fhat_i - s_j fhat_j)/|f_j|
+// ---------------------------------------------------------------------------------------------
+template <int LPA, int VPT>
+__global__ __launch_bounds__(256) void contrast_backward_kernel(
+    int m, int C, int k, int nbr_stride, const float *__restrict__ f, const float *__restrict__ norm,
+    const int *__restrict__ nbr, const unsigned char *__restrict__ posmask, const float *__restrict__ a, float mu,
+    float nu, float temperature, const float *__restrict__ sim, const float *__restrict__ mean_cnt,
+    const float *__restrict__ grad_out, float *__restrict__ grad_f)
+{
+    const int sub = threadIdx.x & (LPA - 1);
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) / LPA;
+    if (i >= m) return;
+    const float ai = a[i];
+    if (!(0.f < ai && ai <= 1.f)) return;
+    const float scale = grad_out[0] / mean_cnt[1];
+    const float ni = norm[i];
+    const float margin = __fadd_rn(__fmul_rn(mu, ai), nu);
+
+    float fhi[VPT], gi[VPT];
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const int c = sub + v * LPA;
+        fhi[v] = c < C ? __fdiv_rn(f[(size_t)i * C + c], ni) : 0.f;
+        gi[v] = 0.f;
+    }
+    // P and S over all neighbours (lanes stride over j)
+    float psum = 0.f, tsum = 0.f;
+    for (int j = sub; j < k; j += LPA) {
+        const bool pos = posmask[(size_t)i * k + j] != 0;
+        const float sj = sim[(size_t)i * k + j];
+        const float e = expf(__fdiv_rn(pos ? __fsub_rn(sj, margin) : sj, temperature));
+        psum += pos ? e : 0.f;
+        tsum += e;
+    }
+#pragma unroll
+    for (int s = LPA / 2; s >= 1; s >>= 1) {
+        psum += __shfl_xor(psum, s, 64);
+        tsum += __shfl_xor(tsum, s, 64);
+    }
+    const float r = psum / tsum;
+    const float coef = -scale / ((r + 1e-12f) * tsum * tsum * temperature);
+    if (psum == 0.f) return;  // no positive neighbour: constant loss, zero gradient
+
+    for (int j = 0; j < k; ++j) {
+        const int nb = nbr[(size_t)i * nbr_stride + j];
+        const bool pos = posmask[(size_t)i * k + j] != 0;
+        const float sj = sim[(size_t)i * k + j];
+        const float e = expf(__fdiv_rn(pos ? __fsub_rn(sj, margin) : sj, temperature));
+        const float g = coef * e * ((pos ? tsum : 0.f) - psum);  // dL/ds_j
+        const float nj = norm[nb];
+        const float gin = g / ni, gjn = g / nj;
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int c = sub + v * LPA;
+            if (c < C) {
+                const float fhj = __fdiv_rn(f[(size_t)nb * C + c], nj);
+                gi[v] += gin * (fhj - sj * fhi[v]);
+                atomicAdd(grad_f + (size_t)nb * C + c, gjn * (fhi[v] - sj * fhj));
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const int c = sub + v * LPA;
+        if (c < C) atomicAdd(grad_f + (size_t)i * C + c, gi[v]);
+    }
+}
+
+}  // namespace amc
+
+using namespace amc;
+
+AMC_API int amc3d_vote_labels(int m, int kr, int num_classes, const int *labels0, const int *nbr_idx, int *labels,
+                              void *stream)
+{
+    if (m <= 0) return 0;
+    if (kr <= 0 || kr > 128 || num_classes <= 0 || !labels0 || !nbr_idx || !labels)
+        return bad_arg("amc3d_vote_labels: bad argument (kr must be in 1..128)");
+    hipLaunchKernelGGL(vote_labels_kernel, dim3(div_up(m, 4)), dim3(256), 0, (hipStream_t)stream, m, kr, num_classes,
+                       labels0, nbr_idx, labels);
+    return launch_status("amc3d_vote_labels");
+}
+
+AMC_API int amc3d_posmask(int m, int k, int nbr_stride, const int *labels, const int *nbr, unsigned char *posmask,
+                          void *stream)
+{
+    if (m <= 0) return 0;
+    if (k <= 0 || nbr_stride < k || !labels || !nbr || !posmask) return bad_arg("amc3d_posmask: bad argument");
+    hipLaunchKernelGGL(posmask_kernel, dim3(div_up((long)m * k, 256)), dim3(256), 0, (hipStream_t)stream, m, k,
+                       nbr_stride, labels, nbr, posmask);
+    return launch_status("amc3d_posmask");
+}
+
+AMC_API size_t amc3d_ambiguity_workspace_bytes(int m) { return (size_t)m * 12 + 64; }
+
+AMC_API int amc3d_ambiguity(int m, int k, int nbr_stride, int mode, float beta, const float *p,
+                            const unsigned char *posmask, const int *nbr, float *a, void *workspace,
+                            size_t workspace_bytes, void *stream_)
+{
+    if (m <= 0) return 0;
+    if (k <= 0 || nbr_stride < k || mode < 1 || mode > 3 || !p || !posmask || !nbr || !a || !workspace ||
+        workspace_bytes < amc3d_ambiguity_workspace_bytes(m))
+        return bad_arg("amc3d_ambiguity: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    int *max_npos = (int *)workspace;  // [0..63] header, then n_pos, d_pos, d_neg
+    int *n_pos = (int *)((char *)workspace + 64);
+    float *d_pos = (float *)(n_pos + m);
+    float *d_neg = d_pos + m;
+    hipError_t e = hipMemsetAsync(max_npos, 0, sizeof(int), stream);
+    if (e != hipSuccess) { set_error("amc3d_ambiguity: memset: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(ambiguity_stats_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, m, k, nbr_stride, mode, p,
+                       posmask, nbr, n_pos, d_pos, d_neg, max_npos);
+    hipLaunchKernelGGL(ambiguity_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, m, k, beta, n_pos, d_pos, d_neg,
+                       max_npos, a);
+    return launch_status("amc3d_ambiguity");
+}
+
+AMC_API int amc3d_contrast_forward(int m, int C, int k, int nbr_stride, const float *f, const int *nbr,
+                                   const unsigned char *posmask, const float *a, float mu, float nu,
+                                   float temperature, float *norm, float *sim, float *loss_pt, float *mean_cnt,
+                                   void *stream_)
+{
+    if (m <= 0) return 0;
+    if (C <= 0 || k <= 0 || nbr_stride < k || !f || !nbr || !posmask || !a || !norm || !sim || !loss_pt || !mean_cnt)
+        return bad_arg("amc3d_contrast_forward: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(row_norm_kernel, dim3(div_up(m, 4)), dim3(256), 0, stream, m, C, f, norm);
+    hipLaunchKernelGGL(contrast_forward_kernel, dim3(div_up((long)m * 32, 256)), dim3(256), 0, stream, m, C, k,
+                       nbr_stride, f, norm, nbr, posmask, a, mu, nu, temperature, sim, loss_pt);
+    hipLaunchKernelGGL(masked_mean_kernel, dim3(1), dim3(1024), 0, stream, m, loss_pt, a, mean_cnt);
+    return launch_status("amc3d_contrast_forward");
+}
+
+AMC_API int amc3d_contrast_backward(int m, int C, int k, int nbr_stride, const float *f, const float *norm,
+                                    const int *nbr, const unsigned char *posmask, const float *a, float mu, float nu,
+                                    float temperature, const float *sim, const float *mean_cnt,
+                                    const float *grad_out, float *grad_f, void *stream_)
+{
+    if (m <= 0) return 0;
+    if (C <= 0 || C > 512 || k <= 0 || !f || !norm || !nbr || !posmask || !a || !sim || !mean_cnt || !grad_out || !grad_f)
+        return bad_arg("amc3d_contrast_backward: bad argument (C must be in 1..512)");
+    hipStream_t stream = (hipStream_t)stream_;
+#define AMC_BWD(LPA, VPT)                                                                                           \
+    hipLaunchKernelGGL((contrast_backward_kernel<LPA, VPT>), dim3(div_up((long)m * LPA, 256)), dim3(256), 0, stream, \
+                       m, C, k, nbr_stride, f, norm, nbr, posmask, a, mu, nu, temperature, sim, mean_cnt, grad_out,  \
+                       grad_f)
+    if (C <= 32) AMC_BWD(32, 1);
+    else if (C <= 64) AMC_BWD(64, 1);
+    else if (C <= 128) AMC_BWD(64, 2);
+    else if (C <= 256) AMC_BWD(64, 4);
+    else AMC_BWD(64, 8);
+#undef AMC_BWD
+    return launch_status("amc3d_contrast_backward");
+}

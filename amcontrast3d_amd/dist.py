@@ -1,0 +1,90 @@
+"""One process per GPU, plain data parallel over RCCL (torch.distributed backend 'nccl').
+
+The path shards by scene: every rank trains on its own clouds, the only
+exchange is the gradient all-reduce (+ SyncBatchNorm statistics, which the reference forces on
+whenever world_size > 1: examples/segmentation/main_AA.py:146-148, 820).  Helpers here are shared by
+bench.py and the gloo tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment (1-process defaults)."""
+    return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)),
+            int(os.environ.get("WORLD_SIZE", 1)))
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group when launched with WORLD_SIZE > 1; returns (rank, local, world)."""
+    rank, local, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def scene_ids(rank, world, per_rank, step=0):
+    """Scene ids of one rank for one step: disjoint across ranks (DistributedSampler semantics,
+    dataset/build.py:78-88), fixed per-rank batch -> weak scaling."""
+    base = (step * world + rank) * per_rank
+    return list(range(base, base + per_rank))
+
+
+def max_over_ranks(value, device):
+    """MAX-reduce a python float over ranks (step time = slowest rank)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def wrap_data_parallel(model, device, world):
+    """SyncBN conversion + DistributedDataParallel, as main_AA.py:146-152 does for world_size > 1."""
+    if world <= 1:
+        return model
+    if device.type == "cuda":
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        return torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], output_device=device.index,
+                                                         gradient_as_bucket_view=True)
+    return torch.nn.parallel.DistributedDataParallel(model)
+
+
+def allreduce_gradients(params, bucket_bytes=32 << 20):
+    """Average gradients across ranks in flat buckets (for modules that bypass DDP's hooks).
+    Buckets are filled in parameter order; one all-reduce per bucket."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    world = dist.get_world_size()
+    grads = [p.grad for p in params if p.grad is not None]
+    buckets, cur, size = [], [], 0
+    for g in grads:
+        nbytes = g.numel() * g.element_size()
+        if cur and size + nbytes > bucket_bytes:
+            buckets.append(cur)
+            cur, size = [], 0
+        cur.append(g)
+        size += nbytes
+    if cur:
+        buckets.append(cur)
+    for b in buckets:
+        flat = torch.cat([g.reshape(-1) for g in b])
+        dist.all_reduce(flat)
+        flat.div_(world)
+        off = 0
+        for g in b:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+    return len(buckets)

@@ -2,15 +2,12 @@
 
 Same inputs, outputs and arithmetic as the reference; the per-boundary-point
 Python loop that builds the neighbour-coordinate tensor with a growing
-``torch.cat`` (ambiguity.py:32-35, O(m_b^2) bytes and 2*m_b launches) is one
-indexed gather here, and the five bucket percentages -- five ``.item()`` host
-syncs in the reference (:79-91), unused by the loss -- are evaluated lazily.
+``torch.cat`` (ambiguity.py:32-35, O(m_b^2) bytes and 2*m_b launches) and the
+torch ops around it are two gfx950 kernels here, and the five bucket percentages
+-- five ``.item()`` host syncs in the reference (:79-91), unused by the loss --
+are evaluated lazily.
 """
-import math
-
 import torch
-
-from .function import _eps, inverse_sigmoid_function, square_distance
 
 
 class _LazyShares:
@@ -42,40 +39,17 @@ class _LazyShares:
 
 
 def ambiguity_function(p, posmask, nsample, neighbor_idx, ambiguity_type, ambiguity_beta, ambiguity_vis, nu):
-    """p (m,3), posmask (m,k) bool, neighbor_idx (m,k) -> a (m) in [0,1], bucket shares.
+    """p (m,3), posmask (m,k) bool, neighbor_idx (m,k) int32 -> a (m) in [0,1], bucket shares.
 
     n+ = #same-class neighbours; a = |n+ - max n+| / max n+  (0 inner, 1 isolated);
     for 0 < n+ < max:  a = 1 / (1 + e^(beta (n+/d+ - n-/d-)))  with d+- the summed
-    (squared, Method2) distances to the positive / negative neighbours."""
-    mask_num = torch.sum(posmask.int(), -1)
-    top = torch.max(mask_num)
-    a = torch.abs(mask_num.add(-top)).div(top)
-    boundary = torch.logical_and(0 < mask_num, mask_num < top)  # == (0 < a) & (a < 1)
-
-    mask_b = posmask[boundary]
-    n_pos = torch.sum(mask_b.int(), -1)
-    n_neg = torch.sum(1 - mask_b.int(), -1)
-
-    if ambiguity_type == 'Method1':
-        d_pos = torch.full(n_pos.shape, 5.0, device=p.device)
-        d_neg = torch.full(n_neg.shape, 5.0, device=p.device)
-    elif ambiguity_type in ('Method2', 'Method3'):
-        centre = p[boundary].unsqueeze(1)            # (m_b,1,3)
-        nbrs = p[neighbor_idx[boundary].long()]      # (m_b,k,3)
-        dd = square_distance(centre, nbrs).squeeze(1)
-        if ambiguity_type == 'Method3':
-            dd = torch.sqrt(torch.abs(dd) + _eps)
-        d_pos = torch.sum(mask_b.int() * dd, -1)
-        d_neg = torch.sum((1 - mask_b.int()) * dd, -1)
-    else:
-        raise ValueError(f'unknown cctype {ambiguity_type}')
-
-    cc_pos = n_pos / d_pos
-    cc_neg = n_neg / d_neg
-    t = torch.full(cc_pos.shape, math.e, device=p.device)
-    ai_soft = inverse_sigmoid_function(cc_pos - cc_neg, t, ambiguity_beta)
-
+    (squared, Method2) distances to the positive / negative neighbours.  One fused kernel pair
+    (amc3d_ambiguity) evaluates it with the reference's fp32 operation order, including the
+    expanded -2ab + a^2 + b^2 distance of AEF/function.py:18-39."""
     if ambiguity_vis:
         raise NotImplementedError("ambiguity_args.vis needs the reference's pyvista viewer (AMContrast3D/vis.py)")
-    a[boundary] = ai_soft
+    if ambiguity_type not in ('Method1', 'Method2', 'Method3'):
+        raise ValueError(f'unknown cctype {ambiguity_type}')
+    from amcontrast3d_amd import ops
+    a = ops.ambiguity(p.contiguous(), posmask.contiguous(), neighbor_idx, ambiguity_type, ambiguity_beta)
     return a, _LazyShares(a, nu)

@@ -27,6 +27,24 @@ def get_subscene_label_CBL(stage_n, stage_i, stage_list, target, nstride, num_cl
     return x.float().mean(-2)
 
 
+def get_subscene_class(stage_n, stage_i, stage_list, target, nstride, num_classes, ignore_index):
+    """arg-max of get_subscene_label_CBL as int32 class ids (m), without materialising the
+    (m,kr,ncls) one-hot gather: the majority vote runs in one kernel (lowest class id wins ties,
+    as torch.argmax of the mean one-hot does)."""
+    from amcontrast3d_amd import ops
+    if ignore_index is not None:
+        num_classes = num_classes + 1
+        target = torch.where(target == ignore_index, torch.full_like(target, num_classes - 1), target)
+    labels0 = target.to(torch.int32)
+    if stage_i == 0:
+        return labels0, num_classes
+    kr = int(torch.prod(nstride[:stage_i]))
+    src = stage_list['up'][0]
+    dst = stage_list[stage_n][stage_i]
+    neighbor_idx, _ = pointops.knnquery(kr, src['p_out'], dst['p_out'], src['offset'], dst['offset'])
+    return ops.vote_labels(labels0, neighbor_idx, num_classes), num_classes
+
+
 def fetch_pxo(stage_n, stage_i, stage_list, ftype):
     stage = stage_list[stage_n][stage_i]
     return stage['p_out'], stage['f_out'], stage['offset']

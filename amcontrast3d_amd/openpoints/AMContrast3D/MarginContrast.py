@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from openpoints.cpp.pointops.functions import pointops
 from .AEF.ambiguity import ambiguity_function
 from .AEF.function import _eps
-from .AEF.utils import fetch_pxo, get_ftype, get_subscene_label_CBL
+from .AEF.utils import fetch_pxo, get_ftype, get_subscene_class, get_subscene_label_CBL  # noqa: F401
 
 
 def _posmask_cnt(labels, neighbor_label):
@@ -26,15 +26,15 @@ def _posmask_cnt(labels, neighbor_label):
 
 
 def _stage_neighbourhood(n, i, stageACE_list, target, nstride, num_classes, ignore_index, nsample, ftype):
+    """k-NN of the stage (self match dropped), per-point classes and the positive mask -- three
+    kernels; the reference gathers (m,k,ncls) one-hot labels for this (MarginContrast.py:220-231)."""
+    from amcontrast3d_amd import ops
     p, features, o = fetch_pxo(n, i, stageACE_list, ftype)
-    labels = get_subscene_label_CBL(n, i, stageACE_list, target, nstride, num_classes, ignore_index)
+    labels, _ = get_subscene_class(n, i, stageACE_list, target, nstride, num_classes, ignore_index)
     neighbor_idx, _ = pointops.knnquery(nsample, p, p, o, o)
-    neighbor_idx = neighbor_idx[..., 1:].contiguous()  # drop the self match
-    m, k = neighbor_idx.shape
-    flat = neighbor_idx.view(-1).long()
-    neighbor_label = labels[flat, :].view(m, k, labels.shape[1])
-    posmask = _posmask_cnt(labels, neighbor_label)
-    return p, features, neighbor_idx, flat, posmask, k
+    neighbor_idx = neighbor_idx[..., 1:]  # drop the self match: a strided view, no copy
+    posmask = ops.posmask_from_labels(labels, neighbor_idx)
+    return p, features, neighbor_idx, posmask, neighbor_idx.shape[1]
 
 
 class AmbiguityHead(nn.Module):
@@ -49,7 +49,7 @@ class AmbiguityHead(nn.Module):
         return _posmask_cnt(labels, neighbor_label)
 
     def point_ambiguity(self, n, i, stageACE_list, target, num_classes, ignore_index, ambiguity_args):
-        p, _, neighbor_idx, _, posmask, k = _stage_neighbourhood(
+        p, _, neighbor_idx, posmask, k = _stage_neighbourhood(
             n, i, stageACE_list, target, self.nstride, num_classes, ignore_index, ambiguity_args.nsample, self.ftype)
         a, _ = ambiguity_function(p, posmask, k, neighbor_idx, ambiguity_args.cctype, ambiguity_args.ccbeta,
                                   ambiguity_args.vis, ambiguity_args.nu)
@@ -115,18 +115,26 @@ class ContrastHead(nn.Module):
         return -torch.log(loss)
 
     def point_contrast_margin(self, n, i, stageACE_list, target, num_classes, ignore_index, ambiguity_args):
-        p, features, neighbor_idx, flat, posmask, k = _stage_neighbourhood(
+        from amcontrast3d_amd import ops
+        p, features, neighbor_idx, posmask, k = _stage_neighbourhood(
             n, i, stageACE_list, target, self.nstride, num_classes, ignore_index, ambiguity_args.nsample, self.ftype)
-        m = neighbor_idx.shape[0]
-        neighbor_feature = features[flat, :].view(m, k, features.shape[1])
-
         ambiguity_soft, _ = ambiguity_function(p, posmask, k, neighbor_idx, ambiguity_args.cctype,
                                                ambiguity_args.ccbeta, ambiguity_args.vis, ambiguity_args.nu)
-        target_ai = torch.clone(ambiguity_soft)
+        target_ai = ambiguity_soft
         output_ai = stageACE_list['ambiguity'][i].flatten() if 'ambiguity' in stageACE_list.keys() else None
 
-        # anchors that enter the loss: everything but the perfectly consistent points (a == 0)
+        fused = (ambiguity_args.margin == 'adaptive' and ambiguity_args.db == '-m'
+                 and ambiguity_args.supervisedCL == 'Method1' and ambiguity_args.temperature is not None)
+        if fused:
+            # anchors with 0 < a <= 1 enter the loss (MarginContrast.py:250-257); selection, cosine
+            # similarity, margin soft-NN loss and the mean are one forward and one backward kernel
+            loss = ops.contrast_stage(features, neighbor_idx, posmask, ambiguity_soft, ambiguity_args.mu,
+                                      ambiguity_args.nu, ambiguity_args.temperature)
+            return loss, output_ai, target_ai
+        # other margin / decision-boundary / Method2 variants: composed from the torch-level pieces
         keep = torch.logical_and(0 < ambiguity_soft, ambiguity_soft <= 1)
+        m = neighbor_idx.shape[0]
+        neighbor_feature = features[neighbor_idx.reshape(-1).long(), :].view(m, k, features.shape[1])
         dist = self.dist_func(features[keep], neighbor_feature[keep])
         loss = self.contrast_func(dist, posmask[keep], ambiguity_soft[keep], ambiguity_args)
         return torch.mean(loss), output_ai, target_ai

@@ -17,7 +17,7 @@ import ctypes
 import torch
 from torch.autograd import Function
 
-from . import _lib
+from . import _lib, timing
 
 
 def _ptr(t):
@@ -45,7 +45,7 @@ class BallQuery(Function):
         B, N, _ = xyz.size()
         npoint = new_xyz.size(1)
         idx = torch.empty(B, npoint, nsample, dtype=torch.int32, device=xyz.device)
-        with torch.cuda.device(xyz.device):
+        with torch.cuda.device(xyz.device), timing.span("ball_query", (B * N + B * npoint) * 12 + idx.numel() * 4):
             _lib.check(_lib.load().amc3d_ball_query(B, N, npoint, float(radius), int(nsample), _ptr(new_xyz),
                                                     _ptr(xyz), _ptr(idx), _stream(xyz)), "ball_query")
         ctx.mark_non_differentiable(idx)
@@ -70,7 +70,7 @@ class GroupingOperation(Function):
         B, nfeatures, nsample = idx.size()
         _, C, N = features.size()
         output = torch.empty(B, C, nfeatures, nsample, dtype=torch.float32, device=features.device)
-        with torch.cuda.device(features.device):
+        with torch.cuda.device(features.device), timing.span("group_points", features.numel() * 4 + idx.numel() * 4 + output.numel() * 4):
             _lib.check(_lib.load().amc3d_group_points(B, C, N, nfeatures, nsample, _ptr(features), _ptr(idx),
                                                       _ptr(output), _stream(features)), "group_points")
         ctx.for_backwards = (idx, N)
@@ -83,7 +83,7 @@ class GroupingOperation(Function):
         B, C, npoint, nsample = grad_out.size()
         grad_features = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
         grad_out_data = grad_out.detach().contiguous()
-        with torch.cuda.device(grad_out.device):
+        with torch.cuda.device(grad_out.device), timing.span("group_points_grad", grad_out_data.numel() * 4 + idx.numel() * 4 + grad_features.numel() * 4):
             _lib.check(_lib.load().amc3d_group_points_grad(B, C, N, npoint, nsample, _ptr(grad_out_data), _ptr(idx),
                                                            _ptr(grad_features), _stream(grad_out)), "group_points_grad")
         return grad_features, None
@@ -102,7 +102,7 @@ class GatherOperation(Function):
         B, npoint = idx.size()
         _, C, N = features.size()
         output = torch.empty(B, C, npoint, dtype=torch.float32, device=features.device)
-        with torch.cuda.device(features.device):
+        with torch.cuda.device(features.device), timing.span("gather_points", features.numel() * 4 + idx.numel() * 4 + output.numel() * 4):
             _lib.check(_lib.load().amc3d_gather_points(B, C, N, npoint, _ptr(features), _ptr(idx), _ptr(output),
                                                        _stream(features)), "gather_points")
         ctx.for_backwards = (idx, C, N)
@@ -114,7 +114,7 @@ class GatherOperation(Function):
         B, npoint = idx.size()
         grad_features = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
         grad_out_data = grad_out.detach().contiguous()
-        with torch.cuda.device(grad_out.device):
+        with torch.cuda.device(grad_out.device), timing.span("gather_points_grad", grad_out_data.numel() * 4 + idx.numel() * 4 + grad_features.numel() * 4):
             _lib.check(_lib.load().amc3d_gather_points_grad(B, C, N, npoint, _ptr(grad_out_data), _ptr(idx),
                                                             _ptr(grad_features), _stream(grad_out)), "gather_points_grad")
         return grad_features, None
@@ -136,7 +136,7 @@ class FurthestPointSampling(Function):
         temp = None
         if N > 24576:
             temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
-        with torch.cuda.device(xyz.device):
+        with torch.cuda.device(xyz.device), timing.span("furthest_point_sampling", B * N * 12 + B * int(npoint) * 4):
             _lib.check(_lib.load().amc3d_furthest_point_sampling(B, N, int(npoint), _ptr(xyz),
                                                                  _ptr(temp) if temp is not None else None,
                                                                  _ptr(output), _stream(xyz)), "furthest_point_sampling")
@@ -162,7 +162,7 @@ class ThreeNN(Function):
         m = known.size(1)
         dist2 = torch.empty(B, N, 3, dtype=torch.float32, device=unknown.device)
         idx = torch.empty(B, N, 3, dtype=torch.int32, device=unknown.device)
-        with torch.cuda.device(unknown.device):
+        with torch.cuda.device(unknown.device), timing.span("three_nn", (B * N + B * m) * 12 + B * N * 24):
             _lib.check(_lib.load().amc3d_three_nn(B, N, m, _ptr(unknown), _ptr(known), _ptr(dist2), _ptr(idx),
                                                   _stream(unknown)), "three_nn")
         ctx.mark_non_differentiable(idx)
@@ -189,7 +189,7 @@ class ThreeInterpolate(Function):
         n = idx.size(1)
         ctx.three_interpolate_for_backward = (idx, weight, m)
         output = torch.empty(B, c, n, dtype=torch.float32, device=features.device)
-        with torch.cuda.device(features.device):
+        with torch.cuda.device(features.device), timing.span("three_interpolate", features.numel() * 4 + idx.numel() * 8 + output.numel() * 4):
             _lib.check(_lib.load().amc3d_three_interpolate(B, c, m, n, _ptr(features), _ptr(idx), _ptr(weight),
                                                            _ptr(output), _stream(features)), "three_interpolate")
         return output
@@ -201,7 +201,7 @@ class ThreeInterpolate(Function):
         B, c, n = grad_out.size()
         grad_features = torch.zeros(B, c, m, dtype=torch.float32, device=grad_out.device)
         grad_out_data = grad_out.detach().contiguous()
-        with torch.cuda.device(grad_out.device):
+        with torch.cuda.device(grad_out.device), timing.span("three_interpolate_grad", grad_out_data.numel() * 4 + idx.numel() * 8 + grad_features.numel() * 4):
             _lib.check(_lib.load().amc3d_three_interpolate_grad(B, c, n, m, _ptr(grad_out_data), _ptr(idx),
                                                                 _ptr(weight), _ptr(grad_features),
                                                                 _stream(grad_out)), "three_interpolate_grad")
@@ -236,7 +236,7 @@ class KNNQuery(Function):
         lib = _lib.load()
         wbytes = int(lib.amc3d_knnquery_workspace_bytes(n, m, nsample, nb))
         work = torch.empty(wbytes, dtype=torch.uint8, device=xyz.device)
-        with torch.cuda.device(xyz.device):
+        with torch.cuda.device(xyz.device), timing.span("knnquery", (n + m) * 12 + m * nsample * 8):
             _lib.check(lib.amc3d_knnquery(m, nsample, n, nb, _ptr(xyz), _ptr(new_xyz), _ptr(offset.contiguous()),
                                           _ptr(new_offset.contiguous()), _ptr(idx), _ptr(dist2), _ptr(work), wbytes,
                                           _stream(xyz)), "knnquery")
@@ -249,3 +249,104 @@ class KNNQuery(Function):
 
 
 knnquery = KNNQuery.apply
+
+
+# ----------------------------------------------------------------------------------------------
+# adaptive-margin contrastive loss (no native counterpart in the reference: it runs these as
+# torch ops + a Python loop -- AMContrast3D/MarginContrast.py, AEF/ambiguity.py, AEF/utils.py)
+# ----------------------------------------------------------------------------------------------
+def _nbr_view(neighbor_idx):
+    """(pointer to first used column, k, row stride) of an int32 index that may be a column slice
+    idx[:, 1:] of a contiguous (m, K) tensor -- no copy (the reference calls .contiguous())."""
+    assert neighbor_idx.dtype == torch.int32 and neighbor_idx.dim() == 2
+    if neighbor_idx.stride(1) != 1:
+        neighbor_idx = neighbor_idx.contiguous()
+    return _ptr(neighbor_idx), neighbor_idx.shape[1], neighbor_idx.stride(0), neighbor_idx
+
+
+def vote_labels(labels0, neighbor_idx, num_classes):
+    """labels0 (n0) int32 classes of the full-resolution points, neighbor_idx (m,kr) int32 -> (m) int32:
+    arg-max of the mean one-hot label over the kr neighbours (AEF/utils.py:29-41)."""
+    _need_gpu(labels0, neighbor_idx)
+    assert labels0.dtype == torch.int32 and neighbor_idx.dtype == torch.int32 and neighbor_idx.is_contiguous()
+    m, kr = neighbor_idx.shape
+    out = torch.empty(m, dtype=torch.int32, device=labels0.device)
+    with torch.cuda.device(labels0.device), timing.span("vote_labels", m * kr * 8 + m * 4):
+        _lib.check(_lib.load().amc3d_vote_labels(m, kr, int(num_classes), _ptr(labels0), _ptr(neighbor_idx), _ptr(out),
+                                                 _stream(labels0)), "vote_labels")
+    return out
+
+
+def posmask_from_labels(labels, neighbor_idx):
+    """labels (m) int32, neighbor_idx (m,k) int32 (may be idx[:, 1:]) -> (m,k) bool"""
+    _need_gpu(labels, neighbor_idx)
+    nptr, k, stride, keep = _nbr_view(neighbor_idx)
+    m = labels.shape[0]
+    out = torch.empty(m, k, dtype=torch.bool, device=labels.device)
+    with torch.cuda.device(labels.device), timing.span("posmask", m * k * 9 + m * 4):
+        _lib.check(_lib.load().amc3d_posmask(m, k, stride, _ptr(labels), nptr, _ptr(out), _stream(labels)), "posmask")
+    return out
+
+
+_CCTYPE = {"Method1": 1, "Method2": 2, "Method3": 3}
+
+
+def ambiguity(p, posmask, neighbor_idx, cctype, beta):
+    """p (m,3), posmask (m,k) bool, neighbor_idx (m,k) int32 -> a (m) fp32 (AEF/ambiguity.py:11-71)"""
+    _need_gpu(p, posmask, neighbor_idx)
+    assert p.is_contiguous() and posmask.is_contiguous() and posmask.dtype == torch.bool
+    nptr, k, stride, keep = _nbr_view(neighbor_idx)
+    m = p.shape[0]
+    lib = _lib.load()
+    wbytes = int(lib.amc3d_ambiguity_workspace_bytes(m))
+    work = torch.empty(wbytes, dtype=torch.uint8, device=p.device)
+    a = torch.empty(m, dtype=torch.float32, device=p.device)
+    with torch.cuda.device(p.device), timing.span("ambiguity", m * (12 + 4) + m * k * (4 + 1 + 12)):
+        _lib.check(lib.amc3d_ambiguity(m, k, stride, _CCTYPE[cctype], float(beta), _ptr(p), _ptr(posmask), nptr,
+                                       _ptr(a), _ptr(work), wbytes, _stream(p)), "ambiguity")
+    return a
+
+
+class ContrastStage(Function):
+    """Stage loss of ContrastHead.point_contrast_margin (MarginContrast.py:250-257): mean over the
+    anchors with 0 < a <= 1 of the margin soft-NN loss on cosine similarities."""
+
+    @staticmethod
+    def forward(ctx, features, neighbor_idx, posmask, a, mu, nu, temperature):
+        _need_gpu(features, neighbor_idx, posmask, a)
+        f = features.contiguous()
+        assert f.dtype == torch.float32 and posmask.dtype == torch.bool and posmask.is_contiguous()
+        nptr, k, stride, keep = _nbr_view(neighbor_idx)
+        m, C = f.shape
+        dev = f.device
+        norm = torch.empty(m, dtype=torch.float32, device=dev)
+        sim = torch.empty(m, k, dtype=torch.float32, device=dev)
+        loss_pt = torch.empty(m, dtype=torch.float32, device=dev)
+        mean_cnt = torch.empty(2, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev), timing.span("contrast_forward", m * C * 4 * (1 + k) + m * k * 9 + m * 12):
+            _lib.check(_lib.load().amc3d_contrast_forward(m, C, k, stride, _ptr(f), nptr, _ptr(posmask), _ptr(a),
+                                                          float(mu), float(nu), float(temperature), _ptr(norm),
+                                                          _ptr(sim), _ptr(loss_pt), _ptr(mean_cnt), _stream(f)),
+                       "contrast_forward")
+        ctx.save_for_backward(f, norm, keep, posmask, a, sim, mean_cnt)
+        ctx.args = (float(mu), float(nu), float(temperature), k, stride)
+        return mean_cnt[0].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        f, norm, nbr, posmask, a, sim, mean_cnt = ctx.saved_tensors
+        mu, nu, temperature, k, stride = ctx.args
+        m, C = f.shape
+        g = grad_out.detach().to(torch.float32).reshape(1).contiguous()
+        grad_f = torch.zeros_like(f)
+        nptr = _ptr(nbr)
+        if nbr.storage_offset() and nbr.stride(1) == 1:
+            pass  # _ptr already points at the first used column (data_ptr includes the offset)
+        with torch.cuda.device(f.device), timing.span("contrast_backward", m * C * 4 * (1 + 2 * k) + m * k * 9):
+            _lib.check(_lib.load().amc3d_contrast_backward(m, C, k, stride, _ptr(f), _ptr(norm), nptr, _ptr(posmask),
+                                                           _ptr(a), mu, nu, temperature, _ptr(sim), _ptr(mean_cnt),
+                                                           _ptr(g), _ptr(grad_f), _stream(f)), "contrast_backward")
+        return grad_f, None, None, None, None, None, None
+
+
+contrast_stage = ContrastStage.apply

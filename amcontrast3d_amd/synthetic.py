@@ -77,6 +77,9 @@ def make_scene(sample_id, n_points, voxel_size=0.04, num_classes=13, ignore_frac
     # crop: the n_points nearest to a random centre (data_util.py:157-160)
     centre = pts[rng.integers(len(pts))]
     d = ((pts - centre) ** 2).sum(1)
+    if duplicates:  # a room with fewer voxels than voxel_max: keep 80 % distinct points, pad the rest
+        near = np.argsort(d, kind="stable")[:max(int(n_points * 0.8), 1)]
+        pts, lab, d = pts[near], lab[near], d[near]
     if len(pts) >= n_points:
         sel = np.argsort(d, kind="stable")[:n_points]
     else:  # pad by repetition (data_util.py:161-167) -> exact duplicate points

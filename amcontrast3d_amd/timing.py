@@ -1,0 +1,60 @@
+"""HIP-event timing of the native operators, on the stream they are launched on.
+
+bench.py switches this on for the timed region: every C-ABI launch made through
+amcontrast3d_amd.ops is bracketed by two events recorded on torch's current stream (the
+stream the kernel is enqueued on), tagged with the operator name and the algorithmic bytes
+of that launch.  Nothing synchronises until ``collect()``.
+"""
+import collections
+
+import torch
+
+_enabled = False
+_records = []  # (name, start_event, end_event, algorithmic_bytes)
+
+
+def enable(flag=True):
+    global _enabled
+    _enabled = bool(flag)
+    if not flag:
+        _records.clear()
+
+
+def enabled():
+    return _enabled
+
+
+class span:
+    """with timing.span('knnquery', bytes): launch(...)"""
+    __slots__ = ("name", "nbytes", "start")
+
+    def __init__(self, name, nbytes=0):
+        self.name, self.nbytes, self.start = name, nbytes, None
+
+    def __enter__(self):
+        if _enabled:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.start is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            _records.append((self.name, self.start, end, self.nbytes))
+        return False
+
+
+def collect():
+    """-> {name: {'launches', 'total_ms', 'avg_ms', 'bytes_per_launch'}}; call after a device sync."""
+    out = collections.OrderedDict()
+    for name, s, e, nbytes in _records:
+        d = out.setdefault(name, {"launches": 0, "total_ms": 0.0, "bytes": 0})
+        d["launches"] += 1
+        d["total_ms"] += s.elapsed_time(e)
+        d["bytes"] += nbytes
+    for d in out.values():
+        d["avg_ms"] = d["total_ms"] / d["launches"]
+        d["bytes_per_launch"] = d["bytes"] / d["launches"]
+    _records.clear()
+    return out

@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""Train-step throughput of the AMContrast3D hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Metric (BASELINE.json): train-step points/sec -- forward + CrossEntropyAce (cross-entropy +
+adaptive-margin contrast over 4 decoder stages) + backward (+ gradient all-reduce for N > 1)
++ clip + AdamW step -- on synthetic S3DIS-shaped 24 000-point clouds.  Workload at every N:
+BASELINE config 2, PointNeXt-S + AMContrast3D-AA, batch 8 clouds per GPU (weak scaling: scenes are
+sharded across ranks, one process per GPU, DDP + SyncBN over RCCL exactly as
+examples/segmentation/main_AA.py:146-152 does).  Inputs are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line.
+
+Besides the contract fields the line carries
+  roofline      the dominant native kernel of the step (largest share of HIP-event time among
+                the C-ABI launches, measured live in the timed region on the launch stream):
+                algorithmic bytes per launch / average launch duration vs 8 TB/s HBM
+  cpu_baseline  the oracle's CPU restatement of the SAME step (oracle/model_ref.py on
+                oracle/pointops_ref.c, OpenMP + torch CPU threads) timed on this box's host cores,
+                rank 0 and N = 1 only, one step of the full batch
+  kernels       per-operator HIP-event totals for the timed region (ms per step)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="clouds per GPU")
+    ap.add_argument("--points", type=int, default=24000)
+    ap.add_argument("--variant", default="S")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-batch", type=int, default=None,
+                    help="clouds in the CPU sample (default: the full per-GPU batch)")
+    return ap.parse_args()
+
+
+def build(variant, dev, world):
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from amcontrast3d_amd import configs, dist as adist
+    from openpoints.loss import build_criterion_from_cfg
+    from openpoints.models import build_model_from_cfg
+    from openpoints.utils import EasyConfig
+    torch.manual_seed(0)
+    cfg = configs.model_cfg(variant, dropout=0.5)
+    c = EasyConfig(); c.update(cfg)
+    model = build_model_from_cfg(c).to(dev).train()
+    model = adist.wrap_data_parallel(model, dev, world)
+    cc = EasyConfig(); cc.update(configs.criterion_cfg())
+    criterion = build_criterion_from_cfg(cc).to(dev)
+    aargs = EasyConfig(); aargs.update(configs.ambiguity_args("s3dis"))
+    # cfgs/s3dis/default.yaml:64-72: AdamW lr 0.01 wd 1e-4, clip 10
+    decay, no_decay = [], []
+    for p in model.parameters():
+        (no_decay if p.ndim <= 1 else decay).append(p)
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 1e-4}, {"params": no_decay, "weight_decay": 0.0}],
+                            lr=0.01)
+    return cfg, model, criterion, aargs, opt
+
+
+def cpu_baseline(cfg, model, batch_np, aargs_dict, points_per_step):
+    """One step of the oracle's CPU restatement on the same batch (bounded sample: one step)."""
+    from oracle import model_ref, pointops_ref
+    pointops_ref.build()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu().clone() for k, v in (model.module if hasattr(model, "module") else model).state_dict().items()}
+    cfg = json.loads(json.dumps(cfg))
+    cfg["cls_args"]["dropout"] = 0
+    # drop the Dropout slot from the head keys is not needed: keys are looked up by name
+    data = {k: torch.from_numpy(v) for k, v in batch_np.items()}
+    t0 = time.perf_counter()
+    model_ref.train_step(sd, cfg, data, data["y"], 13, None, aargs_dict)
+    dt = time.perf_counter() - t0
+    return {"value": points_per_step / dt, "unit": "points/s", "cores": cores, "kind": "port",
+            "sample": f"1 step, batch {data['pos'].shape[0]} x {data['pos'].shape[1]} points, {dt:.1f} s "
+                      f"(oracle/model_ref.py + pointops_ref.c, OpenMP/torch {cores} threads; no optimizer step)"}
+
+
+def main():
+    args = parse()
+    from amcontrast3d_amd import _lib, configs, dist as adist, synthetic, timing
+    rank, local, world = adist.init_from_env()
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    _lib.load()
+
+    cfg, model, criterion, aargs, opt = build(args.variant, dev, world)
+    ids = adist.scene_ids(rank, world, args.batch)
+    nb = synthetic.make_batch(args.batch, args.points, first_id=ids[0])
+    data = {k: torch.from_numpy(v).to(dev) for k, v in nb.items()}
+    torch.cuda.synchronize()
+
+    def step():
+        logits, stage = model(data)
+        loss = criterion(logits, data["y"], stage, 13, None, aargs)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 10, norm_type=2)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    adist.barrier()
+    torch.cuda.synchronize()
+    timing.enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    adist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kernels = timing.collect()
+    timing.enable(False)
+    dt = adist.max_over_ranks(dt, dev)
+    final_loss = float(loss)
+
+    if rank == 0:
+        points_per_step = args.batch * args.points
+        ms_per_step = dt / args.steps * 1e3
+        value = points_per_step * world / (dt / args.steps)
+        dom_name, dom = max(kernels.items(), key=lambda kv: kv[1]["total_ms"]) if kernels else (None, None)
+        roofline = None
+        if dom is not None:
+            achieved = dom["bytes_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                        "avg_launch_ms": round(dom["avg_ms"], 4), "launches_per_step": dom["launches"] / args.steps,
+                        "algorithmic_bytes_per_launch": int(dom["bytes_per_launch"])}
+        line = {
+            "metric": "train-step points/sec (fwd+bwd) on 24k-pt S3DIS clouds",
+            "value": round(value, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"PointNeXt-{args.variant} + AMContrast3D-AA, S3DIS-shaped {args.points}-pt "
+                                   f"voxelised (0.04 m) clouds, batch {args.batch}/GPU, fwd + CE/contrast loss + bwd + "
+                                   f"clip + AdamW",
+                       "global_batch": args.batch * world, "points": args.points,
+                       "parallelism": f"dp{world}" + ("+syncbn" if world > 1 else "")},
+            "loss": round(final_loss, 6),
+            "roofline": roofline,
+            "kernels": {k: {"ms_per_step": round(v["total_ms"] / args.steps, 4),
+                            "launches_per_step": v["launches"] / args.steps} for k, v in kernels.items()},
+            "native_ms_per_step": round(sum(v["total_ms"] for v in kernels.values()) / args.steps, 3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            b = args.cpu_baseline_batch or args.batch
+            sample = {k: v[:b] for k, v in nb.items()}
+            line["cpu_baseline"] = cpu_baseline(cfg, model, sample, configs.ambiguity_args("s3dis"), b * args.points)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -110,6 +110,48 @@ int amc3d_knnquery(int m, int nsample, int n, int nbatch, const float *xyz, cons
                    const int *offset, const int *new_offset, int *idx, float *dist2,
                    void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- adaptive-margin contrastive loss -------------------------------------------
+ * The reference has no native code here: it evaluates this part with torch ops and a Python
+ * loop.  These entry points replace, per decoder stage,
+ *     openpoints/AMContrast3D/AEF/utils.py:29-41            (amc3d_vote_labels)
+ *     openpoints/AMContrast3D/MarginContrast.py:111-115,228-230  (amc3d_posmask)
+ *     openpoints/AMContrast3D/AEF/ambiguity.py:11-71 + AEF/function.py:10-39  (amc3d_ambiguity)
+ *     openpoints/AMContrast3D/MarginContrast.py:77-79,117-174,250-257  (amc3d_contrast_*)
+ * `nbr` is the int32 k-NN index of the stage with `nbr_stride` columns per row; pass the
+ * address of the first column to USE (the reference drops column 0, the self match:
+ * MarginContrast.py:225-226) and k = number of columns used. */
+
+/* labels[q] = majority class among labels0[nbr_idx[q, 0..kr)] (lowest class id on equal
+ * counts): arg-max of the mean one-hot label.  nbr_idx is dense (m,kr), kr <= 128. */
+int amc3d_vote_labels(int m, int kr, int num_classes, const int *labels0, const int *nbr_idx, int *labels,
+                      void *stream);
+
+/* posmask[i,j] = labels[nbr[i,j]] == labels[i]  -> (m,k) bytes (torch.bool layout) */
+int amc3d_posmask(int m, int k, int nbr_stride, const int *labels, const int *nbr, unsigned char *posmask,
+                  void *stream);
+
+/* a[i] = ambiguity of point i from its positive mask and neighbour coordinates.
+ * mode 1/2/3 = cctype Method1/2/3; beta = ccbeta.  Workspace: amc3d_ambiguity_workspace_bytes(m). */
+size_t amc3d_ambiguity_workspace_bytes(int m);
+int amc3d_ambiguity(int m, int k, int nbr_stride, int mode, float beta, const float *p,
+                    const unsigned char *posmask, const int *nbr, float *a, void *workspace,
+                    size_t workspace_bytes, void *stream);
+
+/* Stage loss = mean over anchors with 0 < a <= 1 of
+ *   -log( sum_+ e^{(s-m_i)/T} / (sum_+ e^{(s-m_i)/T} + sum_- e^{s/T}) + 1e-12 ),  m_i = mu*a_i + nu,
+ * s = cosine similarity of the (m,C) embeddings f.  Outputs: norm (m) clamped row norms, sim (m,k),
+ * loss_pt (m), mean_cnt[2] = {stage loss, number of anchors}; all kept for the backward. */
+int amc3d_contrast_forward(int m, int C, int k, int nbr_stride, const float *f, const int *nbr,
+                           const unsigned char *posmask, const float *a, float mu, float nu, float temperature,
+                           float *norm, float *sim, float *loss_pt, float *mean_cnt, void *stream);
+
+/* grad_f (m,C) += grad_out[0] * d(stage loss)/d f; the caller zero-initialises grad_f.
+ * grad_out is a DEVICE scalar (no host sync).  C <= 512. */
+int amc3d_contrast_backward(int m, int C, int k, int nbr_stride, const float *f, const float *norm,
+                            const int *nbr, const unsigned char *posmask, const float *a, float mu, float nu,
+                            float temperature, const float *sim, const float *mean_cnt, const float *grad_out,
+                            float *grad_f, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,259 @@
+"""ORACLE -- test infrastructure only.  CPU restatement of the model + loss path.
+
+A functional (state-dict in, tensors out) fp32 restatement of what the reference computes on
+the AMContrast3D-AA training path, on top of the C restatement of its native kernels
+(oracle/pointops_ref.py).  It is the checker for the GPU product and the "port" timed as
+bench.py's cpu_baseline; only tests/, __graft_entry__.smoke() and that bench leg import it.
+It is pinned by the fixtures oracle/gen_golden.py records from the reference itself
+(tests/test_oracle_model.py).
+
+Each function cites the reference lines it follows (paths relative to /root/reference/openpoints).
+Gradients come from torch autograd on the CPU; the grouping / interpolation gathers are written
+with torch indexing so their backward is a deterministic index_add (the reference uses atomics).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import pointops_ref as K
+
+
+# ------------------------------------------------------------------------------------------
+# layers
+# ------------------------------------------------------------------------------------------
+def _conv(x, sd, prefix):
+    """1x1 conv (models/layers/conv.py:8-21): weight (Cout,Cin,1[,1]) [+ bias]."""
+    w = sd[prefix + ".weight"]
+    b = sd.get(prefix + ".bias")
+    return F.conv2d(x, w, b) if w.dim() == 4 else F.conv1d(x, w, b)
+
+
+def _bn(x, sd, prefix, training, eps=1e-5):
+    """nn.BatchNorm{1,2}d in training mode: batch statistics (models/layers/norm.py:57-60)."""
+    if training:
+        return F.batch_norm(x, None, None, sd[prefix + ".weight"], sd[prefix + ".bias"], True, 0.1, eps)
+    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"],
+                        sd[prefix + ".bias"], False, 0.1, eps)
+
+
+def _convblock(x, sd, prefix, norm, act, training):
+    """conv -> [BN] -> [ReLU]  (conv.py:24-102, order 'conv-norm-act')."""
+    x = _conv(x, sd, prefix + ".0")
+    if norm:
+        x = _bn(x, sd, prefix + ".1", training)
+    return F.relu(x) if act else x
+
+
+def group(features, idx):
+    """grouping_operation (group.py:76-101; group_points_gpu.cu:53-72): (B,C,N),(B,M,K)->(B,C,M,K)."""
+    B, C, _ = features.shape
+    flat = idx.reshape(B, 1, -1).expand(-1, C, -1).long()
+    return features.gather(2, flat).reshape(B, C, idx.shape[1], idx.shape[2])
+
+
+def query_and_group(radius, nsample, query_xyz, support_xyz, features, normalize_dp=True):
+    """QueryAndGroup.forward (group.py:235-255)."""
+    idx = K.ball_query(radius, nsample, support_xyz, query_xyz)
+    dp = group(support_xyz.transpose(1, 2).contiguous(), idx) - query_xyz.transpose(1, 2).unsqueeze(-1)
+    if normalize_dp:
+        dp = dp / radius
+    return dp, group(features, idx), idx
+
+
+def three_interpolation(unknown, known, feat):
+    """three_interpolation (upsampling.py:92-102; interpolate_gpu.cu:16-59, 84-104)."""
+    dist, idx = K.three_nn(unknown, known)
+    recip = 1.0 / (dist + 1e-8)
+    weight = recip / torch.sum(recip, dim=2, keepdim=True)
+    B, C, _ = feat.shape
+    g = feat.gather(2, idx.reshape(B, 1, -1).expand(-1, C, -1).long()).reshape(B, C, -1, 3)
+    w = weight.unsqueeze(1)
+    return w[..., 0] * g[..., 0] + w[..., 1] * g[..., 1] + w[..., 2] * g[..., 2]
+
+
+# ------------------------------------------------------------------------------------------
+# model: models/backbone/pointnext_AA.py + models/segmentation/base_seg.py
+# ------------------------------------------------------------------------------------------
+def _block_params(enc, attr, scaling):
+    """PointNextEncoder._to_full_list (pointnext_AA.py:374-392) for a scalar radius / nsample."""
+    out, param = [], enc[attr]
+    for i, stride in enumerate(enc["strides"]):
+        if stride == 1:
+            out.append([param] * enc["blocks"][i])
+        else:
+            out.append([param] + [param * scaling] * (enc["blocks"][i] - 1))
+            param = param * scaling
+    return out
+
+
+def model_forward(sd, cfg, data, training=True):
+    """BaseSeg_AMContrast3D.forward (base_seg.py:122-126) -> logits (B,ncls,N), stage list.
+
+    ``sd``: state dict (CPU tensors; those that require grad carry the autograd graph),
+    ``cfg``: the dict of amcontrast3d_amd.configs.model_cfg, ``data``: {'pos','x'} CPU tensors."""
+    enc = cfg["encoder_args"]
+    normalize_dp = enc["group_args"].get("normalize_dp", False)
+    radii = _block_params(enc, "radius", enc.get("radius_scaling", 2))
+    nsamples = _block_params(enc, "nsample", enc.get("nsample_scaling", 1))
+    sa_layers, sa_res = enc["sa_layers"], enc["sa_use_res"]
+
+    p, f = [data["pos"]], [data["x"]]
+    down = []
+    nstage = len(enc["blocks"])
+    for i in range(nstage):
+        pre = f"encoder.encoder.{i}.0"
+        stride = enc["strides"][i]
+        pi, fi_in = p[-1], f[-1]
+        if i == 0 and stride == 1:
+            # stem: point-wise conv, no norm / act (pointnext_AA.py:119-127, 141-142)
+            fo, po = _convblock(fi_in, sd, pre + ".convs.0", norm=False, act=False, training=training), pi
+        else:
+            # SetAbstraction.forward (pointnext_AA.py:139-170)
+            idx = K.furthest_point_sample(pi, pi.shape[1] // stride).long()
+            po = torch.gather(pi, 1, idx.unsqueeze(-1).expand(-1, -1, 3))
+            use_res = sa_res
+            if use_res:
+                fsel = torch.gather(fi_in, -1, idx.unsqueeze(1).expand(-1, fi_in.shape[1], -1))
+                identity = _convblock(fsel, sd, pre + ".skipconv", norm=False, act=False, training=training) \
+                    if (pre + ".skipconv.0.weight") in sd else fsel
+            dp, fj, _ = query_and_group(radii[i][0], nsamples[i][0], po.contiguous(), pi, fi_in, normalize_dp)
+            x = torch.cat([dp, fj], 1)  # get_aggregation_feautres 'dp_fj' (group.py:323-325)
+            for k in range(sa_layers):
+                last = k == sa_layers - 1
+                x = _convblock(x, sd, f"{pre}.convs.{k}", norm=True, act=not (last and use_res), training=training)
+            fo = torch.max(x, dim=-1)[0]
+            if use_res:
+                fo = F.relu(fo + identity)
+        # InvResMLP blocks (pointnext_AA.py:269-277, LocalAggregation :57-63)
+        for j in range(1, enc["blocks"][i]):
+            bp = f"encoder.encoder.{i}.{j}"
+            dp, fj, _ = query_and_group(radii[i][j], nsamples[i][j], po.contiguous(), po.contiguous(), fo, normalize_dp)
+            x = _convblock(torch.cat([dp, fj], 1), sd, bp + ".convs.convs.0", norm=True, act=True, training=training)
+            x = torch.max(x, dim=-1)[0]
+            x = _convblock(x, sd, bp + ".pwconv.0", norm=True, act=True, training=training)
+            x = _convblock(x, sd, bp + ".pwconv.1", norm=True, act=False, training=training)
+            fo = F.relu(x + fo)
+        p.append(po)
+        f.append(fo)
+        if i != nstage - 1:  # pointnext_AA.py:458-462
+            down.append({"p_out": po.reshape(-1, 3), "f_out": fo.transpose(1, 2).reshape(-1, fo.shape[1]),
+                         "offset": torch.tensor([po.shape[0] * po.shape[1]], dtype=torch.int32)})
+    stage = {"inputs": data, "down": down, "up": down}
+
+    # decoder (pointnext_AA.py:508-522; FeaturePropogation.forward :210-226)
+    ndec = 4
+    for i in range(-1, -ndec - 1, -1):
+        dpre = f"decoder.decoder.{ndec + i}.0"
+        up = three_interpolation(p[i - 1], p[i], f[i])
+        x = torch.cat((f[i - 1], up), dim=1)
+        k = 0
+        while f"{dpre}.convs.{k}.0.weight" in sd:
+            x = _convblock(x, sd, f"{dpre}.convs.{k}", norm=True, act=True, training=training)
+            k += 1
+        f[i - 1] = x
+        stage["up"][i]["f_out"] = x.transpose(1, 2).reshape(-1, x.shape[1])
+
+    # SegHead (base_seg.py:256-267); dropout is expected to be disabled (p = 0) in parity runs
+    x = f[-ndec - 1]
+    gf = cfg["cls_args"].get("global_feat")
+    if gf is not None:
+        parts = []
+        for kind in gf.split(","):
+            parts.append(torch.max(x, dim=-1, keepdim=True)[0] if "max" in kind else torch.mean(x, dim=-1, keepdim=True))
+        x = torch.cat((x, torch.cat(parts, dim=1).expand(-1, -1, x.shape[-1])), dim=1)
+    keys = sorted({int(k.split(".")[2]) for k in sd if k.startswith("head.head.")})
+    for n, hi in enumerate(keys):
+        lastk = n == len(keys) - 1
+        x = _convblock(x, sd, f"head.head.{hi}", norm=not lastk, act=not lastk, training=training)
+    return x, stage
+
+
+# ------------------------------------------------------------------------------------------
+# loss: loss/build.py:331-346, AMContrast3D/MarginContrast.py, AMContrast3D/AEF/*
+# ------------------------------------------------------------------------------------------
+def subscene_labels(stage_i, stage, target, num_classes, ignore_index):
+    """get_subscene_label_CBL (AEF/utils.py:11-43) -> (m, ncls) soft labels."""
+    if ignore_index is not None:
+        num_classes = num_classes + 1
+        if (target == ignore_index).sum() > 0:
+            target = target.clone()
+            target[target == ignore_index] = num_classes - 1
+    x = F.one_hot(target, num_classes)
+    if stage_i == 0:
+        return x.float()
+    kr = 4 ** stage_i  # prod(nstride[:i]) with nstride = [4,4,4,4] (MarginContrast.py:59)
+    src, dst = stage["up"][0], stage["up"][stage_i]
+    nidx, _ = K.knnquery(kr, src["p_out"].contiguous(), dst["p_out"].contiguous(), src["offset"], dst["offset"])
+    x = x[nidx.view(-1).long(), :].view(dst["p_out"].shape[0], kr, x.shape[1])
+    return x.float().mean(-2)
+
+
+def ambiguity(p, posmask, neighbor_idx, beta):
+    """ambiguity_function, cctype Method2 (AEF/ambiguity.py:11-71; function.py:10-39)."""
+    mask_num = posmask.int().sum(-1)
+    top = mask_num.max()
+    a = torch.abs(mask_num - top).div(top)
+    boundary = (0 < mask_num) & (mask_num < top)
+    mb = posmask[boundary]
+    n_pos, n_neg = mb.int().sum(-1), (1 - mb.int()).sum(-1)
+    src = p[boundary].unsqueeze(1)
+    dst = p[neighbor_idx[boundary].long()]
+    dd = -2 * torch.matmul(src, dst.permute(0, 2, 1))
+    dd += torch.sum(src ** 2, -1).view(-1, 1, 1)
+    dd += torch.sum(dst ** 2, -1).view(dst.shape[0], 1, -1)
+    dd = dd.squeeze(1)
+    d_pos = (mb.int() * dd).sum(-1)
+    d_neg = ((1 - mb.int()) * dd).sum(-1)
+    cc = n_pos / d_pos - n_neg / d_neg
+    t = torch.full(cc.shape, math.e)
+    a[boundary] = 1 / (1 + t.pow(beta * cc))
+    return a
+
+
+def contrast_stage(stage_i, stage, target, num_classes, ignore_index, args):
+    """ContrastHead.point_contrast_margin (MarginContrast.py:220-259) -> (loss_i, a_i)."""
+    st = stage["up"][stage_i]
+    p, feats, o = st["p_out"].contiguous(), st["f_out"], st["offset"]
+    labels = subscene_labels(stage_i, stage, target, num_classes, ignore_index)
+    nidx, _ = K.knnquery(args["nsample"], p, p, o, o)
+    nidx = nidx[..., 1:].contiguous()
+    m, k = nidx.shape
+    flat = nidx.view(-1).long()
+    posmask = torch.argmax(labels, -1).unsqueeze(-1) == torch.argmax(labels[flat].view(m, k, -1), -1)
+    a = ambiguity(p, posmask, nidx, args["ccbeta"])
+    keep = (0 < a) & (a <= 1)
+    fk = feats[keep]
+    nf = feats[flat].view(m, k, -1)[keep]
+    sim = F.cosine_similarity(fk.unsqueeze(-2), nf, dim=2)            # dist_cos (:77-79)
+    pm, ak = posmask[keep], a[keep]
+    margin = args["mu"] * ak.unsqueeze(-1) + args["nu"]              # 'adaptive' (:123-126)
+    s = (sim - margin) * pm + sim * ~pm                               # db '-m' (:141-142)
+    e = torch.exp(s / args["temperature"])
+    loss = -torch.log((e * pm).sum(-1) / e.sum(-1) + 1e-12)           # Method1 (:159-173)
+    return loss.mean(), a
+
+
+def criterion(logits, target, stage, num_classes, ignore_index, args):
+    """CrossEntropyAce.forward (loss/build.py:331-346) -> (loss, ce, [contrast_i], [a_i])."""
+    logit = logits.transpose(1, 2).reshape(-1, logits.shape[1])
+    tgt = target.flatten()
+    ce = F.cross_entropy(logit, tgt)
+    parts, amb = [], []
+    for i in range(args["stages_num"]):
+        li, ai = contrast_stage(i, stage, tgt, num_classes, ignore_index, args)
+        parts.append(li)
+        amb.append(ai)
+    return args["w1"] * ce + args["w2"] * sum(parts), ce, parts, amb
+
+
+def train_step(sd, cfg, data, target, num_classes, ignore_index, args):
+    """forward + loss + backward on leaf copies of ``sd``; returns (loss, logits, grads dict)."""
+    leaf = {k: (v.detach().clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
+            for k, v in sd.items()}
+    logits, stage = model_forward(leaf, cfg, data, training=True)
+    loss, ce, parts, amb = criterion(logits, target, stage, num_classes, ignore_index, args)
+    loss.backward()
+    grads = {k: v.grad for k, v in leaf.items() if isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None}
+    return {"loss": loss.detach(), "ce": ce.detach(), "contrast": [x.detach() for x in parts], "ambiguity": amb,
+            "logits": logits.detach(), "grads": grads, "stage": stage}

@@ -1,0 +1,172 @@
+"""Host-side contract of the drop-in (no GPU needed): registries, config objects, module / state-dict
+naming identical to the reference (key lists recorded from the reference's own classes in
+tests/golden/state_keys.json), and the C-ABI library exporting every symbol include/amc3d.h declares."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+import amcontrast3d_amd
+from amcontrast3d_amd import configs
+from conftest import GOLDEN, ROOT
+
+amcontrast3d_amd.activate()
+
+from openpoints.loss import LOSS, build_criterion_from_cfg  # noqa: E402
+from openpoints.models import MODELS, build_model_from_cfg  # noqa: E402
+from openpoints.utils import EasyConfig, registry  # noqa: E402
+
+
+def easy(d):
+    c = EasyConfig()
+    c.update(d)
+    return c
+
+
+def test_openpoints_resolves_to_this_build():
+    import openpoints
+    assert openpoints.__file__.startswith(os.path.join(ROOT, "amcontrast3d_amd"))
+
+
+def test_registry_contract():
+    assert {"BaseSeg_AMContrast3D", "PointNextEncoder_AMContrast3D", "PointNextDecoder_AMContrast3D", "SegHead"} <= set(MODELS.module_dict)
+    assert {"CrossEntropyAce", "CrossEntropy", "CrossEntropyLoss", "BCEWithLogitsLoss"} <= set(LOSS.module_dict)
+    R = registry.Registry("things")
+
+    @R.register_module()
+    class A:
+        def __init__(self, x, y=2):
+            self.x, self.y = x, y
+
+    R.register_module(name="alias", module=A)
+    assert R.get("A") is A and R.get("alias") is A and "A" in R and len(R) == 2
+    with pytest.raises(KeyError, match="already registered"):
+        R.register_module(module=A)
+    cfg = {"NAME": "A", "x": 1}
+    obj = R.build(cfg)
+    assert (obj.x, obj.y) == (1, 2) and cfg == {"NAME": "A", "x": 1}  # cfg is deep-copied, not consumed
+    with pytest.raises(KeyError, match="not in the things registry"):
+        R.build({"NAME": "B"})
+    with pytest.raises(KeyError, match='must contain the key "NAME"'):
+        R.build({"x": 1})
+    with pytest.raises(TypeError, match="cfg must be a dict"):
+        R.build([1])
+    with pytest.raises(TypeError, match="^A: "):  # ctor errors carry the class name (registry.py:292-294)
+        R.build({"NAME": "A"})
+
+
+def test_easyconfig_behaviour(tmp_path):
+    c = easy({"a": {"b": 1, "c": {"d": 2}}, "e": [1, 2]})
+    assert c.a.c.d == 2 and isinstance(c.a, EasyConfig)
+    c.update(["a.b=5", "--a.c.d", "7", "new.key=[1,2]", "s=hello"])
+    assert c.a.b == 5 and c.a.c.d == 7 and c.new.key == [1, 2] and c.s == "hello"
+    with pytest.raises(AttributeError):
+        c.missing
+    # recursive default.yaml layering (utils/config.py:30-49)
+    (tmp_path / "default.yaml").write_text("x: 1\ny: {z: 1}\n")
+    sub = tmp_path / "ds"
+    sub.mkdir()
+    (sub / "default.yaml").write_text("y: {z: 2, w: 3}\n")
+    (sub / "m.yaml").write_text("x: 9\n")
+    d = EasyConfig()
+    d.load(str(sub / "m.yaml"), recursive=True)
+    assert d.x == 9 and d.y.z == 2 and d.y.w == 3
+    assert d.dict() == {"x": 9, "y": {"z": 2, "w": 3}} and len(d.hash()) == 64
+
+
+@pytest.mark.parametrize("variant", ["S", "B", "L", "XL"])
+def test_state_dict_keys_match_reference(variant):
+    keys = json.load(open(os.path.join(GOLDEN, "state_keys.json")))
+    model = build_model_from_cfg(easy(configs.model_cfg(variant)))
+    got = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert got == keys[variant]
+    assert sum(p.numel() for p in model.parameters()) == keys[variant + "_nparams"]
+
+
+def test_scannet_head_and_bn_module_types():
+    keys = json.load(open(os.path.join(GOLDEN, "state_keys.json")))
+    model = build_model_from_cfg(easy(configs.model_cfg("S", num_classes=20, in_channels=7, global_feat="max")))
+    assert {k: list(v.shape) for k, v in model.state_dict().items()} == keys["S_scannet"]
+    # BN layers must stay real torch modules so SyncBatchNorm conversion / DDP see them (main_AA.py:146-151)
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    assert len(bns) == 17
+    conv = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    assert sum(isinstance(m, torch.nn.SyncBatchNorm) for m in conv.modules()) == 17
+
+
+def test_builder_side_effects_on_cfg():
+    """Built through the registry the constructors work on a deep copy (registry.py:287), so the caller's
+    cfg is untouched; built directly they write into the caller's objects like the reference does."""
+    cfg = easy(configs.model_cfg("S"))
+    model = build_model_from_cfg(cfg)
+    assert cfg.cls_args.in_channels is None and model.decoder.out_channels == 32
+    assert "radius" not in cfg.encoder_args.group_args
+    assert model.encoder.channel_list == [32, 64, 128, 256, 512] and model.encoder.out_channels == 512
+    assert model.encoder.radii == [[0.1], [0.1], [0.2], [0.4], [0.8]]
+    assert [s[0].grouper.radius for s in list(model.encoder.encoder)[1:]] == [0.1, 0.2, 0.4, 0.8]
+    enc = easy(configs.model_cfg("S")["encoder_args"])
+    from openpoints.models.backbone import PointNextEncoder_AMContrast3D
+    ga = enc.group_args
+    kw = dict(enc); kw.pop("NAME")
+    PointNextEncoder_AMContrast3D(**kw)
+    assert ga.radius == 0.8 and ga.nsample == 32  # pointnext_AA.py:362-363, 405-406 leave the last stage's values
+
+
+def test_criterion_ctor_swallows_kwargs():
+    crit = build_criterion_from_cfg(easy({"NAME": "CrossEntropyAce", "label_smoothing": 0.2, "weight": None, "ignore_index": -100}))
+    assert isinstance(crit.creterion, torch.nn.CrossEntropyLoss) and crit.creterion.label_smoothing == 0.0
+    assert type(crit.contrast_head).__name__ == "ContrastHead"
+    assert crit.contrast_head.nstride.tolist() == [4, 4, 4, 4]
+
+
+def test_product_ops_have_no_cpu_path():
+    from amcontrast3d_amd import ops
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.ball_query(0.1, 4, torch.rand(1, 8, 3), torch.rand(1, 2, 3))
+    model = build_model_from_cfg(easy(configs.model_cfg("S")))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        model({"pos": torch.rand(1, 64, 3), "x": torch.rand(1, 4, 64)})
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from amcontrast3d_amd import _lib
+    header = open(os.path.join(ROOT, "include", "amc3d.h")).read()
+    declared = set(re.findall(r"\b(amc3d_\w+)\s*\(", header))
+    assert declared and declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    so = _lib.build()
+    lib = ctypes.CDLL(so)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.amc3d_version.restype = ctypes.c_char_p
+    assert lib.amc3d_version() == b"amc3d-hip gfx950 1"
+    # no torch / libc10 dependency in the boundary library
+    import subprocess
+    deps = subprocess.run(["ldd", so], capture_output=True, text=True).stdout
+    assert "torch" not in deps and "c10" not in deps
+
+
+def test_compat_modules_have_the_reference_entry_points():
+    from amcontrast3d_amd import compat
+    names = ["ball_query_wrapper", "group_points_wrapper", "group_points_grad_wrapper", "gather_points_wrapper",
+             "gather_points_grad_wrapper", "furthest_point_sampling_wrapper", "three_nn_wrapper",
+             "three_interpolate_wrapper", "three_interpolate_grad_wrapper"]  # pointnet2_api.cpp:10-24
+    for n in names:
+        assert callable(getattr(compat.pointnet2_batch_cuda, n))
+    assert callable(compat.pointops_cuda.knnquery_cuda)  # pointops_api.cpp:14
+
+
+def test_synthetic_scenes_are_reproducible_and_shaped():
+    from amcontrast3d_amd import synthetic
+    a = synthetic.make_batch(2, 1500, first_id=3)
+    b = synthetic.make_batch(2, 1500, first_id=3)
+    for k in a:
+        assert (a[k] == b[k]).all()
+    assert a["pos"].shape == (2, 1500, 3) and a["x"].shape == (2, 4, 1500) and a["y"].shape == (2, 1500)
+    assert a["pos"].dtype == "float32" and a["y"].dtype == "int64" and a["pos"].min() == 0
+    assert (a["x"][:, 3] == a["pos"][..., 2]).all()  # heights channel
+    d = synthetic.make_scene(5, 4000, duplicates=True)
+    import numpy as np
+    assert len(np.unique(d["pos"], axis=0)) < 4000  # padded by repetition like data_util.py:161-167

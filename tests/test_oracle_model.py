@@ -1,0 +1,64 @@
+"""The oracle's model/loss restatement (oracle/model_ref.py) against outputs recorded from the
+reference's own Python layer (oracle/gen_golden.py -> tests/golden/model_*.npz).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from amcontrast3d_amd import configs
+from conftest import load_golden
+from oracle import model_ref
+
+CASES = ["model_S_b2_n2048", "model_w8_blocks_b2_n1024", "model_S_scannet_b2_n2048"]
+
+
+def reference_state_dict(g, cfg):
+    """Weights of the golden run: stored, or re-created from seed 0 and verified by checksum."""
+    if any(k.startswith("w/") for k in g):
+        return {k[2:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("w/")}
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from openpoints.models import build_model_from_cfg
+    from openpoints.utils import EasyConfig
+    torch.manual_seed(0)
+    c = EasyConfig()
+    c.update(cfg)
+    sd = build_model_from_cfg(c).state_dict()
+    for k, (s, a) in g["meta"]["param_checksums"].items():
+        v = sd[k].double()
+        assert abs(float(v.sum()) - s) <= 1e-9 * max(1, abs(s)) and abs(float(v.abs().sum()) - a) <= 1e-9 * max(1, a), k
+    return sd
+
+
+def case_setup(name):
+    g = load_golden(name)
+    m = g["meta"]
+    cfg = configs.model_cfg(m["variant"], num_classes=m["num_classes"], in_channels=m["in_channels"], dropout=0,
+                            **m["model_kw"])
+    sd = reference_state_dict(g, cfg)
+    data = {"pos": torch.from_numpy(g["pos"]), "x": torch.from_numpy(g["x"])}
+    target = torch.from_numpy(g["y"])
+    return g, m, cfg, sd, data, target
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference_run(name):
+    g, m, cfg, sd, data, target = case_setup(name)
+    torch.set_num_threads(8)
+    r = model_ref.train_step(sd, cfg, data, target, m["num_classes"], m["ignore_index"],
+                             configs.ambiguity_args(m["dataset"]))
+    # tolerance stated by BASELINE.json north_star: logits / loss within 1e-4 (fp32)
+    np.testing.assert_allclose(r["logits"].numpy(), g["logits"], rtol=1e-4, atol=1e-4)
+    assert abs(float(r["loss"]) - float(g["loss"])) <= 1e-4 * max(1.0, abs(float(g["loss"])))
+    assert abs(float(r["ce"]) - float(g["loss_ce"])) <= 1e-4
+    for i in range(4):
+        assert abs(float(r["contrast"][i]) - float(g[f"contrast/{i}"])) <= 1e-4, i
+        np.testing.assert_allclose(r["ambiguity"][i].numpy(), g[f"ambiguity/{i}"], rtol=0, atol=1e-4)
+        np.testing.assert_array_equal(r["stage"]["up"][i]["p_out"].numpy(), g[f"p_out/{i}"])  # FPS picks: exact
+        np.testing.assert_allclose(r["stage"]["up"][i]["f_out"].detach().numpy(), g[f"f_out/{i}"], rtol=1e-4, atol=1e-4)
+    for k, v in g.items():
+        if k.startswith("g/"):
+            ref = torch.from_numpy(v)
+            got = r["grads"][k[2:]]
+            assert float((got - ref).norm()) <= 1e-3 * float(ref.norm()) + 1e-7, k
+    for k, n in m["grad_norms"].items():
+        assert abs(float(r["grads"][k].double().norm()) - n) <= 2e-3 * n + 1e-6, k
