@@ -44,8 +44,8 @@ def parse():
     ap.add_argument("--points", type=int, default=24000)
     ap.add_argument("--variant", default="S")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-batch", type=int, default=None,
-                    help="clouds in the CPU sample (default: the full per-GPU batch)")
+    ap.add_argument("--cpu-baseline-batch", type=int, default=2,
+                    help="clouds in the CPU sample (bounded: the full batch of 8 takes minutes on the host)")
     return ap.parse_args()
 
 
@@ -77,8 +77,10 @@ def cpu_baseline(cfg, model, batch_np, aargs_dict, points_per_step):
     """One step of the oracle's CPU restatement on the same batch (bounded sample: one step)."""
     from oracle import model_ref, pointops_ref
     pointops_ref.build()
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, int(os.environ.get("AMC3D_CPU_THREADS", "16")))  # the box's CPU share for one GPU
     torch.set_num_threads(cores)
+    pointops_ref.set_threads(cores)
     sd = {k: v.detach().cpu().clone() for k, v in (model.module if hasattr(model, "module") else model).state_dict().items()}
     cfg = json.loads(json.dumps(cfg))
     cfg["cls_args"]["dropout"] = 0

@@ -23,7 +23,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <omp.h>
+
 #define REF_API __attribute__((visibility("default")))
+
+/* number of OpenMP threads the restatement uses (bench.py's cpu_baseline states it) */
+REF_API void ref_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+REF_API int ref_get_threads(void) { return omp_get_max_threads(); }
 
 /* ------------------------------------------------------------------------ *
  * ball query -- openpoints/cpp/pointnet2_batch/src/ball_query_gpu.cu:15-51

@@ -105,6 +105,11 @@ def knnquery_cuda(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2):
     lib().ref_knnquery(_c(m), _c(nsample), _f(xyz), _f(new_xyz), _i(offset), _i(new_offset), _i(idx), _f(dist2))
 
 
+def set_threads(n):
+    lib().ref_set_threads(_c(int(n)))
+    return int(lib().ref_get_threads())
+
+
 def fps_block_size(n):
     return int(lib().ref_fps_block_size(_c(n)))
 
