@@ -120,28 +120,453 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_exact_kernel(
     }
 }
 
+
+// =============================================================================================
+// Grid-accelerated path (k <= 64).
+//
+// Brute force is O(m*n): 5.1e10 distance evaluations per training step at the benchmark shape.
+// The same answers come from a uniform grid over the support cloud: bin the support points into
+// cells of edge h (counting sort, x fastest), then each query scans the 3x3x3 block of cells
+// around it, then shells of growing Chebyshev radius R, until its current k-th distance is
+// provably smaller than the distance to anything outside the scanned block.
+//
+// Exactness.  One wavefront owns one query and keeps its k best candidates in lanes 0..k-1,
+// sorted ascending (insertion = one ballot + a lane shift).  When the k+1 smallest distances of a
+// query are pairwise different, the reference's max-heap + heap-sort output is fully determined:
+// those k indices in ascending distance -- independent of scan order -- which is what the lane
+// list holds.  When two of them are EQUAL the reference's output depends on its heap history
+// (index scan order); such queries are detected (adjacent equal values in the list, or the best
+// rejected distance equal to the k-th) and recomputed by knn_exact_kernel, which replays the
+// reference's heap.  Distances are always the reference's expression (dist2_ref).
+//
+// Cell size.  h is calibrated on the data, per call: 64 sample queries get their exact k-th
+// neighbour distance by brute force (one workgroup each), and h = 1.05 * the 80th percentile, so
+// that ~4 of 5 queries finish after the 3x3x3 block whatever the density or dimensionality of the
+// cloud (surfaces, volumes, 8 overlapping clouds in one segment...).
+// =============================================================================================
+constexpr int KG_SAMPLES = 64;
+constexpr int KG_MAXK = 64;
+
+struct GridParams {
+    float minx, miny, minz, h, inv_h, margin;
+    int nx, ny, nz, ncell;  // per segment
+};
+
+struct KnnWorkspace {           // byte offsets into the caller's workspace
+    size_t params, bbox, samples, fb_count, cell_start, cursor, sorted, fb_list, total;
+};
+
+__host__ __device__ inline int knn_cell_cap(int n)
+{
+    long c = 8L * n;
+    if (c < 4096) c = 4096;
+    if (c > (1L << 22)) c = 1L << 22;
+    return (int)c;
+}
+
+static KnnWorkspace knn_layout(int n, int m)
+{
+    KnnWorkspace w;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t cap = (size_t)knn_cell_cap(n);
+    w.params = 0;
+    w.bbox = 256;
+    w.samples = 512;
+    w.fb_count = 1024;
+    w.cell_start = 2048;
+    w.cursor = up(w.cell_start + (cap + 1) * 4);
+    w.sorted = up(w.cursor + (cap + 1) * 4);
+    w.fb_list = up(w.sorted + (size_t)n * 16);
+    w.total = up(w.fb_list + (size_t)m * 4);
+    return w;
+}
+
+// order-preserving float <-> int for atomicMin/Max
+__device__ __forceinline__ int f2ord(float f)
+{
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__global__ void kg_init_kernel(int *bbox, int *fb_count)
+{
+    if (threadIdx.x < 3) bbox[threadIdx.x] = 0x7fffffff;          // min
+    else if (threadIdx.x < 6) bbox[threadIdx.x] = (int)0x80000000;  // max
+    if (threadIdx.x == 6) *fb_count = 0;
+}
+
+__global__ __launch_bounds__(256) void kg_bbox_kernel(int n, const float *__restrict__ xyz, int *__restrict__ bbox)
+{
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = xyz[(size_t)i * 3 + c];
+            lo[c] = fminf(lo[c], v);
+            hi[c] = fmaxf(hi[c], v);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        for (int s = 32; s >= 1; s >>= 1) {
+            lo[c] = fminf(lo[c], __shfl_xor(lo[c], s, 64));
+            hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], s, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            atomicMin(bbox + c, f2ord(lo[c]));
+            atomicMax(bbox + 3 + c, f2ord(hi[c]));
+        }
+    }
+}
+
+// segment [start,end) of point/query `i` given cumulative ends (knnquery_cuda_kernel.cu:51-62,74-80)
+__device__ __forceinline__ int seg_of(int i, const int *__restrict__ ends, int nb)
+{
+    int s = 0;
+    while (s < nb - 1 && !(i < ends[s])) ++s;
+    return s;
+}
+
+// ---- a wavefront's sorted list of its k best candidates (lanes 0..k-1) ---------------------------
+struct LaneList {
+    float v;    // this lane's distance (ascending with lane id); 1e10 = the reference's placeholder
+    int id;     // this lane's point index
+    float tau;  // wave-uniform copy of the k-th (worst kept) distance
+};
+
+__device__ __forceinline__ void ll_init(LaneList &l, int start)
+{
+    l.v = 1e10f;
+    l.id = start;
+    l.tau = 1e10f;
+}
+
+// insert (cd, ci), cd < tau, keeping ascending order; returns the evicted k-th value
+__device__ __forceinline__ float ll_insert(LaneList &l, int k, int lane, float cd, int ci)
+{
+    const float evicted = l.tau;
+    const int p = (int)__popcll(__ballot(lane < k && l.v <= cd));  // first lane with v > cd
+    const float upv = __shfl_up(l.v, 1, 64);
+    const int upi = __shfl_up(l.id, 1, 64);
+    if (lane > p) { l.v = upv; l.id = upi; }
+    if (lane == p) { l.v = cd; l.id = ci; }
+    l.tau = __shfl(l.v, k - 1, 64);
+    return evicted;
+}
+
+// feed one chunk of up to 64 candidates (one per lane) to the list; rej tracks rejected distances
+__device__ __forceinline__ void ll_feed(LaneList &l, int k, int lane, bool valid, float d2, int ci, float &rej_lane,
+                                        float &rej_uni)
+{
+    const bool pass = valid && d2 < l.tau;
+    rej_lane = fminf(rej_lane, (valid && !pass) ? d2 : 3.4e38f);
+    unsigned long long mask = __ballot(pass);
+    while (mask) {
+        const int b = (int)__builtin_ctzll(mask);
+        mask &= mask - 1;
+        const float cd = __shfl(d2, b, 64);
+        const int cc = __shfl(ci, b, 64);
+        if (cd < l.tau) rej_uni = fminf(rej_uni, ll_insert(l, k, lane, cd, cc));
+        else rej_uni = fminf(rej_uni, cd);
+    }
+}
+
+// ---- calibration: exact k-th neighbour distance of KG_SAMPLES queries -----------------------------
+__global__ __launch_bounds__(1024) void kg_sample_kernel(int m, int k, int nb, const float *__restrict__ xyz,
+                                                         const float *__restrict__ new_xyz,
+                                                         const int *__restrict__ offset,
+                                                         const int *__restrict__ new_offset, float *__restrict__ samples)
+{
+    __shared__ float vals[16 * KG_MAXK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = (int)(((long)blockIdx.x * m) / KG_SAMPLES);
+    const int s = seg_of(q, new_offset, nb);
+    const int start = s == 0 ? 0 : offset[s - 1], end = offset[s];
+    const float qx = new_xyz[(size_t)q * 3], qy = new_xyz[(size_t)q * 3 + 1], qz = new_xyz[(size_t)q * 3 + 2];
+    LaneList l;
+    ll_init(l, start);
+    float rl = 3.4e38f, ru = 3.4e38f;
+    const int span = (end - start + 15) / 16;
+    const int lo = start + wave * span, hi = min(end, lo + span);
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int i = i0 + lane;
+        const bool valid = i < hi;
+        const int ii = valid ? i : lo;
+        const float d2 = dist2_ref(qx, qy, qz, xyz[(size_t)ii * 3], xyz[(size_t)ii * 3 + 1], xyz[(size_t)ii * 3 + 2]);
+        ll_feed(l, k, lane, valid, d2, i, rl, ru);
+    }
+    if (lane < k) vals[wave * k + lane] = l.v;
+    __syncthreads();
+    // the k-th smallest of the 16*k kept values: rank by counting
+    const int total = 16 * k;
+    if ((int)threadIdx.x < total) {
+        const float mine = vals[threadIdx.x];
+        int rank = 0;
+        for (int j = 0; j < total; ++j) {
+            const float o = vals[j];
+            rank += (o < mine || (o == mine && j < (int)threadIdx.x)) ? 1 : 0;
+        }
+        if (rank == k - 1) samples[blockIdx.x] = mine;
+    }
+}
+
+__global__ __launch_bounds__(64) void kg_params_kernel(int n, int nb, const int *__restrict__ bbox,
+                                                       const float *__restrict__ samples, GridParams *__restrict__ gp)
+{
+    const int lane = threadIdx.x;
+    const float mine = samples[lane];
+    int rank = 0;
+    for (int j = 0; j < KG_SAMPLES; ++j) {
+        const float o = __shfl(mine, j, 64);
+        rank += (o < mine || (o == mine && j < lane)) ? 1 : 0;
+    }
+    const unsigned long long pick = __ballot(rank == (KG_SAMPLES * 4) / 5);
+    const float r2 = __shfl(mine, (int)__builtin_ctzll(pick), 64);
+    if (lane != 0) return;
+    const float minx = ord2f(bbox[0]), miny = ord2f(bbox[1]), minz = ord2f(bbox[2]);
+    const float ex = fmaxf(ord2f(bbox[3]) - minx, 0.f), ey = fmaxf(ord2f(bbox[4]) - miny, 0.f),
+                ez = fmaxf(ord2f(bbox[5]) - minz, 0.f);
+    const float emax = fmaxf(fmaxf(ex, ey), fmaxf(ez, 1e-30f));
+    float h = 1.05f * sqrtf(r2);
+    if (!(r2 < 1e9f) || !(h > emax * 1e-6f)) h = emax;  // fewer than k points, or all points coincide
+    const float cap = (float)(knn_cell_cap(n) / (nb > 0 ? nb : 1));
+    // grow h until the grid fits the cell budget (float arithmetic: no int overflow on huge extents)
+    for (int it = 0; it < 400 && (ex / h + 1.f) * (ey / h + 1.f) * (ez / h + 1.f) > cap; ++it) h *= 1.26f;
+    const int nx = (int)(ex / h) + 1, ny = (int)(ey / h) + 1, nz = (int)(ez / h) + 1;
+    gp->minx = minx; gp->miny = miny; gp->minz = minz;
+    gp->h = h;
+    gp->inv_h = 1.f / h;
+    // fp32 rounding of (x - min) * inv_h is below 2^-22 * (cells along the axis): stay clear of it
+    gp->margin = h * (1e-3f + 4e-7f * (float)max(nx, max(ny, nz)));
+    gp->nx = nx; gp->ny = ny; gp->nz = nz;
+    gp->ncell = nx * ny * nz;
+}
+
+__device__ __forceinline__ int cell_coord(float v, float mn, float inv_h, int dim)
+{
+    const int c = (int)floorf((v - mn) * inv_h);
+    return min(max(c, 0), dim - 1);
+}
+
+__global__ void kg_count_kernel(int n, int nb, const float *__restrict__ xyz, const int *__restrict__ offset,
+                                const GridParams *__restrict__ gp, int *__restrict__ cell_count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const GridParams g = *gp;
+    const int cx = cell_coord(xyz[(size_t)i * 3], g.minx, g.inv_h, g.nx);
+    const int cy = cell_coord(xyz[(size_t)i * 3 + 1], g.miny, g.inv_h, g.ny);
+    const int cz = cell_coord(xyz[(size_t)i * 3 + 2], g.minz, g.inv_h, g.nz);
+    const int seg = nb > 1 ? seg_of(i, offset, nb) : 0;
+    atomicAdd(cell_count + (size_t)seg * g.ncell + ((size_t)cz * g.ny + cy) * g.nx + cx, 1);
+}
+
+// in-place exclusive scan of cell_count[0 .. nb*ncell] (one workgroup; the grid is at most 4M cells)
+__global__ __launch_bounds__(1024) void kg_scan_kernel(int nb, const GridParams *__restrict__ gp, int *__restrict__ cells)
+{
+    __shared__ int part[1024];
+    const int total = nb * gp->ncell;
+    const int per = (total + 1023) / 1024;
+    const int lo = min(threadIdx.x * per, total), hi = min(lo + per, total);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += cells[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int s = 1; s < 1024; s <<= 1) {  // Hillis-Steele inclusive scan
+        const int v = threadIdx.x >= s ? part[threadIdx.x - s] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+    for (int i = lo; i < hi; ++i) {
+        const int c = cells[i];
+        cells[i] = run;
+        run += c;
+    }
+    if (threadIdx.x == 1023) cells[total] = part[1023];
+}
+
+__global__ void kg_scatter_kernel(int n, int nb, const float *__restrict__ xyz, const int *__restrict__ offset,
+                                  const GridParams *__restrict__ gp, const int *__restrict__ cell_start,
+                                  int *__restrict__ cursor, float4 *__restrict__ sorted)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const GridParams g = *gp;
+    const float x = xyz[(size_t)i * 3], y = xyz[(size_t)i * 3 + 1], z = xyz[(size_t)i * 3 + 2];
+    const int cx = cell_coord(x, g.minx, g.inv_h, g.nx), cy = cell_coord(y, g.miny, g.inv_h, g.ny),
+              cz = cell_coord(z, g.minz, g.inv_h, g.nz);
+    const int seg = nb > 1 ? seg_of(i, offset, nb) : 0;
+    const size_t cell = (size_t)seg * g.ncell + ((size_t)cz * g.ny + cy) * g.nx + cx;
+    const int pos = cell_start[cell] + atomicAdd(cursor + cell, 1);
+    sorted[pos] = make_float4(x, y, z, __int_as_float(i));
+}
+
+// ---- queries --------------------------------------------------------------------------------------
+__device__ __forceinline__ void kg_scan_range(LaneList &l, int k, int lane, int b, int e, float qx, float qy, float qz,
+                                              const float4 *__restrict__ sorted, float &rl, float &ru)
+{
+    for (int i0 = b; i0 < e; i0 += 64) {
+        const int i = i0 + lane;
+        const bool valid = i < e;
+        const float4 p = sorted[valid ? i : b];
+        const float d2 = dist2_ref(qx, qy, qz, p.x, p.y, p.z);
+        ll_feed(l, k, lane, valid, d2, __float_as_int(p.w), rl, ru);
+    }
+}
+
+__global__ __launch_bounds__(256) void kg_query_kernel(int m, int k, int nb, const float *__restrict__ new_xyz,
+                                                       const int *__restrict__ offset,
+                                                       const int *__restrict__ new_offset,
+                                                       const GridParams *__restrict__ gp,
+                                                       const int *__restrict__ cell_start,
+                                                       const float4 *__restrict__ sorted, int *__restrict__ idx,
+                                                       float *__restrict__ dist2, int *__restrict__ fb_list,
+                                                       int *__restrict__ fb_count)
+{
+    const int lane = threadIdx.x & 63;
+    const GridParams g = *gp;
+    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < m; q += gridDim.x * 4) {
+        const int seg = nb > 1 ? seg_of(q, new_offset, nb) : 0;
+        const int start = seg == 0 ? 0 : offset[seg - 1];
+        const float qx = new_xyz[(size_t)q * 3], qy = new_xyz[(size_t)q * 3 + 1], qz = new_xyz[(size_t)q * 3 + 2];
+        const int cx = cell_coord(qx, g.minx, g.inv_h, g.nx), cy = cell_coord(qy, g.miny, g.inv_h, g.ny),
+                  cz = cell_coord(qz, g.minz, g.inv_h, g.nz);
+        const int *cs = cell_start + (size_t)seg * g.ncell;
+        LaneList l;
+        ll_init(l, start);
+        float rl = 3.4e38f, ru = 3.4e38f;
+
+        for (int R = 1;; ++R) {
+            // (dz,dy) pairs of this shell, one per lane, in batches of 64: a pair on the shell's
+            // rim contributes the full x-run [cx-R, cx+R]; an interior pair only its two end cells
+            // (for R == 1 every pair contributes the full run: the whole 3x3x3 block)
+            const int side = 2 * R + 1, npairs = side * side;
+            for (int p0 = 0; p0 < npairs; p0 += 64) {
+                const int pi = p0 + lane;
+                int bA = 0, eA = 0, bB = 0, eB = 0;
+                if (pi < npairs) {
+                    const int dz = pi / side - R, dy = pi % side - R;
+                    const int z = cz + dz, y = cy + dy;
+                    if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+                        const int row = (z * g.ny + y) * g.nx;
+                        const bool rim = R == 1 || dz == -R || dz == R || dy == -R || dy == R;
+                        if (rim) {
+                            const int x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
+                            bA = cs[row + x0];
+                            eA = cs[row + x1 + 1];
+                        } else {
+                            if (cx - R >= 0) { bA = cs[row + cx - R]; eA = cs[row + cx - R + 1]; }
+                            if (cx + R < g.nx) { bB = cs[row + cx + R]; eB = cs[row + cx + R + 1]; }
+                        }
+                    }
+                }
+                unsigned long long mA = __ballot(eA > bA);
+                while (mA) {
+                    const int src = (int)__builtin_ctzll(mA);
+                    mA &= mA - 1;
+                    kg_scan_range(l, k, lane, __shfl(bA, src, 64), __shfl(eA, src, 64), qx, qy, qz, sorted, rl, ru);
+                }
+                unsigned long long mB = __ballot(eB > bB);
+                while (mB) {
+                    const int src = (int)__builtin_ctzll(mB);
+                    mB &= mB - 1;
+                    kg_scan_range(l, k, lane, __shfl(bB, src, 64), __shfl(eB, src, 64), qx, qy, qz, sorted, rl, ru);
+                }
+            }
+            // everything outside the scanned block is at least `dmin` away (sides that coincide with
+            // the grid boundary impose nothing: there are no points beyond it)
+            float dmin = 3.4e38f;
+            bool whole = true;
+            if (cx - R > 0) { dmin = fminf(dmin, qx - (g.minx + (float)(cx - R) * g.h)); whole = false; }
+            if (cx + R + 1 < g.nx) { dmin = fminf(dmin, (g.minx + (float)(cx + R + 1) * g.h) - qx); whole = false; }
+            if (cy - R > 0) { dmin = fminf(dmin, qy - (g.miny + (float)(cy - R) * g.h)); whole = false; }
+            if (cy + R + 1 < g.ny) { dmin = fminf(dmin, (g.miny + (float)(cy + R + 1) * g.h) - qy); whole = false; }
+            if (cz - R > 0) { dmin = fminf(dmin, qz - (g.minz + (float)(cz - R) * g.h)); whole = false; }
+            if (cz + R + 1 < g.nz) { dmin = fminf(dmin, (g.minz + (float)(cz + R + 1) * g.h) - qz); whole = false; }
+            if (whole) break;
+            dmin -= g.margin;
+            if (dmin > 0.f && l.tau < dmin * dmin * 0.99999f) break;
+        }
+
+        // ties among the k+1 smallest distances -> the reference's order depends on its heap history
+        for (int s = 32; s >= 1; s >>= 1) rl = fminf(rl, __shfl_xor(rl, s, 64));
+        const float rej = fminf(rl, ru);
+        const float nextv = __shfl_down(l.v, 1, 64);
+        const bool tie_in = lane < k - 1 && l.v == nextv && l.v < 1e10f;
+        const bool tie_edge = lane == k - 1 && l.v < 1e10f && rej == l.v;
+        if (__ballot(tie_in || tie_edge)) {
+            if (lane == 0) fb_list[atomicAdd(fb_count, 1)] = q;
+        } else if (lane < k) {
+            idx[(size_t)q * k + lane] = l.id;
+            dist2[(size_t)q * k + lane] = l.v;
+        }
+    }
+}
+
 }  // namespace amc
 
 using namespace amc;
 
 AMC_API size_t amc3d_knnquery_workspace_bytes(int n, int m, int nsample, int nbatch)
 {
-    (void)n; (void)m; (void)nsample; (void)nbatch;
-    return 256;
+    (void)nsample; (void)nbatch;
+    return knn_layout(n > 0 ? n : 1, m > 0 ? m : 1).total;
 }
 
 AMC_API int amc3d_knnquery(int m, int nsample, int n, int nbatch, const float *xyz, const float *new_xyz,
                            const int *offset, const int *new_offset, int *idx, float *dist2, void *workspace,
-                           size_t workspace_bytes, void *stream)
+                           size_t workspace_bytes, void *stream_)
 {
-    (void)workspace; (void)workspace_bytes; (void)n;
     if (m <= 0) return 0;
     if (nsample <= 0 || nsample > KNN_MAXK) return bad_arg("amc3d_knnquery: nsample must be in 1..100");
-    if (nbatch <= 0 || !xyz || !new_xyz || !offset || !new_offset || !idx || !dist2)
+    if (nbatch <= 0 || n < 0 || !xyz || !new_xyz || !offset || !new_offset || !idx || !dist2)
         return bad_arg("amc3d_knnquery: bad argument");
-    const int blocks = min(div_up(m, KNN_WAVES), 256 * 64);
-    hipLaunchKernelGGL(knn_exact_kernel, dim3(blocks), dim3(KNN_WAVES * 64), 0, (hipStream_t)stream, m, nsample,
-                       nbatch, xyz, new_xyz, offset, new_offset, idx, dist2, (const int *)nullptr,
-                       (const int *)nullptr);
+    hipStream_t stream = (hipStream_t)stream_;
+    const int exact_blocks = min(div_up(m, KNN_WAVES), 256 * 8);
+    // small problems and k > 64: the heap replay alone (it is exact for every input)
+    const bool grid = nsample <= KG_MAXK && (long)n * m >= (1L << 22) && n >= 4 * KG_SAMPLES && nbatch <= 64;
+    if (!grid) {
+        hipLaunchKernelGGL(knn_exact_kernel, dim3(exact_blocks), dim3(KNN_WAVES * 64), 0, stream, m, nsample, nbatch,
+                           xyz, new_xyz, offset, new_offset, idx, dist2, (const int *)nullptr, (const int *)nullptr);
+        return launch_status("amc3d_knnquery");
+    }
+    const KnnWorkspace w = knn_layout(n, m);
+    if (!workspace || workspace_bytes < w.total) return bad_arg("amc3d_knnquery: workspace too small");
+    char *base = (char *)workspace;
+    GridParams *gp = (GridParams *)(base + w.params);
+    int *bbox = (int *)(base + w.bbox);
+    float *samples = (float *)(base + w.samples);
+    int *fb_count = (int *)(base + w.fb_count);
+    int *cell_start = (int *)(base + w.cell_start);
+    int *cursor = (int *)(base + w.cursor);
+    float4 *sorted = (float4 *)(base + w.sorted);
+    int *fb_list = (int *)(base + w.fb_list);
+    const size_t cells = (size_t)knn_cell_cap(n) + 1;
+
+    hipError_t e = hipMemsetAsync(cell_start, 0, cells * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(cursor, 0, cells * 4, stream);
+    if (e != hipSuccess) { set_error("amc3d_knnquery: memset: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(kg_init_kernel, dim3(1), dim3(64), 0, stream, bbox, fb_count);
+    hipLaunchKernelGGL(kg_bbox_kernel, dim3(min(div_up(n, 256), 1024)), dim3(256), 0, stream, n, xyz, bbox);
+    hipLaunchKernelGGL(kg_sample_kernel, dim3(KG_SAMPLES), dim3(1024), 0, stream, m, nsample, nbatch, xyz, new_xyz,
+                       offset, new_offset, samples);
+    hipLaunchKernelGGL(kg_params_kernel, dim3(1), dim3(64), 0, stream, n, nbatch, bbox, samples, gp);
+    hipLaunchKernelGGL(kg_count_kernel, dim3(div_up(n, 256)), dim3(256), 0, stream, n, nbatch, xyz, offset, gp,
+                       cell_start);
+    hipLaunchKernelGGL(kg_scan_kernel, dim3(1), dim3(1024), 0, stream, nbatch, gp, cell_start);
+    hipLaunchKernelGGL(kg_scatter_kernel, dim3(div_up(n, 256)), dim3(256), 0, stream, n, nbatch, xyz, offset, gp,
+                       cell_start, cursor, sorted);
+    hipLaunchKernelGGL(kg_query_kernel, dim3(min(div_up(m, 4), 256 * 32)), dim3(256), 0, stream, m, nsample, nbatch,
+                       new_xyz, offset, new_offset, gp, cell_start, sorted, idx, dist2, fb_list, fb_count);
+    // queries with equal distances among their k+1 nearest: replay the reference's heap
+    hipLaunchKernelGGL(knn_exact_kernel, dim3(min(exact_blocks, 512)), dim3(KNN_WAVES * 64), 0, stream, m, nsample,
+                       nbatch, xyz, new_xyz, offset, new_offset, idx, dist2, (const int *)fb_list,
+                       (const int *)fb_count);
     return launch_status("amc3d_knnquery");
 }

@@ -240,7 +240,11 @@ def test_knn_golden(dev, ops_fix, tag):
 @pytest.mark.parametrize("n,m,k,segs,kind", [
     (2000, 2000, 24, 1, "room"), (3000, 700, 16, 3, "uniform"), (1500, 1500, 24, 2, "lattice"),
     (900, 900, 24, 1, "dup"), (10, 10, 24, 1, "uniform"), (5000, 300, 64, 1, "room"), (4000, 100, 100, 2, "uniform"),
-    (257, 1029, 4, 1, "uniform"), (1, 3, 1, 1, "uniform")])
+    (257, 1029, 4, 1, "uniform"), (1, 3, 1, 1, "uniform"),
+    # above the brute-force threshold (n*m >= 2^22): the grid path, incl. its tie fallback
+    (6000, 6000, 24, 1, "lattice"), (6000, 6000, 24, 2, "dup"), (20000, 3000, 64, 1, "room"),
+    (8000, 8000, 16, 3, "uniform"), (30000, 5000, 4, 1, "room"), (12000, 12000, 24, 1, "room"),
+    (5000, 5000, 1, 1, "uniform"), (70000, 64, 24, 1, "uniform")])
 def test_knn_vs_oracle(dev, n, m, k, segs, kind):
     """including ragged segments, fewer points than k (placeholders), k = 100 (the reference's cap)
     and tie-heavy clouds: indices bit-exact, i.e. the heap's tie order is reproduced"""
