@@ -41,6 +41,12 @@ __device__ __forceinline__ float dist2_ref(float qx, float qy, float qz, float x
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
+// Zero-fill as an ordinary kernel.  The library never uses hipMemsetAsync: under hipGraph replay a
+// memset node was observed to race with the kernels captured after it on ROCm 7.2 (stale counters ->
+// out-of-range scatter), whereas kernel nodes of one captured stream always run in order.
+__global__ void fill_i32_kernel(int *__restrict__ p, int value, size_t count);
+int fill_i32(int *p, int value, size_t count, hipStream_t stream);
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // number of set bits of `mask` below this lane

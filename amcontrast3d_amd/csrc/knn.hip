@@ -153,7 +153,7 @@ struct GridParams {
 };
 
 struct KnnWorkspace {           // byte offsets into the caller's workspace
-    size_t params, bbox, samples, fb_count, cell_start, cursor, sorted, fb_list, total;
+    size_t params, bbox, samples, fb_count, tile_sums, cell_start, cursor, sorted, fb_list, total;
 };
 
 __host__ __device__ inline int knn_cell_cap(int n)
@@ -173,7 +173,8 @@ static KnnWorkspace knn_layout(int n, int m)
     w.bbox = 256;
     w.samples = 512;
     w.fb_count = 1024;
-    w.cell_start = 2048;
+    w.tile_sums = 2048;  // 1025 ints
+    w.cell_start = 8192;
     w.cursor = up(w.cell_start + (cap + 1) * 4);
     w.sorted = up(w.cursor + (cap + 1) * 4);
     w.fb_list = up(w.sorted + (size_t)n * 16);
@@ -198,6 +199,7 @@ __global__ void kg_init_kernel(int *bbox, int *fb_count)
 
 __global__ __launch_bounds__(256) void kg_bbox_kernel(int n, const float *__restrict__ xyz, int *__restrict__ bbox)
 {
+    __shared__ float s_lo[4][3], s_hi[4][3];
     float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 #pragma unroll
@@ -216,10 +218,15 @@ __global__ __launch_bounds__(256) void kg_bbox_kernel(int n, const float *__rest
     }
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            atomicMin(bbox + c, f2ord(lo[c]));
-            atomicMax(bbox + 3 + c, f2ord(hi[c]));
-        }
+        for (int c = 0; c < 3; ++c) { s_lo[threadIdx.x >> 6][c] = lo[c]; s_hi[threadIdx.x >> 6][c] = hi[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {  // one atomic pair per workgroup and axis
+        const int c = threadIdx.x;
+        const float l = fminf(fminf(s_lo[0][c], s_lo[1][c]), fminf(s_lo[2][c], s_lo[3][c]));
+        const float h = fmaxf(fmaxf(s_hi[0][c], s_hi[1][c]), fmaxf(s_hi[2][c], s_hi[3][c]));
+        atomicMin(bbox + c, f2ord(l));
+        atomicMax(bbox + 3 + c, f2ord(h));
     }
 }
 
@@ -365,30 +372,78 @@ __global__ void kg_count_kernel(int n, int nb, const float *__restrict__ xyz, co
     atomicAdd(cell_count + (size_t)seg * g.ncell + ((size_t)cz * g.ny + cy) * g.nx + cx, 1);
 }
 
-// in-place exclusive scan of cell_count[0 .. nb*ncell] (one workgroup; the grid is at most 4M cells)
-__global__ __launch_bounds__(1024) void kg_scan_kernel(int nb, const GridParams *__restrict__ gp, int *__restrict__ cells)
+// In-place exclusive scan of cell_count[0 .. nb*ncell] in three coalesced phases over tiles of
+// KG_SCAN_TILE cells: per-tile sums, scan of the (<= 1024) tile sums, per-tile scan + offset.
+// The cell count is only known on the device, so the grid is sized for the cell budget and
+// surplus workgroups return.
+constexpr int KG_SCAN_TILE = 4096;  // cells per workgroup (256 threads x 16)
+
+__device__ __forceinline__ int block_excl_scan_256(int v, int *s_part, int &block_total)
+{
+    // exclusive scan of one int per thread across a 256-thread workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+    for (int s = 1; s < 64; s <<= 1) {
+        const int o = __shfl_up(inc, s, 64);
+        if (lane >= s) inc += o;
+    }
+    if (lane == 63) s_part[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += s_part[w];
+    block_total = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void kg_scan_sums_kernel(int nb, const GridParams *__restrict__ gp,
+                                                           const int *__restrict__ cells, int *__restrict__ tile_sums)
+{
+    __shared__ int s_part[4];
+    const int total = nb * gp->ncell;
+    const int t0 = blockIdx.x * KG_SCAN_TILE;
+    if (t0 >= total) { if (threadIdx.x == 0) tile_sums[blockIdx.x] = 0; return; }
+    int sum = 0;
+    for (int i = t0 + threadIdx.x; i < min(t0 + KG_SCAN_TILE, total); i += 256) sum += cells[i];
+    int tot;
+    block_excl_scan_256(sum, s_part, tot);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(1024) void kg_scan_tiles_kernel(int ntiles, int *__restrict__ tile_sums)
 {
     __shared__ int part[1024];
-    const int total = nb * gp->ncell;
-    const int per = (total + 1023) / 1024;
-    const int lo = min(threadIdx.x * per, total), hi = min(lo + per, total);
-    int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += cells[i];
-    part[threadIdx.x] = sum;
+    const int v = (int)threadIdx.x < ntiles ? tile_sums[threadIdx.x] : 0;
+    part[threadIdx.x] = v;
     __syncthreads();
-    for (int s = 1; s < 1024; s <<= 1) {  // Hillis-Steele inclusive scan
-        const int v = threadIdx.x >= s ? part[threadIdx.x - s] : 0;
+    for (int s = 1; s < 1024; s <<= 1) {
+        const int o = threadIdx.x >= s ? part[threadIdx.x - s] : 0;
         __syncthreads();
-        part[threadIdx.x] += v;
+        part[threadIdx.x] += o;
         __syncthreads();
     }
-    int run = part[threadIdx.x] - sum;
-    for (int i = lo; i < hi; ++i) {
-        const int c = cells[i];
-        cells[i] = run;
-        run += c;
+    if ((int)threadIdx.x < ntiles) tile_sums[threadIdx.x] = part[threadIdx.x] - v;  // exclusive
+    if (threadIdx.x == 1023) tile_sums[ntiles] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void kg_scan_apply_kernel(int nb, const GridParams *__restrict__ gp,
+                                                            int *__restrict__ cells, const int *__restrict__ tile_sums,
+                                                            int ntiles)
+{
+    __shared__ int s_part[4];
+    const int total = nb * gp->ncell;
+    const int t0 = blockIdx.x * KG_SCAN_TILE;
+    if (t0 >= total) return;
+    int run = tile_sums[blockIdx.x];
+    for (int c0 = t0; c0 < min(t0 + KG_SCAN_TILE, total); c0 += 256) {
+        const int i = c0 + threadIdx.x;
+        const int v = i < total ? cells[i] : 0;
+        int tot;
+        const int ex = block_excl_scan_256(v, s_part, tot);
+        if (i < total) cells[i] = run + ex;
+        run += tot;
     }
-    if (threadIdx.x == 1023) cells[total] = part[1023];
+    if (t0 + KG_SCAN_TILE >= total && threadIdx.x == 0) cells[total] = tile_sums[ntiles];
 }
 
 __global__ void kg_scatter_kernel(int n, int nb, const float *__restrict__ xyz, const int *__restrict__ offset,
@@ -404,7 +459,7 @@ __global__ void kg_scatter_kernel(int n, int nb, const float *__restrict__ xyz, 
     const int seg = nb > 1 ? seg_of(i, offset, nb) : 0;
     const size_t cell = (size_t)seg * g.ncell + ((size_t)cz * g.ny + cy) * g.nx + cx;
     const int pos = cell_start[cell] + atomicAdd(cursor + cell, 1);
-    sorted[pos] = make_float4(x, y, z, __int_as_float(i));
+    if (pos >= 0 && pos < n) sorted[pos] = make_float4(x, y, z, __int_as_float(i));  // guard: never write outside
 }
 
 // ---- queries --------------------------------------------------------------------------------------
@@ -549,17 +604,21 @@ AMC_API int amc3d_knnquery(int m, int nsample, int n, int nbatch, const float *x
     int *fb_list = (int *)(base + w.fb_list);
     const size_t cells = (size_t)knn_cell_cap(n) + 1;
 
-    hipError_t e = hipMemsetAsync(cell_start, 0, cells * 4, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(cursor, 0, cells * 4, stream);
-    if (e != hipSuccess) { set_error("amc3d_knnquery: memset: %s", hipGetErrorString(e)); return (int)e; }
+    if (int st = fill_i32(cell_start, 0, cells, stream)) return st;
+    if (int st = fill_i32(cursor, 0, cells, stream)) return st;
     hipLaunchKernelGGL(kg_init_kernel, dim3(1), dim3(64), 0, stream, bbox, fb_count);
-    hipLaunchKernelGGL(kg_bbox_kernel, dim3(min(div_up(n, 256), 1024)), dim3(256), 0, stream, n, xyz, bbox);
+    hipLaunchKernelGGL(kg_bbox_kernel, dim3(min(div_up(n, 256), 64)), dim3(256), 0, stream, n, xyz, bbox);
     hipLaunchKernelGGL(kg_sample_kernel, dim3(KG_SAMPLES), dim3(1024), 0, stream, m, nsample, nbatch, xyz, new_xyz,
                        offset, new_offset, samples);
     hipLaunchKernelGGL(kg_params_kernel, dim3(1), dim3(64), 0, stream, n, nbatch, bbox, samples, gp);
     hipLaunchKernelGGL(kg_count_kernel, dim3(div_up(n, 256)), dim3(256), 0, stream, n, nbatch, xyz, offset, gp,
                        cell_start);
-    hipLaunchKernelGGL(kg_scan_kernel, dim3(1), dim3(1024), 0, stream, nbatch, gp, cell_start);
+    int *tile_sums = (int *)(base + w.tile_sums);
+    const int ntiles = div_up(knn_cell_cap(n), KG_SCAN_TILE);  // <= 1024
+    hipLaunchKernelGGL(kg_scan_sums_kernel, dim3(ntiles), dim3(256), 0, stream, nbatch, gp, cell_start, tile_sums);
+    hipLaunchKernelGGL(kg_scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, ntiles, tile_sums);
+    hipLaunchKernelGGL(kg_scan_apply_kernel, dim3(ntiles), dim3(256), 0, stream, nbatch, gp, cell_start, tile_sums,
+                       ntiles);
     hipLaunchKernelGGL(kg_scatter_kernel, dim3(div_up(n, 256)), dim3(256), 0, stream, n, nbatch, xyz, offset, gp,
                        cell_start, cursor, sorted);
     hipLaunchKernelGGL(kg_query_kernel, dim3(min(div_up(m, 4), 256 * 32)), dim3(256), 0, stream, m, nsample, nbatch,

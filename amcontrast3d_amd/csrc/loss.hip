@@ -330,8 +330,7 @@ AMC_API int amc3d_ambiguity(int m, int k, int nbr_stride, int mode, float beta, 
     int *n_pos = (int *)((char *)workspace + 64);
     float *d_pos = (float *)(n_pos + m);
     float *d_neg = d_pos + m;
-    hipError_t e = hipMemsetAsync(max_npos, 0, sizeof(int), stream);
-    if (e != hipSuccess) { set_error("amc3d_ambiguity: memset: %s", hipGetErrorString(e)); return (int)e; }
+    if (int st = fill_i32(max_npos, 0, 1, stream)) return st;
     hipLaunchKernelGGL(ambiguity_stats_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, m, k, nbr_stride, mode, p,
                        posmask, nbr, n_pos, d_pos, d_neg, max_npos);
     hipLaunchKernelGGL(ambiguity_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, m, k, beta, n_pos, d_pos, d_neg,

@@ -213,6 +213,19 @@ class ResBlock(nn.Module):
 
 _BLOCKS = {'InvResMLP': InvResMLP, 'ResBlock': ResBlock}
 
+_OFFSETS = {}
+
+
+def _segment_offset(n, device):
+    """int32 [n] on `device` -- the single-segment offset of a flattened batch.  Cached per
+    (n, device): the reference builds it with IntTensor([n]).cuda() every stage and step
+    (pointnext_AA.py:461), a pageable host-to-device copy that also cannot be graph-captured."""
+    key = (int(n), str(device))
+    t = _OFFSETS.get(key)
+    if t is None:
+        t = _OFFSETS[key] = torch.tensor([int(n)], dtype=torch.int32, device=device)
+    return t
+
 
 @MODELS.register_module()
 class PointNextEncoder_AMContrast3D(nn.Module):
@@ -319,7 +332,7 @@ class PointNextEncoder_AMContrast3D(nn.Module):
                 flat_p = torch.flatten(_p, start_dim=0, end_dim=1)
                 flat_f = torch.flatten(_f.transpose(1, 2), start_dim=0, end_dim=1)
                 # the whole flattened batch is ONE segment: neighbours are searched across samples
-                offset = torch.tensor([flat_p.shape[0]], dtype=torch.int32, device=flat_p.device)
+                offset = _segment_offset(flat_p.shape[0], flat_p.device)
                 down.append({'p_out': flat_p, 'f_out': flat_f, 'offset': offset})
         stageACE_list['down'] = down
         stageACE_list['up'] = down  # decoder overwrites ['f_out'] in place

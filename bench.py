@@ -44,12 +44,16 @@ def parse():
     ap.add_argument("--points", type=int, default=24000)
     ap.add_argument("--variant", default="S")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="N > 1: the reference's SyncBatchNorm + DistributedDataParallel (eager) instead of "
+                         "graph-captured per-rank steps + bucketed RCCL gradient all-reduce")
     ap.add_argument("--cpu-baseline-batch", type=int, default=2,
                     help="clouds in the CPU sample (bounded: the full batch of 8 takes minutes on the host)")
     return ap.parse_args()
 
 
-def build(variant, dev, world):
+def build(variant, dev, world, ddp):
     import amcontrast3d_amd
     amcontrast3d_amd.activate()
     from amcontrast3d_amd import configs, dist as adist
@@ -60,7 +64,8 @@ def build(variant, dev, world):
     cfg = configs.model_cfg(variant, dropout=0.5)
     c = EasyConfig(); c.update(cfg)
     model = build_model_from_cfg(c).to(dev).train()
-    model = adist.wrap_data_parallel(model, dev, world)
+    if ddp:
+        model = adist.wrap_data_parallel(model, dev, world)
     cc = EasyConfig(); cc.update(configs.criterion_cfg())
     criterion = build_criterion_from_cfg(cc).to(dev)
     aargs = EasyConfig(); aargs.update(configs.ambiguity_args("s3dis"))
@@ -69,7 +74,7 @@ def build(variant, dev, world):
     for p in model.parameters():
         (no_decay if p.ndim <= 1 else decay).append(p)
     opt = torch.optim.AdamW([{"params": decay, "weight_decay": 1e-4}, {"params": no_decay, "weight_decay": 0.0}],
-                            lr=0.01)
+                            lr=0.01, capturable=True)
     return cfg, model, criterion, aargs, opt
 
 
@@ -106,38 +111,85 @@ def main():
     dev = torch.device("cuda", local)
     _lib.load()
 
-    cfg, model, criterion, aargs, opt = build(args.variant, dev, world)
+    use_ddp = world > 1 and args.sync_bn
+    use_graph = not args.no_graph and not use_ddp
+    cfg, model, criterion, aargs, opt = build(args.variant, dev, world, use_ddp)
     ids = adist.scene_ids(rank, world, args.batch)
     nb = synthetic.make_batch(args.batch, args.points, first_id=ids[0])
     data = {k: torch.from_numpy(v).to(dev) for k, v in nb.items()}
+    params = list(model.parameters())
     torch.cuda.synchronize()
+    out = {}
 
-    def step():
+    def fwd_bwd():
         logits, stage = model(data)
-        loss = criterion(logits, data["y"], stage, 13, None, aargs)
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 10, norm_type=2)
+        out["loss"] = criterion(logits, data["y"], stage, 13, None, aargs)
+        out["loss"].backward()
+
+    def update():
+        torch.nn.utils.clip_grad_norm_(params, 10, norm_type=2)
         opt.step()
+
+    def eager_step():
         opt.zero_grad(set_to_none=True)
-        return loss
+        fwd_bwd()
+        if world > 1 and not use_ddp:
+            adist.allreduce_gradients(params)
+        update()
+
+    step = eager_step
+    if use_graph:
+        # Whole-step hipGraph capture (PyTorch's whole-network recipe): warm up on a side stream,
+        # then capture forward + loss + backward as one graph and clip + AdamW as a second one; the
+        # only work between them is the RCCL gradient all-reduce (N > 1).  ~700 launches per step
+        # become two graph launches.
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        opt.zero_grad(set_to_none=True)
+        g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_fb):
+            fwd_bwd()
+        with torch.cuda.graph(g_up, pool=g_fb.pool()):
+            update()
+
+        def step():
+            g_fb.replay()
+            if world > 1:
+                adist.allreduce_gradients(params)
+            g_up.replay()
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     adist.barrier()
     torch.cuda.synchronize()
-    timing.enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        step()
     torch.cuda.synchronize()
     adist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dt = adist.max_over_ranks(dt, dev)
+    final_loss = float(out["loss"].detach())
+
+    # per-operator HIP-event timing: the same step, launched eagerly so each C-ABI launch can be
+    # bracketed by events on its stream (events cannot bracket nodes inside a graph replay)
+    ksteps = min(args.steps, 3)
+    timing.enable(True)
+    for _ in range(ksteps):
+        eager_step()
+    torch.cuda.synchronize()
     kernels = timing.collect()
     timing.enable(False)
-    dt = adist.max_over_ranks(dt, dev)
-    final_loss = float(loss)
+    for v in kernels.values():
+        v["total_ms"] *= args.steps / ksteps
+        v["launches"] *= args.steps / ksteps
 
     if rank == 0:
         points_per_step = args.batch * args.points
@@ -160,7 +212,8 @@ def main():
                                    f"voxelised (0.04 m) clouds, batch {args.batch}/GPU, fwd + CE/contrast loss + bwd + "
                                    f"clip + AdamW",
                        "global_batch": args.batch * world, "points": args.points,
-                       "parallelism": f"dp{world}" + ("+syncbn" if world > 1 else "")},
+                       "parallelism": f"dp{world}" + ("+syncbn+ddp" if use_ddp else ""),
+                       "launch": "hipGraph replay (fwd+loss+bwd | clip+AdamW)" if use_graph else "eager"},
             "loss": round(final_loss, 6),
             "roofline": roofline,
             "kernels": {k: {"ms_per_step": round(v["total_ms"] / args.steps, 4),
