@@ -45,7 +45,8 @@ def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
 
 
 def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
-    _call("amc3d_group_points_grad", grad_out, b, c, n, npoints, nsample, _p(grad_out), _p(idx), _p(grad_points))
+    _call("amc3d_group_points_grad", grad_out, b, c, n, npoints, nsample, _p(grad_out), _p(idx), _p(grad_points),
+          None, 0)
     return 1
 
 
@@ -73,7 +74,8 @@ def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
 
 
 def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
-    _call("amc3d_three_interpolate_grad", grad_out, b, c, n, m, _p(grad_out), _p(idx), _p(weight), _p(grad_points))
+    _call("amc3d_three_interpolate_grad", grad_out, b, c, n, m, _p(grad_out), _p(idx), _p(weight), _p(grad_points),
+          None, 0)
 
 
 def knnquery_cuda(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2):

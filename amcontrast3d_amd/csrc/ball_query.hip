@@ -159,12 +159,23 @@ AMC_API int amc3d_group_points(int b, int c, int n, int npoints, int nsample, co
     return launch_status("amc3d_group_points");
 }
 
+namespace amc {
+int scatter_add_pm(int fan, int b, int c, int n, long entries, const float *grad_out, const int *idx,
+                   const float *weight, float *grad_points, float *scratch, hipStream_t stream, const char *what);
+}
+
+AMC_API size_t amc3d_scatter_workspace_bytes(int b, int c, int n) { return (size_t)b * c * n * sizeof(float); }
+
 AMC_API int amc3d_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
-                                    const int *idx, float *grad_points, void *stream)
+                                    const int *idx, float *grad_points, void *workspace, size_t workspace_bytes,
+                                    void *stream)
 {
     const long ps = (long)npoints * nsample;
     if (b <= 0 || c <= 0 || ps <= 0) return 0;
     if (!grad_out || !idx || !grad_points) return bad_arg("amc3d_group_points_grad: null pointer");
+    if (workspace && workspace_bytes >= amc3d_scatter_workspace_bytes(b, c, n) && c >= 8)
+        return scatter_add_pm(1, b, c, n, ps, grad_out, idx, nullptr, grad_points, (float *)workspace,
+                              (hipStream_t)stream, "amc3d_group_points_grad");
     hipLaunchKernelGGL(group_points_grad_kernel, dim3(div_up(ps, 256), b), dim3(256), 0, (hipStream_t)stream, c,
                        n, (int)ps, grad_out, idx, grad_points);
     return launch_status("amc3d_group_points_grad");
@@ -180,5 +191,5 @@ AMC_API int amc3d_gather_points(int b, int c, int n, int npoints, const float *p
 AMC_API int amc3d_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out, const int *idx,
                                      float *grad_points, void *stream)
 {
-    return amc3d_group_points_grad(b, c, n, npoints, 1, grad_out, idx, grad_points, stream);
+    return amc3d_group_points_grad(b, c, n, npoints, 1, grad_out, idx, grad_points, nullptr, 0, stream);
 }

@@ -135,11 +135,20 @@ AMC_API int amc3d_three_interpolate(int b, int c, int m, int n, const float *poi
     return launch_status("amc3d_three_interpolate");
 }
 
+namespace amc {
+int scatter_add_pm(int fan, int b, int c, int n, long entries, const float *grad_out, const int *idx,
+                   const float *weight, float *grad_points, float *scratch, hipStream_t stream, const char *what);
+}
+
 AMC_API int amc3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
-                                         const float *weight, float *grad_points, void *stream)
+                                         const float *weight, float *grad_points, void *workspace,
+                                         size_t workspace_bytes, void *stream)
 {
     if (b <= 0 || c <= 0 || n <= 0) return 0;
     if (!grad_out || !idx || !weight || !grad_points) return bad_arg("amc3d_three_interpolate_grad: null pointer");
+    if (workspace && workspace_bytes >= (size_t)b * c * m * sizeof(float) && c >= 8)
+        return scatter_add_pm(3, b, c, m, n, grad_out, idx, weight, grad_points, (float *)workspace,
+                              (hipStream_t)stream, "amc3d_three_interpolate_grad");
     hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3(div_up(n, 256), b), dim3(256), 0, (hipStream_t)stream, c, n,
                        m, grad_out, idx, weight, grad_points);
     return launch_status("amc3d_three_interpolate_grad");

@@ -84,8 +84,10 @@ class GroupingOperation(Function):
         grad_features = torch.zeros(B, C, N, dtype=torch.float32, device=grad_out.device)
         grad_out_data = grad_out.detach().contiguous()
         with torch.cuda.device(grad_out.device), timing.span("group_points_grad", grad_out_data.numel() * 4 + idx.numel() * 4 + grad_features.numel() * 4):
+            work = torch.empty(B * C * N, dtype=torch.float32, device=grad_out.device)
             _lib.check(_lib.load().amc3d_group_points_grad(B, C, N, npoint, nsample, _ptr(grad_out_data), _ptr(idx),
-                                                           _ptr(grad_features), _stream(grad_out)), "group_points_grad")
+                                                           _ptr(grad_features), _ptr(work), work.numel() * 4,
+                                                           _stream(grad_out)), "group_points_grad")
         return grad_features, None
 
 
@@ -202,9 +204,11 @@ class ThreeInterpolate(Function):
         grad_features = torch.zeros(B, c, m, dtype=torch.float32, device=grad_out.device)
         grad_out_data = grad_out.detach().contiguous()
         with torch.cuda.device(grad_out.device), timing.span("three_interpolate_grad", grad_out_data.numel() * 4 + idx.numel() * 8 + grad_features.numel() * 4):
+            work = torch.empty(B * c * m, dtype=torch.float32, device=grad_out.device)
             _lib.check(_lib.load().amc3d_three_interpolate_grad(B, c, n, m, _ptr(grad_out_data), _ptr(idx),
-                                                                _ptr(weight), _ptr(grad_features),
-                                                                _stream(grad_out)), "three_interpolate_grad")
+                                                                _ptr(weight), _ptr(grad_features), _ptr(work),
+                                                                work.numel() * 4, _stream(grad_out)),
+                       "three_interpolate_grad")
         return grad_features, None, None
 
 

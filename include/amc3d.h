@@ -56,11 +56,18 @@ int amc3d_ball_query(int b, int n, int m, float radius, int nsample,
 int amc3d_group_points(int b, int c, int n, int npoints, int nsample,
                        const float *points, const int *idx, float *out, void *stream);
 
+/* bytes of the optional scratch of the two scatter-add gradients below (one (b,n,c) fp32 image) */
+size_t amc3d_scatter_workspace_bytes(int b, int c, int n);
+
 /* replaces group_points_grad_wrapper_fast (group_points_gpu.cu:14-50):
  * grad_points (b,c,n) += scatter(grad_out (b,c,npoints,nsample)); the caller
- * zero-initialises grad_points (group.py:111). */
+ * zero-initialises grad_points (group.py:111).  With a workspace of
+ * amc3d_scatter_workspace_bytes(b,c,n) the adds go through a point-major image (full-rate atomic
+ * shape) and are transposed back; workspace = NULL selects the reference's direct per-element
+ * atomics. */
 int amc3d_group_points_grad(int b, int c, int n, int npoints, int nsample,
-                            const float *grad_out, const int *idx, float *grad_points, void *stream);
+                            const float *grad_out, const int *idx, float *grad_points,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* replaces gather_points_wrapper_fast / gather_points_grad_wrapper_fast
  * (sampling_gpu.cu:15-90): points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */
@@ -90,9 +97,11 @@ int amc3d_three_interpolate(int b, int c, int m, int n, const float *points,
                             const int *idx, const float *weight, float *out, void *stream);
 
 /* replaces three_interpolate_grad_wrapper_fast (interpolate_gpu.cu:127-169):
- * grad_points (b,c,m) += ...; caller zero-initialises (upsampling.py:82). */
+ * grad_points (b,c,m) += ...; caller zero-initialises (upsampling.py:82).
+ * Optional workspace: amc3d_scatter_workspace_bytes(b,c,m), as above. */
 int amc3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
-                                 const int *idx, const float *weight, float *grad_points, void *stream);
+                                 const int *idx, const float *weight, float *grad_points,
+                                 void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- pointops surface --------------------------------------------------------- */
 
