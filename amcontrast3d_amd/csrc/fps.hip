@@ -1,39 +1,400 @@
 // Furthest point sampling for gfx950.
 //
-// Reference: pointnet2_batch/src/sampling_gpu.cu:100-216 (+ __update :93-98,
-// block size cuda_utils.h:10-14).  One workgroup per cloud, idxs[0] = 0, then
-// m-1 dependent iterations: update every point's running minimum distance to
-// the selected set, take the arg-max.
+// Reference: pointnet2_batch/src/sampling_gpu.cu:100-216 (+ __update :93-98, block size
+// cuda_utils.h:10-14).  One workgroup per cloud, idxs[0] = 0, then m-1 DEPENDENT iterations: update
+// every point's running minimum distance to the selected set, take the arg-max.  The reference
+// re-reads xyz and the running minima from global memory each iteration and reduces through a
+// 10-level __syncthreads tree; at 24000 -> 6000 points that is 6000 x (24000-point sweep + tree).
 //
-// The reference keeps the running minimum in global memory and re-reads xyz from
-// global every iteration.  Here the workgroup has exactly the reference's block
-// size RB = opt_n_threads(n) and thread t owns the same points k = t + RB*j,
-// but x/y/z/min-dist of its points live in VGPRs for the whole kernel
-// (PPT = ceil(n/RB) of each), so an iteration touches no memory except the
-// broadcast of the winner.  The arg-max is a DPP/bpermute wave reduction plus a
-// <=16-entry LDS step instead of a 10-level __syncthreads tree.
+// This kernel keeps the whole cloud (x, y, z, running minimum: <= 48 points per thread of a 512-thread
+// workgroup, i.e. up to 192 of the 256 VGPRs a wave may hold at 2 waves per SIMD) in registers and
+// shortens both halves of the iteration:
 //
-// Tie rule (bit-exact with the reference): inside a thread the first strict
-// maximum in ascending j wins (same scan order); across threads the reference's
-// tree `dists_i[t] = v2 > v1 ? i2 : i1` over strides RB/2 ... 1 keeps, among
-// equal values, the thread whose bit-reversed id (log2 RB bits) is smallest.
-// The reduction here orders candidates by (value desc, bitrev(tid) asc).
+//  * Sweep -- exact pruning.  The workgroup first sorts its cloud by the Morton index of a 16^3 grid
+//    (LDS counting sort) and deals consecutive runs of 64*GS points ("groups") round-robin to its
+//    waves.  Every group carries a bounding sphere (c, r) and M = max running minimum inside it.  A
+//    new sample q cannot lower any running minimum of the group when |c-q| - r >= sqrt(M), so the
+//    group is skipped and its cached per-lane maximum stays valid.  Late in the sampling only the few
+//    groups around q are swept (measured on S3DIS-shaped clouds: ~18 % of the groups per iteration).
+//    Skipping never changes a value, so the result is the brute-force result.
+//  * Arg-max -- DPP wave reduction, one LDS record per wave that already carries the wave winner's
+//    coordinates (read from the owner lane's VGPRs under a wave-uniform switch), ONE barrier, a
+//    16-lane reduction; no dependent global load and no second barrier on the critical path.
+//
+// Ties.  The reference resolves equal maxima by its thread layout: thread t scans k = t, t+RB, ...
+// keeping the first strict maximum, and the tree `dists_i[t] = v2 > v1 ? i2 : i1` keeps the lower
+// slot, i.e. among equal values the point with the smallest key (bitrev(k mod RB), k div RB) wins,
+// RB = opt_n_threads(n).  The sorted layout here has nothing to do with k, so whenever the maximum is
+// attained by more than one point (detected per lane, per wave and per workgroup) the iteration takes
+// a slow path that evaluates exactly that key order over all tied points.
 #include "common.h"
 
 namespace amc {
 
+// ---- DPP helpers ------------------------------------------------------------------------------
+// v = max(v, v[permuted lane]) as ONE v_max_f32_dpp.  hipcc (ROCm 7.2) lowers
+// fmaxf(v, __builtin_amdgcn_update_dpp(v)) to mov + v_mov_b32_dpp + canonicalising max + max + s_nop
+// (5 issue slots); the reductions below sit on the per-iteration critical path of the sampler, so they
+// are written as asm.  The s_nop covers the VALU-write -> DPP-read hazard hipcc does not pad inside asm.
+#define AMC_DPP_MAX(v, CTRL) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " CTRL : "+v"(v))
+
+// max over the 16 lanes of each row, result in every lane of the row
+__device__ __forceinline__ float row_max_f32(float v)
+{
+    AMC_DPP_MAX(v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    AMC_DPP_MAX(v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    AMC_DPP_MAX(v, "row_half_mirror row_mask:0xf bank_mask:0xf");
+    AMC_DPP_MAX(v, "row_mirror row_mask:0xf bank_mask:0xf");
+    return v;
+}
+
+// max over the wavefront, returned wave-uniform
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+    v = row_max_f32(v);
+    AMC_DPP_MAX(v, "row_bcast:15 row_mask:0xa bank_mask:0xf");  // rows 1,3 <- lane 15 of rows 0,2
+    AMC_DPP_MAX(v, "row_bcast:31 row_mask:0xc bank_mask:0xf");  // rows 2,3 <- lane 31
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would make
+// every iteration wait (~1 us) for the acknowledgement of the global store of the previous pick.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+
+__device__ __forceinline__ float readlane_f32(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__device__ __forceinline__ float uniform_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+// the reference's tie order: smaller key wins among equal running minima
+__device__ __forceinline__ unsigned fps_key(int k, int log2rb)
+{
+    const unsigned tid = (unsigned)k & ((1u << log2rb) - 1u);
+    const unsigned rev = log2rb ? (__brev(tid) >> (32 - log2rb)) : 0u;
+    return (rev << 20) | ((unsigned)k >> log2rb);  // k div RB < 2^20 for any n the register path takes
+}
+__device__ __forceinline__ int fps_unkey(unsigned key, int log2rb)
+{
+    const unsigned rev = key >> 20, pass = key & 0xfffffu;
+    const unsigned tid = log2rb ? (__brev(rev) >> (32 - log2rb)) : 0u;
+    return (int)((pass << log2rb) | tid);
+}
+
+__device__ __forceinline__ unsigned morton3_4bit(unsigned x, unsigned y, unsigned z)
+{
+    auto spread = [](unsigned v) { return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6); };
+    return spread(x) | (spread(y) << 1) | (spread(z) << 2);
+}
+
+struct FpsRecord {  // one per wave and iteration parity, 32 bytes
+    float v;        // wave maximum
+    int amb;        // maximum attained by more than one point of the wave
+    int spos;       // sorted position of the wave winner
+    int pad;
+    float x, y, z, pad2;
+};
+
+template <int PPT, int NG>
+__global__ __launch_bounds__(512) void fps_kernel(int n, int m, int log2rb, const float *__restrict__ dataset,
+                                                   float *__restrict__ temp, int *__restrict__ idxs,
+                                                   int *__restrict__ perm_ws)
+{
+    constexpr int GS = PPT / NG;  // slots per group
+    static_assert(GS * NG == PPT, "PPT must be a multiple of NG");
+    __shared__ int s_cells[4096];
+    __shared__ float s_red[16][6];
+    __shared__ int s_wsum[16];
+    __shared__ FpsRecord s_rec[2][16];
+    __shared__ unsigned s_key[2][16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const float *pts = dataset + (size_t)blockIdx.x * n * 3;
+    int *perm = perm_ws + (size_t)blockIdx.x * n;
+    int *out = idxs + (size_t)blockIdx.x * m;
+
+    // ================= prologue 1: Morton-cell counting sort of the cloud (perm[sorted] = k) =========
+    {
+        float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+        for (int k = tid; k < n; k += nthreads) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = pts[(size_t)k * 3 + c];
+                lo[c] = fminf(lo[c], v);
+                hi[c] = fmaxf(hi[c], v);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = -wave_max_f32(-lo[c]);
+            hi[c] = wave_max_f32(hi[c]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { s_red[wave][c] = lo[c]; s_red[wave][3 + c] = hi[c]; }
+        }
+        for (int i = tid; i < 4096; i += nthreads) s_cells[i] = 0;
+        __syncthreads();
+        float mn[3], sc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float l = s_red[0][c], h = s_red[0][3 + c];
+            for (int w = 1; w < nwaves; ++w) { l = fminf(l, s_red[w][c]); h = fmaxf(h, s_red[w][3 + c]); }
+            mn[c] = l;
+            sc[c] = h > l ? 16.f / (h - l) : 0.f;
+        }
+        auto cell_of = [&](int k) {
+            unsigned cc[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int v = (int)((pts[(size_t)k * 3 + c] - mn[c]) * sc[c]);
+                cc[c] = (unsigned)min(max(v, 0), 15);
+            }
+            return (int)morton3_4bit(cc[0], cc[1], cc[2]);
+        };
+        for (int k = tid; k < n; k += nthreads) atomicAdd(&s_cells[cell_of(k)], 1);
+        __syncthreads();
+        // exclusive scan of the 4096 counters: each thread owns a contiguous chunk
+        const int per = 4096 / nthreads;  // nthreads in {64,...,1024} divides 4096
+        int sum = 0;
+        for (int i = 0; i < per; ++i) sum += s_cells[tid * per + i];
+        int inc = sum;
+        for (int s = 1; s < 64; s <<= 1) {
+            const int o = __shfl_up(inc, s, 64);
+            if (lane >= s) inc += o;
+        }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wave; ++w) base += s_wsum[w];
+        int run = base + inc - sum;
+        for (int i = 0; i < per; ++i) {
+            const int c = s_cells[tid * per + i];
+            s_cells[tid * per + i] = run;
+            run += c;
+        }
+        __syncthreads();
+        for (int k = tid; k < n; k += nthreads) perm[atomicAdd(&s_cells[cell_of(k)], 1)] = k;
+        __syncthreads();  // perm (global, written by this workgroup) is visible to it from here on
+    }
+
+    // ================= prologue 2: load the cloud in sorted order, group spheres ====================
+    // group G = g * nwaves + wave holds sorted positions [G*GS*64, (G+1)*GS*64): neighbouring groups
+    // (which tend to be swept in the same iteration) sit in different waves / SIMDs
+    auto spos_of = [&](int j, int l) { return (((j / GS) * nwaves + wave) * GS + (j % GS)) * 64 + l; };
+    float px[PPT], py[PPT], pz[PPT], pt[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int s = spos_of(j, lane);
+        const bool ok = s < n;
+        const int k = ok ? perm[s] : 0;
+        px[j] = ok ? pts[(size_t)k * 3 + 0] : 0.f;
+        py[j] = ok ? pts[(size_t)k * 3 + 1] : 0.f;
+        pz[j] = ok ? pts[(size_t)k * 3 + 2] : 0.f;
+        // running minimum: the caller's fill value (1e10, subsample.py:95); -2 marks an empty slot
+        pt[j] = ok ? (temp ? temp[(size_t)blockIdx.x * n + k] : 1e10f) : -2.f;
+    }
+    // group g's sphere and skip threshold live in lane g (one distance test serves all groups)
+    float pcx = 0.f, pcy = 0.f, pcz = 0.f, prad = 0.f, pthr = -1.f;
+    float gb[NG];                                          // per lane: best running minimum in the group
+    int gsl[NG];                                           // per lane: its slot
+    unsigned tiebits = 0;                                  // per lane: group maximum attained twice
+    auto thr_of = [](float rad, float mx) {
+        if (mx < 0.f) return -1.f;  // empty group: always skipped
+        const float t = rad + __builtin_amdgcn_sqrtf(mx) * 1.00001f;  // v_sqrt_f32 (1 ulp): the margin covers it
+        return t * t * 1.00001f;
+    };
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        float sx = 0.f, sy = 0.f, sz = 0.f, cnt = 0.f, mx = -2.f;
+#pragma unroll
+        for (int jj = 0; jj < GS; ++jj) {
+            const int j = g * GS + jj;
+            const bool ok = pt[j] > -1.f;
+            sx += ok ? px[j] : 0.f; sy += ok ? py[j] : 0.f; sz += ok ? pz[j] : 0.f;
+            cnt += ok ? 1.f : 0.f;
+            mx = fmaxf(mx, pt[j]);
+        }
+        cnt = wave_sum_f32(cnt);
+        const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+        const float cx = uniform_f32(wave_sum_f32(sx) * inv), cy = uniform_f32(wave_sum_f32(sy) * inv),
+                    cz = uniform_f32(wave_sum_f32(sz) * inv);
+        float r2 = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < GS; ++jj) {
+            const int j = g * GS + jj;
+            const float d = dist2_ref(px[j], py[j], pz[j], cx, cy, cz);
+            r2 = fmaxf(r2, pt[j] > -1.f ? d : 0.f);
+        }
+        const float rad = sqrtf(wave_max_f32(r2)) * 1.00001f + 1e-30f;
+        const float thr = thr_of(rad, wave_max_f32(mx));
+        if (lane == g) { pcx = cx; pcy = cy; pcz = cz; prad = rad; pthr = thr; }
+        gb[g] = -1.f;
+        gsl[g] = g * GS;
+    }
+
+    float x1 = pts[0], y1 = pts[1], z1 = pts[2];  // old = 0
+    if (tid == 0) out[0] = 0;
+
+    for (int it = 1; it < m; ++it) {
+        const int buf = it & 1;
+        // ---- 1. sweep the groups the new sample can affect --------------------------------------
+        const float d2c = dist2_ref(pcx, pcy, pcz, x1, y1, z1);
+        const unsigned sweep = (unsigned)__ballot(lane < NG && !(d2c > pthr));
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if ((sweep >> g) & 1u) {  // wave-uniform: group g is not provably untouched
+                float b = -1.f;
+                int sl = g * GS;
+                bool tie = false;
+#pragma unroll
+                for (int jj = 0; jj < GS; ++jj) {
+                    const int j = g * GS + jj;
+                    const float d = dist2_ref(px[j], py[j], pz[j], x1, y1, z1);
+                    const float dm = fminf(d, pt[j]);
+                    pt[j] = dm;
+                    const bool gtm = dm > b, eqm = dm == b;
+                    tie = gtm ? false : (tie || eqm);
+                    sl = gtm ? j : sl;
+                    b = fmaxf(b, dm);
+                    if (GS >= 4) __builtin_amdgcn_sched_barrier(0);  // keep register pressure flat
+                }
+                gb[g] = b;
+                gsl[g] = sl;
+                tiebits = tie ? (tiebits | (1u << g)) : (tiebits & ~(1u << g));
+                const float nthr = thr_of(prad, wave_max_f32(b));  // evaluated in every lane, kept by lane g
+                pthr = lane == g ? nthr : pthr;
+            }
+        }
+        // ---- 2. lane maximum over its groups ---------------------------------------------------------
+        float best = gb[0];
+        int slot = gsl[0];
+        bool ltie = (tiebits & 1u) != 0;
+#pragma unroll
+        for (int g = 1; g < NG; ++g) {
+            const bool gtm = gb[g] > best, eqm = gb[g] == best;
+            ltie = gtm ? ((tiebits >> g) & 1u) != 0 : (ltie || eqm);
+            slot = gtm ? gsl[g] : slot;
+            best = fmaxf(best, gb[g]);
+        }
+        // ---- 3. wave arg-max; the winner lane's coordinates come straight from its VGPRs ---------
+        const float vw = wave_max_f32(best);
+        const unsigned long long cand = __ballot(best == vw);
+        const bool amb_w = __popcll(cand) != 1 || __ballot(best == vw && ltie) != 0;
+        const int wl = (int)__builtin_ctzll(cand);
+        const int jstar = __builtin_amdgcn_readlane(slot, wl);
+        float wx = 0.f, wy = 0.f, wz = 0.f;
+        switch (jstar) {
+#define AMC_FPS_CASE(J)                                                                                        \
+    case J:                                                                                                    \
+        if (J < PPT) {                                                                                         \
+            wx = readlane_f32(px[J < PPT ? J : 0], wl);                                                        \
+            wy = readlane_f32(py[J < PPT ? J : 0], wl);                                                        \
+            wz = readlane_f32(pz[J < PPT ? J : 0], wl);                                                        \
+        }                                                                                                      \
+        break;
+            AMC_FPS_CASE(0) AMC_FPS_CASE(1) AMC_FPS_CASE(2) AMC_FPS_CASE(3) AMC_FPS_CASE(4) AMC_FPS_CASE(5)
+            AMC_FPS_CASE(6) AMC_FPS_CASE(7) AMC_FPS_CASE(8) AMC_FPS_CASE(9) AMC_FPS_CASE(10) AMC_FPS_CASE(11)
+            AMC_FPS_CASE(12) AMC_FPS_CASE(13) AMC_FPS_CASE(14) AMC_FPS_CASE(15) AMC_FPS_CASE(16) AMC_FPS_CASE(17)
+            AMC_FPS_CASE(18) AMC_FPS_CASE(19) AMC_FPS_CASE(20) AMC_FPS_CASE(21) AMC_FPS_CASE(22) AMC_FPS_CASE(23)
+            AMC_FPS_CASE(24) AMC_FPS_CASE(25) AMC_FPS_CASE(26) AMC_FPS_CASE(27) AMC_FPS_CASE(28) AMC_FPS_CASE(29)
+            AMC_FPS_CASE(30) AMC_FPS_CASE(31) AMC_FPS_CASE(32) AMC_FPS_CASE(33) AMC_FPS_CASE(34) AMC_FPS_CASE(35)
+            AMC_FPS_CASE(36) AMC_FPS_CASE(37) AMC_FPS_CASE(38) AMC_FPS_CASE(39) AMC_FPS_CASE(40) AMC_FPS_CASE(41)
+            AMC_FPS_CASE(42) AMC_FPS_CASE(43) AMC_FPS_CASE(44) AMC_FPS_CASE(45) AMC_FPS_CASE(46) AMC_FPS_CASE(47)
+#undef AMC_FPS_CASE
+            default: break;
+        }
+        if (lane == 0) {
+            FpsRecord r;
+            r.v = vw; r.amb = amb_w ? 1 : 0; r.spos = spos_of(jstar, wl); r.pad = 0;
+            r.x = wx; r.y = wy; r.z = wz; r.pad2 = 0.f;
+            s_rec[buf][wave] = r;
+        }
+        lds_barrier();
+        // ---- 4. workgroup arg-max over <= 16 wave records (every wave does it redundantly) ------------
+        float rv = -3.f;
+        int ra = 0;
+        if (lane < nwaves) { rv = s_rec[buf][lane].v; ra = s_rec[buf][lane].amb; }
+        const float vb = readlane_f32(row_max_f32(rv), 0);
+        const unsigned long long candw = __ballot(lane < nwaves && rv == vb);
+        const bool amb_b = __popcll(candw) != 1 || __ballot(lane < nwaves && rv == vb && ra != 0) != 0;
+        if (!amb_b) {
+            const int ww = (int)__builtin_ctzll(candw);
+            x1 = uniform_f32(s_rec[buf][ww].x);
+            y1 = uniform_f32(s_rec[buf][ww].y);
+            z1 = uniform_f32(s_rec[buf][ww].z);
+            if (tid == 0) out[it] = -1 - s_rec[buf][ww].spos;  // sorted position, translated after the loop
+        } else {
+            // ---- slow path: the maximum is attained by several points -> the reference's key order ----
+            unsigned mykey = 0xffffffffu;
+            int l2 = lane;  // opaque copy: keeps the 48 sorted-position addresses from being hoisted out
+            asm volatile("" : "+v"(l2));  // of the main loop (they would cost a VGPR each)
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                if (pt[j] == vb) {  // rare and divergent
+                    const unsigned key = fps_key(perm[spos_of(j, l2)], log2rb);
+                    mykey = min(mykey, key);
+                }
+            }
+            for (int s = 32; s >= 1; s >>= 1) mykey = min(mykey, (unsigned)__shfl_xor((int)mykey, s, 64));
+            if (lane == 0) s_key[buf][wave] = mykey;
+            lds_barrier();
+            unsigned kk = 0xffffffffu;
+            for (int w = 0; w < nwaves; ++w) kk = min(kk, s_key[buf][w]);
+            const int old = fps_unkey(kk, log2rb);
+            x1 = uniform_f32(pts[(size_t)old * 3 + 0]);
+            y1 = uniform_f32(pts[(size_t)old * 3 + 1]);
+            z1 = uniform_f32(pts[(size_t)old * 3 + 2]);
+            if (tid == 0) out[it] = old;
+        }
+    }
+
+    // fast-path picks were stored as -1 - (sorted position): translate them to point indices now, so
+    // that no iteration waits for a dependent load (tid 0's stores above are fire-and-forget)
+    __syncthreads();
+    for (int i = tid; i < m; i += nthreads) {
+        const int v = out[i];
+        if (v < 0) out[i] = perm[-1 - v];
+    }
+
+    if (temp) {
+        int l3 = lane;
+        asm volatile("" : "+v"(l3));  // see the slow path: no address hoisting across the main loop
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int s = spos_of(j, l3);
+            if (s < n) temp[(size_t)blockIdx.x * n + perm[s]] = pt[j];
+        }
+    }
+}
+
+// Large clouds (more than 24 points per thread): the reference's structure, running minimum in global
+// memory, thread t owns k = t, t+1024, ...  Not on the benchmark path (n <= 24576 there); kept so the
+// entry point has no size limit.
 struct Cand {
     float v;
     int key;  // bit-reversed thread id: smaller wins on equal v
-    int k;    // point index
+    int k;
 };
-
 __device__ __forceinline__ Cand better(Cand a, Cand b)
 {
     const bool take_b = (b.v > a.v) || (b.v == a.v && b.key < a.key);
     return take_b ? b : a;
 }
-
 __device__ __forceinline__ Cand shfl_xor(Cand c, int m)
 {
     Cand r;
@@ -43,86 +404,6 @@ __device__ __forceinline__ Cand shfl_xor(Cand c, int m)
     return r;
 }
 
-template <int PPT>
-__global__ __launch_bounds__(1024) void fps_kernel(int n, int m, int log2rb,
-                                                   const float *__restrict__ dataset,
-                                                   float *__restrict__ temp, int *__restrict__ idxs)
-{
-    __shared__ float s_v[2][16];
-    __shared__ int s_key[2][16], s_k[2][16];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nwaves = (blockDim.x + 63) >> 6;
-    const int rb = 1 << log2rb;  // reference block size; blockDim.x = max(rb, 64)
-    const float *pts = dataset + (size_t)blockIdx.x * n * 3;
-    int *out = idxs + (size_t)blockIdx.x * m;
-
-    float px[PPT], py[PPT], pz[PPT], pt[PPT];
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const int k = tid + rb * j;
-        const bool ok = tid < rb && k < n;
-        px[j] = ok ? pts[(size_t)k * 3 + 0] : 0.f;
-        py[j] = ok ? pts[(size_t)k * 3 + 1] : 0.f;
-        pz[j] = ok ? pts[(size_t)k * 3 + 2] : 0.f;
-        // running minimum distance: the caller's fill value (1e10, subsample.py:95)
-        pt[j] = ok ? (temp ? temp[(size_t)blockIdx.x * n + k] : 1e10f) : -2.f;
-    }
-    const int key = tid < rb ? (int)(__brev((unsigned)tid) >> (32 - max(log2rb, 1))) : 0x7fffffff;
-
-    float x1 = pts[0], y1 = pts[1], z1 = pts[2];  // old = 0
-    if (tid == 0) out[0] = 0;
-
-    for (int it = 1; it < m; ++it) {
-        // ---- update running minima, per-thread first strict maximum -------------
-        float best = -1.f;
-        int bestj = 0;
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const float d = dist2_ref(px[j], py[j], pz[j], x1, y1, z1);
-            // slots past the end hold -2 and never win (min keeps -2 < best = -1)
-            const float d2 = fminf(d, pt[j]);
-            pt[j] = d2;
-            bestj = d2 > best ? j : bestj;
-            best = fmaxf(best, d2);
-            // keep the unrolled bodies in order: interleaving them costs ~1.5 VGPRs per
-            // point and spills at 24 points per thread (96 of the 128 VGPRs are the cloud)
-            if (PPT >= 16) __builtin_amdgcn_sched_barrier(0);
-        }
-        Cand c{best, key, tid + rb * bestj};
-        // ---- wave arg-max --------------------------------------------------------
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) c = better(c, shfl_xor(c, s));
-        if (nwaves > 1) {
-            // double-buffered by iteration parity: one barrier per iteration is enough
-            const int buf = it & 1;
-            if (lane == 0) { s_v[buf][wave] = c.v; s_key[buf][wave] = c.key; s_k[buf][wave] = c.k; }
-            __syncthreads();
-            Cand w{-3.f, 0x7fffffff, 0};
-            if (lane < nwaves) { w.v = s_v[buf][lane]; w.key = s_key[buf][lane]; w.k = s_k[buf][lane]; }
-#pragma unroll
-            for (int s = 8; s >= 1; s >>= 1) w = better(w, shfl_xor(w, s));
-            c = w;  // lanes 0..15 of every wave now agree on the block winner
-        }
-        // every wave knows the winner: fetch its coordinates with a wave-uniform
-        // (scalar) load from L2 -- no second barrier, no LDS broadcast
-        const int old = __builtin_amdgcn_readfirstlane(c.k);
-        x1 = pts[(size_t)old * 3 + 0]; y1 = pts[(size_t)old * 3 + 1]; z1 = pts[(size_t)old * 3 + 2];
-        if (tid == 0) out[it] = old;
-    }
-
-    if (temp) {
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const int k = tid + rb * j;
-            if (tid < rb && k < n) temp[(size_t)blockIdx.x * n + k] = pt[j];
-        }
-    }
-}
-
-// Large clouds (more than 24 points per reference thread): same algorithm with the
-// running minimum in global memory, as the reference does.  Not on the benchmark
-// path (n <= 24576 there); kept so the entry point has no size limit.
 __global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, const float *__restrict__ dataset,
                                                          float *__restrict__ temp, int *__restrict__ idxs)
 {
@@ -161,12 +442,12 @@ __global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, const flo
     }
 }
 
-template <int PPT>
-static int launch_fps(int b, int n, int m, int log2rb, const float *dataset, float *temp, int *idxs,
-                      hipStream_t stream)
+template <int PPT, int NG>
+static int launch_fps(int b, int n, int m, int waves, int log2rb, const float *dataset, float *temp, int *idxs,
+                      int *perm, hipStream_t stream)
 {
-    const int threads = max(1 << log2rb, 64);
-    hipLaunchKernelGGL(fps_kernel<PPT>, dim3(b), dim3(threads), 0, stream, n, m, log2rb, dataset, temp, idxs);
+    hipLaunchKernelGGL((fps_kernel<PPT, NG>), dim3(b), dim3(waves * 64), 0, stream, n, m, log2rb, dataset, temp, idxs,
+                       perm);
     return launch_status("amc3d_furthest_point_sampling");
 }
 
@@ -174,27 +455,40 @@ static int launch_fps(int b, int n, int m, int log2rb, const float *dataset, flo
 
 using namespace amc;
 
+AMC_API size_t amc3d_fps_workspace_bytes(int b, int n)
+{
+    return (size_t)(b > 0 ? b : 0) * (size_t)(n > 0 ? n : 0) * sizeof(int);
+}
+
 AMC_API int amc3d_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp, int *idxs,
-                                          void *stream_)
+                                          void *workspace, size_t workspace_bytes, void *stream_)
 {
     if (b <= 0 || m <= 0) return 0;  // sampling_gpu.cu:108 `if (m <= 0) return;`
     if (n <= 0 || !dataset || !idxs) return bad_arg("amc3d_furthest_point_sampling: bad argument");
     hipStream_t stream = (hipStream_t)stream_;
-    // cuda_utils.h:10-14: largest power of two <= n, capped at 1024
+    // cuda_utils.h:10-14: largest power of two <= n, capped at 1024 (defines the tie order)
     int log2rb = 0;
     while ((2 << log2rb) <= n && log2rb < 10) ++log2rb;
-    const int rb = 1 << log2rb;
-    const int ppt = (n + rb - 1) / rb;
-    if (ppt <= 1) return launch_fps<1>(b, n, m, log2rb, dataset, temp, idxs, stream);
-    if (ppt <= 2) return launch_fps<2>(b, n, m, log2rb, dataset, temp, idxs, stream);
-    if (ppt <= 4) return launch_fps<4>(b, n, m, log2rb, dataset, temp, idxs, stream);
-    if (ppt <= 6) return launch_fps<6>(b, n, m, log2rb, dataset, temp, idxs, stream);
-    if (ppt <= 8) return launch_fps<8>(b, n, m, log2rb, dataset, temp, idxs, stream);
-    if (ppt <= 12) return launch_fps<12>(b, n, m, log2rb, dataset, temp, idxs, stream);
-    if (ppt <= 16) return launch_fps<16>(b, n, m, log2rb, dataset, temp, idxs, stream);
-    if (ppt <= 24) return launch_fps<24>(b, n, m, log2rb, dataset, temp, idxs, stream);
-    // 24 points x 4 VGPRs is what fits the 128-VGPR budget of a 1024-thread workgroup
-    if (!temp) return bad_arg("amc3d_furthest_point_sampling: n > 24576 needs the temp buffer");
-    hipLaunchKernelGGL(fps_kernel_large, dim3(b), dim3(1024), 0, stream, n, m, dataset, temp, idxs);
-    return launch_status("amc3d_furthest_point_sampling");
+    if (n > 24576) {
+        if (!temp) return bad_arg("amc3d_furthest_point_sampling: n > 24576 needs the temp buffer");
+        hipLaunchKernelGGL(fps_kernel_large, dim3(b), dim3(1024), 0, stream, n, m, dataset, temp, idxs);
+        return launch_status("amc3d_furthest_point_sampling");
+    }
+    if (!workspace || workspace_bytes < amc3d_fps_workspace_bytes(b, n))
+        return bad_arg("amc3d_furthest_point_sampling: workspace too small (amc3d_fps_workspace_bytes)");
+    int *perm = (int *)workspace;
+    // waves: enough 64-lane rows for the cloud at the chosen points-per-thread; a power of two so that the
+    // 4096-cell scan divides evenly
+    auto waves_for = [&](int ppt) {
+        int w = 1;
+        while (w < 8 && w * 64 * ppt < n) w <<= 1;
+        return w;
+    };
+    if (n > 12288) return launch_fps<48, 6>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
+    if (n > 6144) return launch_fps<24, 3>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
+    if (n > 3072) return launch_fps<12, 3>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
+    if (n > 1536) return launch_fps<6, 3>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
+    if (n > 512) return launch_fps<3, 1>(b, n, m, waves_for(3), log2rb, dataset, temp, idxs, perm, stream);
+    if (n > 64) return launch_fps<2, 1>(b, n, m, waves_for(2), log2rb, dataset, temp, idxs, perm, stream);
+    return launch_fps<1, 1>(b, n, m, 1, log2rb, dataset, temp, idxs, perm, stream);
 }

@@ -139,9 +139,11 @@ class FurthestPointSampling(Function):
         if N > 24576:
             temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
         with torch.cuda.device(xyz.device), timing.span("furthest_point_sampling", B * N * 12 + B * int(npoint) * 4):
+            work = torch.empty(B * N, dtype=torch.int32, device=xyz.device)
             _lib.check(_lib.load().amc3d_furthest_point_sampling(B, N, int(npoint), _ptr(xyz),
                                                                  _ptr(temp) if temp is not None else None,
-                                                                 _ptr(output), _stream(xyz)), "furthest_point_sampling")
+                                                                 _ptr(output), _ptr(work), work.numel() * 4,
+                                                                 _stream(xyz)), "furthest_point_sampling")
         ctx.mark_non_differentiable(output)
         return output
 

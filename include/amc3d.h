@@ -78,13 +78,16 @@ int amc3d_gather_points_grad(int b, int c, int n, int npoints,
 
 /* replaces furthest_point_sampling_wrapper (sampling.cpp, sampling_gpu.cu:100-260):
  * dataset (b,n,3) -> idxs (b,m), idxs[:,0] = 0.  `temp` (b,n) is the reference's
- * running-min-distance scratch (the caller fills it with 1e10, subsample.py:95);
- * it may be NULL: this implementation keeps the running minimum on chip and only
- * writes it back when a buffer is given.  Ties resolve exactly as the
- * reference's block-strided scan + shared-memory tree does for its block size
- * opt_n_threads(n) (cuda_utils.h:10-14). */
+ * running-min-distance buffer (the caller fills it with 1e10, subsample.py:95); it may be
+ * NULL for n <= 24576: the running minima then start at 1e10 and stay on chip.  When given it
+ * is read as the initial minima and receives the final ones, as in the reference.
+ * `workspace`: amc3d_fps_workspace_bytes(b,n) bytes (the cloud's spatial sort order).
+ * Ties resolve exactly as the reference's block-strided scan + shared-memory tree does for
+ * its block size opt_n_threads(n) (cuda_utils.h:10-14). */
+size_t amc3d_fps_workspace_bytes(int b, int n);
 int amc3d_furthest_point_sampling(int b, int n, int m, const float *dataset,
-                                  float *temp, int *idxs, void *stream);
+                                  float *temp, int *idxs, void *workspace, size_t workspace_bytes,
+                                  void *stream);
 
 /* replaces three_nn_wrapper_fast (interpolate_gpu.cu:16-81):
  * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) squared distances, idx (b,n,3) */

@@ -104,7 +104,11 @@ def test_fps_golden(dev, ops_fix, tag):
 @pytest.mark.parametrize("B,N,M,kind", [
     (2, 1000, 250, "room"), (3, 375, 93, "uniform"), (2, 93, 23, "uniform"), (1, 6000, 1500, "room"),
     (2, 512, 512, "lattice"), (2, 300, 300, "dup"), (1, 40, 10, "dup"), (1, 1, 1, "uniform"), (2, 2, 2, "uniform"),
-    (1, 24000, 600, "room"), (1, 4097, 300, "lattice"), (1, 24577, 64, "uniform"), (1, 40000, 50, "uniform")])
+    (1, 24000, 600, "room"), (1, 4097, 300, "lattice"), (1, 24577, 64, "uniform"), (1, 40000, 50, "uniform"),
+    # every points-per-thread bracket of the register kernel, tie-heavy clouds included (slow path)
+    (2, 24000, 1500, "dup"), (1, 13000, 500, "room"), (1, 12288, 300, "lattice"), (1, 7000, 700, "dup"),
+    (2, 3100, 400, "uniform"), (1, 1600, 1600, "lattice"), (3, 600, 150, "dup"), (1, 65, 65, "uniform"),
+    (1, 64, 64, "lattice"), (2, 1537, 200, "room"), (1, 24576, 200, "uniform")])
 def test_fps_vs_oracle(dev, B, N, M, kind):
     from amcontrast3d_amd import ops
     from oracle import pointops_ref as K
