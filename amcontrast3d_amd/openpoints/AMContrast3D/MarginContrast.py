@@ -25,16 +25,27 @@ def _posmask_cnt(labels, neighbor_label):
     return torch.argmax(torch.unsqueeze(labels, -2), -1) == torch.argmax(neighbor_label, -1)
 
 
-def _stage_neighbourhood(n, i, stageACE_list, target, nstride, num_classes, ignore_index, nsample, ftype):
-    """k-NN of the stage (self match dropped), per-point classes and the positive mask -- three
-    kernels; the reference gathers (m,k,ncls) one-hot labels for this (MarginContrast.py:220-231)."""
+def plan_stage(n, i, stageACE_list, target, nstride, num_classes, ignore_index, ambiguity_args, ftype='f_out'):
+    """Everything of one loss stage that depends only on coordinates and labels (not on the
+    embeddings): the stage's k-NN (self match dropped, a strided view), the positive mask and the
+    ambiguity a_i -- MarginContrast.py:220-240.  Cached in stageACE_list['geometry']['loss'] when a
+    caller prepared it ahead of time (amcontrast3d_amd.geometry.precompute)."""
     from amcontrast3d_amd import ops
-    p, features, o = fetch_pxo(n, i, stageACE_list, ftype)
+    p, o = stageACE_list[n][i]['p_out'], stageACE_list[n][i]['offset']  # no embeddings needed here
     labels, _ = get_subscene_class(n, i, stageACE_list, target, nstride, num_classes, ignore_index)
-    neighbor_idx, _ = pointops.knnquery(nsample, p, p, o, o)
+    neighbor_idx, _ = pointops.knnquery(ambiguity_args.nsample, p, p, o, o)
     neighbor_idx = neighbor_idx[..., 1:]  # drop the self match: a strided view, no copy
     posmask = ops.posmask_from_labels(labels, neighbor_idx)
-    return p, features, neighbor_idx, posmask, neighbor_idx.shape[1]
+    a, shares = ambiguity_function(p, posmask, neighbor_idx.shape[1], neighbor_idx, ambiguity_args.cctype,
+                                   ambiguity_args.ccbeta, ambiguity_args.vis, ambiguity_args.nu)
+    return {'neighbor_idx': neighbor_idx, 'posmask': posmask, 'ambiguity': a, 'shares': shares}
+
+
+def _stage_plan(n, i, stageACE_list, target, nstride, num_classes, ignore_index, ambiguity_args, ftype):
+    geometry = stageACE_list.get('geometry') if hasattr(stageACE_list, 'get') else None
+    if geometry is not None and 'loss' in geometry:
+        return geometry['loss'][i]
+    return plan_stage(n, i, stageACE_list, target, nstride, num_classes, ignore_index, ambiguity_args, ftype)
 
 
 class AmbiguityHead(nn.Module):
@@ -49,11 +60,8 @@ class AmbiguityHead(nn.Module):
         return _posmask_cnt(labels, neighbor_label)
 
     def point_ambiguity(self, n, i, stageACE_list, target, num_classes, ignore_index, ambiguity_args):
-        p, _, neighbor_idx, posmask, k = _stage_neighbourhood(
-            n, i, stageACE_list, target, self.nstride, num_classes, ignore_index, ambiguity_args.nsample, self.ftype)
-        a, _ = ambiguity_function(p, posmask, k, neighbor_idx, ambiguity_args.cctype, ambiguity_args.ccbeta,
-                                  ambiguity_args.vis, ambiguity_args.nu)
-        return a
+        return _stage_plan(n, i, stageACE_list, target, self.nstride, num_classes, ignore_index, ambiguity_args,
+                           self.ftype)['ambiguity']
 
     def forward(self, target, stageACE_list, num_classes, ignore_index, ambiguity_args):
         return [self.main(ambiguity_args.stages, i, stageACE_list, target, num_classes, ignore_index, ambiguity_args)
@@ -114,12 +122,19 @@ class ContrastHead(nn.Module):
             loss = torch.sum(loss, axis=-1) / (torch.sum(posmask.int(), axis=-1) + _eps)
         return -torch.log(loss)
 
+    def plan(self, target, stageACE_list, num_classes, ignore_index, ambiguity_args):
+        """coordinate / label-only part of every stage (see plan_stage)"""
+        with torch.no_grad():
+            return [plan_stage(ambiguity_args.stages, i, stageACE_list, target.flatten(), self.nstride, num_classes,
+                               ignore_index, ambiguity_args, self.ftype) for i in range(ambiguity_args.stages_num)]
+
     def point_contrast_margin(self, n, i, stageACE_list, target, num_classes, ignore_index, ambiguity_args):
         from amcontrast3d_amd import ops
-        p, features, neighbor_idx, posmask, k = _stage_neighbourhood(
-            n, i, stageACE_list, target, self.nstride, num_classes, ignore_index, ambiguity_args.nsample, self.ftype)
-        ambiguity_soft, _ = ambiguity_function(p, posmask, k, neighbor_idx, ambiguity_args.cctype,
-                                               ambiguity_args.ccbeta, ambiguity_args.vis, ambiguity_args.nu)
+        g = _stage_plan(n, i, stageACE_list, target, self.nstride, num_classes, ignore_index, ambiguity_args,
+                        self.ftype)
+        neighbor_idx, posmask, ambiguity_soft = g['neighbor_idx'], g['posmask'], g['ambiguity']
+        features = fetch_pxo(n, i, stageACE_list, self.ftype)[1]
+        k = neighbor_idx.shape[1]
         target_ai = ambiguity_soft
         output_ai = stageACE_list['ambiguity'][i].flatten() if 'ambiguity' in stageACE_list.keys() else None
 

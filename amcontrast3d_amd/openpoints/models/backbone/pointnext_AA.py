@@ -13,6 +13,13 @@ keys) and return structures:
 
 All neighbour search, sampling, grouping and interpolation runs on the gfx950
 kernels in amcontrast3d_amd (no torch fallback).
+
+Geometry / feature split.  Everything that depends only on the coordinates -- FPS picks,
+ball-query indices, relative positions, 3-NN indices and weights -- is computed by the
+``plan*`` methods and consumed by ``forward``; ``forward`` builds the plan itself when the
+batch dict carries none (key ``'_geometry'``), so there is one code path.  A trainer can build
+the plan of the NEXT batch on a side stream while the current batch trains (bench.py does):
+FPS is a serial chain that occupies 8 of the 256 CUs.
 """
 import logging
 from typing import List
@@ -22,7 +29,7 @@ import torch.nn as nn
 
 from ..build import MODELS
 from ..layers import (CHANNEL_MAP, create_act, create_convblock1d, create_convblock2d, create_grouper,
-                      furthest_point_sample, get_aggregation_feautres, random_sample, three_interpolation)
+                      furthest_point_sample, get_aggregation_feautres, random_sample, three_interpolate, three_nn)
 
 
 def get_reduction_fn(reduction):
@@ -55,9 +62,19 @@ class LocalAggregation(nn.Module):
         self.pool = get_reduction_fn(self.reduction)
         self.feature_type = feature_type
 
-    def forward(self, pf):
+    @torch.no_grad()
+    def plan(self, p):
+        """coordinate-only part: neighbour indices and relative positions of the self query"""
+        if not hasattr(self.grouper, 'query'):
+            return None
+        idx = self.grouper.query(p, p)
+        return {'idx': idx, 'dp': self.grouper.relative_positions(idx, p, p)}
+
+    def forward(self, pf, geom=None):
         p, f = pf
-        dp, fj = self.grouper(p, p, f)
+        if geom is None:
+            geom = self.plan(p)
+        dp, fj = self.grouper(p, p, f, geom=geom)
         fj = get_aggregation_feautres(p, dp, f, fj, self.feature_type)
         return self.pool(self.convs(fj))
 
@@ -105,21 +122,35 @@ class SetAbstraction(nn.Module):
             elif sampler.lower() == 'random':
                 self.sample_fn = random_sample
 
-    def forward(self, pf):
-        p, f = pf
+    @torch.no_grad()
+    def plan(self, p):
+        """coordinate-only part: FPS picks, the sub-sampled cloud, neighbour indices, relative positions"""
         if self.is_head:
-            return p, self.convs(f)
+            return {'new_p': p}
         if not self.all_aggr:
             idx = self.sample_fn(p, p.shape[1] // self.stride).long()
             new_p = torch.gather(p, 1, idx.unsqueeze(-1).expand(-1, -1, 3))
         else:
-            new_p = p
+            idx, new_p = None, p
+        g = {'fps_idx': idx, 'new_p': new_p}
+        if hasattr(self.grouper, 'query'):
+            g['idx'] = self.grouper.query(new_p, p)
+            g['dp'] = self.grouper.relative_positions(g['idx'], new_p, p)
+        return g
+
+    def forward(self, pf, geom=None):
+        p, f = pf
+        if self.is_head:
+            return p, self.convs(f)
+        if geom is None:
+            geom = self.plan(p)
+        idx, new_p = geom['fps_idx'], geom['new_p']
         fi = None
         if self.use_res or 'df' in self.feature_type:
             fi = torch.gather(f, -1, idx.unsqueeze(1).expand(-1, f.shape[1], -1))
             if self.use_res:
                 identity = self.skipconv(fi)
-        dp, fj = self.grouper(new_p, p, f)
+        dp, fj = self.grouper(new_p, p, f, geom=geom if 'idx' in geom else None)
         fj = get_aggregation_feautres(new_p, dp, fi, fj, feature_type=self.feature_type)
         f = self.pool(self.convs(fj))
         if self.use_res:
@@ -145,14 +176,26 @@ class FeaturePropogation(nn.Module):
                 for i in range(len(mlp) - 1)])
         self.pool = lambda x: torch.mean(x, dim=-1, keepdim=False)
 
-    def forward(self, pf1, pf2=None):
+    @staticmethod
+    @torch.no_grad()
+    def plan(p1, p2):
+        """coordinate-only part: the 3 nearest coarse points of every fine point and their
+        inverse-distance weights (upsampling.py:97-100)"""
+        dist, idx = three_nn(p1, p2)
+        dist_recip = 1.0 / (dist + 1e-8)
+        weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+        return {'idx': idx, 'weight': weight}
+
+    def forward(self, pf1, pf2=None, geom=None):
         if pf2 is None:  # global branch (not used by the segmentation decoder)
             _, f = pf1
             g = self.linear2(self.pool(f))
             return self.linear1(torch.cat((f, g.unsqueeze(-1).expand(-1, -1, f.shape[-1])), dim=1))
         p1, f1 = pf1
         p2, f2 = pf2
-        up = three_interpolation(p1, p2, f2)
+        if geom is None:
+            geom = self.plan(p1, p2)
+        up = three_interpolate(f2, geom['idx'], geom['weight'])
         return self.convs(up if f1 is None else torch.cat((f1, up), dim=1))
 
 
@@ -181,10 +224,13 @@ class InvResMLP(nn.Module):
             for i in range(len(channels) - 1)])
         self.act = create_act(act_args)
 
-    def forward(self, pf):
+    def plan(self, p):
+        return self.convs.plan(p)
+
+    def forward(self, pf, geom=None):
         p, f = pf
         identity = f
-        f = self.pwconv(self.convs([p, f]))
+        f = self.pwconv(self.convs([p, f], geom=geom))
         if f.shape[-1] == identity.shape[-1] and self.use_res:
             f += identity
         return [p, self.act(f)]
@@ -202,10 +248,13 @@ class ResBlock(nn.Module):
                                       **kwargs)
         self.act = create_act(act_args)
 
-    def forward(self, pf):
+    def plan(self, p):
+        return self.convs.plan(p)
+
+    def forward(self, pf, geom=None):
         p, f = pf
         identity = f
-        f = self.convs([p, f])
+        f = self.convs([p, f], geom=geom)
         if f.shape[-1] == identity.shape[-1] and self.use_res:
             f += identity
         return [p, self.act(f)]
@@ -315,17 +364,47 @@ class PointNextEncoder_AMContrast3D(nn.Module):
             p0, f0 = stage([p0, f0])
         return f0.squeeze(-1)
 
+    @torch.no_grad()
+    def plan_geometry(self, p0):
+        """Coordinate-only work of the whole encoder: per stage a list with one plan per block.  Blocks of
+        one stage that query the same cloud with the same radius / nsample (every InvResMLP of a stage,
+        pointnext_AA.py:419-427) share one neighbour search."""
+        plans, p = [], p0
+        for stage in self.encoder:
+            blocks, cache = [], {}
+            for blk in stage:
+                if isinstance(blk, SetAbstraction):
+                    g = blk.plan(p)
+                    p = g['new_p']
+                else:
+                    grouper = blk.convs.grouper
+                    key = (getattr(grouper, 'radius', None), getattr(grouper, 'nsample', None))
+                    if key not in cache:
+                        cache[key] = blk.plan(p)
+                    g = cache[key]
+                blocks.append(g)
+            plans.append(blocks)
+        return plans
+
     def forward_seg_feat_ACE(self, p0, f0=None):
         """-> p[6], f[6], stageACE_list = {'inputs', 'down', 'up'}; 'down' and 'up' are the SAME list of
         per-stage dicts {p_out (B*n,3), f_out (B*n,C), offset int32 [B*n]} (pointnext_AA.py:439-467)."""
         stageACE_list = {'inputs': p0}
+        geometry = None
         if hasattr(p0, 'keys'):
+            geometry = p0.get('_geometry', None)
             p0, f0 = p0['pos'], p0.get('x', None)
         if f0 is None:
             f0 = p0.clone().transpose(1, 2).contiguous()
+        if geometry is None:
+            geometry = {'encoder': self.plan_geometry(p0)}
+        stageACE_list['geometry'] = geometry
         p, f, down = [p0], [f0], []
         for i, stage in enumerate(self.encoder):
-            _p, _f = stage([p[-1], f[-1]])
+            pf = [p[-1], f[-1]]
+            for blk, g in zip(stage, geometry['encoder'][i]):
+                pf = blk(pf, geom=g)
+            _p, _f = pf
             p.append(_p)
             f.append(_f)
             if i != len(self.encoder) - 1:
@@ -365,10 +444,20 @@ class PointNextDecoder_AMContrast3D(nn.Module):
         self.in_channels = fp_channels
         return nn.Sequential(FeaturePropogation(mlp))
 
+    @torch.no_grad()
+    def plan_geometry(self, p):
+        """3-NN indices / weights of every decoder level (coordinate-only), keyed by level -1 .. -n"""
+        return {i: FeaturePropogation.plan(p[i - 1], p[i]) for i in range(-1, -len(self.decoder) - 1, -1)}
+
     def forward_then_ACE(self, p, f, stageACE_list):
+        geometry = stageACE_list.get('geometry') if isinstance(stageACE_list, dict) else None
+        if geometry is None:
+            geometry = stageACE_list['geometry'] = {}
+        if 'decoder' not in geometry:
+            geometry['decoder'] = self.plan_geometry(p)
         for i in range(-1, -len(self.decoder) - 1, -1):
             f[i - 1] = self.decoder[i][1:](
-                [p[i], self.decoder[i][0]([p[i - 1], f[i - 1]], [p[i], f[i]])])[1]
+                [p[i], self.decoder[i][0]([p[i - 1], f[i - 1]], [p[i], f[i]], geom=geometry['decoder'][i])])[1]
             # decoder embedding of this resolution, (B*n, C) rows, for the contrastive loss
             stageACE_list['up'][i]['f_out'] = torch.flatten(f[i - 1].transpose(1, 2), start_dim=0, end_dim=1)
         return f[-len(self.decoder) - 1].squeeze(-1), stageACE_list

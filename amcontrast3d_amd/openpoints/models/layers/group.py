@@ -34,23 +34,34 @@ class QueryAndGroup(nn.Module):
         self.relative_xyz = relative_xyz
         self.return_only_idx = return_only_idx
 
-    def forward(self, query_xyz, support_xyz, features=None):
-        """query (B,npoint,3), support (B,N,3), features (B,C,N)
-        -> relative positions (B,3,npoint,nsample), grouped features (B,C,npoint,nsample)"""
-        idx = ball_query(self.radius, self.nsample, support_xyz, query_xyz)
-        if self.return_only_idx:
-            return idx
+    def query(self, query_xyz, support_xyz):
+        """neighbour indices (B,npoint,nsample) int32 -- geometry only"""
+        return ball_query(self.radius, self.nsample, support_xyz, query_xyz)
+
+    def relative_positions(self, idx, query_xyz, support_xyz):
+        """(B,3,npoint,nsample) neighbour offsets, divided by the radius if normalize_dp -- geometry only"""
         grouped_xyz = grouping_operation(support_xyz.transpose(1, 2).contiguous(), idx)
         if self.relative_xyz:
             grouped_xyz = grouped_xyz - query_xyz.transpose(1, 2).unsqueeze(-1)
             if self.normalize_dp:
                 grouped_xyz /= self.radius
+        return grouped_xyz
+
+    def forward(self, query_xyz, support_xyz, features=None, geom=None):
+        """query (B,npoint,3), support (B,N,3), features (B,C,N)
+        -> relative positions (B,3,npoint,nsample), grouped features (B,C,npoint,nsample).
+        `geom` = {'idx', 'dp'} precomputed by query()/relative_positions() (they do not depend on the
+        features, so a caller may prepare them ahead of time / on another stream)."""
+        idx = geom['idx'] if geom is not None else self.query(query_xyz, support_xyz)
+        if self.return_only_idx:
+            return idx
+        grouped_xyz = geom['dp'] if geom is not None else self.relative_positions(idx, query_xyz, support_xyz)
         grouped_features = grouping_operation(features, idx) if features is not None else None
         return grouped_xyz, grouped_features
 
 
 class GroupAll(nn.Module):
-    def forward(self, new_xyz, xyz, features=None):
+    def forward(self, new_xyz, xyz, features=None, geom=None):
         grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
         grouped_features = features.unsqueeze(2) if features is not None else None
         return grouped_xyz, grouped_features

@@ -133,3 +133,30 @@ def test_stage_list_structure():
         st = stage["up"][i]
         assert st["p_out"].shape == (2 * n, 3) and st["f_out"].shape == (2 * n, c)
         assert st["offset"].dtype == torch.int32 and st["offset"].tolist() == [2 * n]
+
+
+def test_precomputed_geometry_is_the_same_computation():
+    """geometry.precompute (the coordinate-only half, e.g. built a step ahead on a side stream) followed by
+    model/criterion must give bit-identical logits and loss to the inline path, for S and for a model with
+    InvResMLP blocks (shared per-stage ball queries)."""
+    from amcontrast3d_amd import geometry, synthetic
+    dev = torch.device("cuda:0")
+    for cfg in (configs.model_cfg("S", dropout=0), configs.model_cfg("L", dropout=0, width=8, blocks=[1, 2, 2, 1, 1])):
+        model, criterion = build(cfg, dev)
+        nb = synthetic.make_batch(2, 2048, first_id=77)
+        data = {k: torch.from_numpy(v).to(dev) for k, v in nb.items()}
+        aa = easy(configs.ambiguity_args("s3dis"))
+        logits0, stage0 = model(dict(data))
+        loss0 = criterion(logits0, data["y"], stage0, 13, None, aa)
+        plan = geometry.precompute(model, criterion.contrast_head, data, 13, None, aa)
+        d2 = dict(data)
+        d2["_geometry"] = plan
+        logits1, stage1 = model(d2)
+        loss1 = criterion(logits1, data["y"], stage1, 13, None, aa)
+        assert torch.equal(logits0, logits1)
+        assert float(loss0) == float(loss1)
+        # static-buffer refresh used under graph replay
+        plan2 = geometry.precompute(model, criterion.contrast_head, data, 13, None, aa)
+        geometry.copy_into(plan, plan2)
+        logits2, _ = model(d2)
+        assert torch.equal(logits0, logits2)
