@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-_SO = os.path.join(_CSRC, "libamc3d_hip.so")
+_SO = os.environ.get("AMC3D_LIB") or os.path.join(_CSRC, "libamc3d_hip.so")  # AMC3D_LIB: diagnostic builds
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 

@@ -249,6 +249,19 @@ __global__ __launch_bounds__(512) void fps_kernel(int n, int m, int log2rb, cons
 
     float x1 = pts[0], y1 = pts[1], z1 = pts[2];  // old = 0
     if (tid == 0) out[0] = 0;
+#ifdef AMC_FPS_DIAG
+    unsigned long long t_acc[5] = {0, 0, 0, 0, 0}, t_prev;
+#define AMC_STAMP(i)                                                                          \
+    {                                                                                         \
+        unsigned long long t_now;                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now)::"memory");         \
+        t_acc[i] += t_now - t_prev;                                                           \
+        t_prev = t_now;                                                                       \
+    }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+#else
+#define AMC_STAMP(i)
+#endif
 
     for (int it = 1; it < m; ++it) {
         const int buf = it & 1;
@@ -280,6 +293,7 @@ __global__ __launch_bounds__(512) void fps_kernel(int n, int m, int log2rb, cons
                 pthr = lane == g ? nthr : pthr;
             }
         }
+        AMC_STAMP(0)
         // ---- 2. lane maximum over its groups ---------------------------------------------------------
         float best = gb[0];
         int slot = gsl[0];
@@ -324,20 +338,27 @@ __global__ __launch_bounds__(512) void fps_kernel(int n, int m, int log2rb, cons
             r.x = wx; r.y = wy; r.z = wz; r.pad2 = 0.f;
             s_rec[buf][wave] = r;
         }
+        AMC_STAMP(1)
         lds_barrier();
+        AMC_STAMP(2)
         // ---- 4. workgroup arg-max over <= 16 wave records (every wave does it redundantly) ------------
-        float rv = -3.f;
-        int ra = 0;
-        if (lane < nwaves) { rv = s_rec[buf][lane].v; ra = s_rec[buf][lane].amb; }
+        // lanes 0..nwaves-1 fetch one whole record each (two 16-byte LDS reads, ONE round trip); the winner's
+        // coordinates then come out of the winner lane's registers, not out of a second LDS access
+        float rv = -3.f, rx = 0.f, ry = 0.f, rz = 0.f;
+        int ra = 0, rs = 0;
+        if (lane < nwaves) {
+            const FpsRecord r = s_rec[buf][lane];
+            rv = r.v; ra = r.amb; rs = r.spos; rx = r.x; ry = r.y; rz = r.z;
+        }
         const float vb = readlane_f32(row_max_f32(rv), 0);
         const unsigned long long candw = __ballot(lane < nwaves && rv == vb);
         const bool amb_b = __popcll(candw) != 1 || __ballot(lane < nwaves && rv == vb && ra != 0) != 0;
         if (!amb_b) {
             const int ww = (int)__builtin_ctzll(candw);
-            x1 = uniform_f32(s_rec[buf][ww].x);
-            y1 = uniform_f32(s_rec[buf][ww].y);
-            z1 = uniform_f32(s_rec[buf][ww].z);
-            if (tid == 0) out[it] = -1 - s_rec[buf][ww].spos;  // sorted position, translated after the loop
+            x1 = readlane_f32(rx, ww);
+            y1 = readlane_f32(ry, ww);
+            z1 = readlane_f32(rz, ww);
+            if (tid == 0) out[it] = -1 - __builtin_amdgcn_readlane(rs, ww);  // sorted position, translated after the loop
         } else {
             // ---- slow path: the maximum is attained by several points -> the reference's key order ----
             unsigned mykey = 0xffffffffu;
@@ -361,6 +382,7 @@ __global__ __launch_bounds__(512) void fps_kernel(int n, int m, int log2rb, cons
             z1 = uniform_f32(pts[(size_t)old * 3 + 2]);
             if (tid == 0) out[it] = old;
         }
+        AMC_STAMP(3)
     }
 
     // fast-path picks were stored as -1 - (sorted position): translate them to point indices now, so
@@ -380,6 +402,12 @@ __global__ __launch_bounds__(512) void fps_kernel(int n, int m, int log2rb, cons
             if (s < n) temp[(size_t)blockIdx.x * n + perm[s]] = pt[j];
         }
     }
+#ifdef AMC_FPS_DIAG
+    __syncthreads();
+    if (lane == 0 && temp) {  // diag build only: per-wave cycle sums overwrite the head of the temp buffer
+        for (int i = 0; i < 5; ++i) temp[(size_t)blockIdx.x * n + wave * 8 + i] = (float)t_acc[i];
+    }
+#endif
 }
 
 // Large clouds (more than 24 points per thread): the reference's structure, running minimum in global

@@ -17,20 +17,92 @@ def _unwrap(model):
 
 
 @torch.no_grad()
-def precompute(model, contrast_head, data, num_classes, ignore_index, ambiguity_args):
-    """-> {'encoder': ..., 'decoder': ..., 'loss': ...} for the batch dict `data` (pos, y)."""
+def precompute_sampling(model, data, aux_stream=None, join=True):
+    """Encoder / decoder geometry of the batch dict `data` (needs only 'pos'):
+    -> {'encoder': per stage a list with one plan per block, 'decoder': per level 3-NN idx / weights}.
+
+    The four FPS levels form the only serial chain (level i+1 samples level i's output); they run
+    back to back on the current stream.  Ball queries, relative positions and 3-NN hang off that chain
+    and, when an `aux_stream` is given, run there, concurrently with the later FPS levels.
+
+    Under hipGraph capture fork `aux_stream` from the capture's origin stream yourself, like the
+    calling stream, and pass join=False (join it at the origin): ROCm 7.2 segfaults while capturing a
+    fork made from an already forked stream or a wait in both directions between two forks
+    (scratch/graph_patterns.py)."""
+    from openpoints.models.backbone.pointnext_AA import _segment_offset  # noqa: F401
     m = _unwrap(model)
     pos = data["pos"]
-    enc = m.encoder.plan_geometry(pos)
-    p = [pos] + [blocks[0]["new_p"] for blocks in enc]
-    dec = m.decoder.plan_geometry(p)
+    cur = torch.cuda.current_stream(pos.device)
+    aux = aux_stream if aux_stream is not None else cur
+    stages_mod = list(m.encoder.encoder)
+    p, enc = [pos], []
+    for i, stage in enumerate(stages_mod):
+        g = stage[0].plan_sample(p[-1])
+        enc.append([g])
+        p.append(g["new_p"])
+        if aux is not cur:
+            aux.wait_stream(cur)
+        with torch.cuda.stream(aux):
+            stage[0].plan_group(p[i], g)
+            cache = {}
+            for blk in list(stage)[1:]:  # blocks of one stage share one self-query per (radius, nsample)
+                grouper = blk.convs.grouper
+                key = (getattr(grouper, "radius", None), getattr(grouper, "nsample", None))
+                if key not in cache:
+                    cache[key] = blk.plan(p[i + 1])
+                enc[i].append(cache[key])
+    with torch.cuda.stream(aux):
+        dec = m.decoder.plan_geometry(p)
+    if aux is not cur and join:
+        cur.wait_stream(aux)
+    return {"encoder": enc, "decoder": dec}
+
+
+def stage_points(plan):
+    """The flattened clouds of the loss stages of a sampling plan: [{'p_out' (B*n,3), 'offset'}] x 4
+    (what pointnext_AA.py:458-462 puts into stageACE_list)."""
     from openpoints.models.backbone.pointnext_AA import _segment_offset
-    stages = []
-    for q in p[1:-1]:
-        flat = torch.flatten(q, start_dim=0, end_dim=1)
-        stages.append({"p_out": flat, "offset": _segment_offset(flat.shape[0], flat.device)})
-    loss = contrast_head.plan(data["y"], {"up": stages, "down": stages}, num_classes, ignore_index, ambiguity_args)
-    return {"encoder": enc, "decoder": dec, "loss": loss}
+    out = []
+    for blocks in plan["encoder"][:-1]:
+        flat = torch.flatten(blocks[0]["new_p"], start_dim=0, end_dim=1)
+        out.append({"p_out": flat, "offset": _segment_offset(flat.shape[0], flat.device)})
+    return out
+
+
+@torch.no_grad()
+def precompute_loss(contrast_head, plan, y, num_classes, ignore_index, ambiguity_args):
+    """Loss geometry (per stage: k-NN, class vote, positive mask, ambiguity) of the batch whose
+    sampling plan is `plan`; needs only coordinates and labels."""
+    stages = stage_points(plan)
+    return contrast_head.plan(y, {"up": stages, "down": stages}, num_classes, ignore_index, ambiguity_args)
+
+
+@torch.no_grad()
+def precompute(model, contrast_head, data, num_classes, ignore_index, ambiguity_args, aux_stream=None, join=True):
+    """-> {'encoder', 'decoder', 'loss'}: the whole coordinate-only half of a step for `data` (pos, y)."""
+    plan = precompute_sampling(model, data, aux_stream=aux_stream, join=True if aux_stream is None else join)
+    if aux_stream is not None and not join:
+        with torch.cuda.stream(aux_stream):
+            plan["loss"] = precompute_loss(contrast_head, plan, data["y"], num_classes, ignore_index, ambiguity_args)
+    else:
+        plan["loss"] = precompute_loss(contrast_head, plan, data["y"], num_classes, ignore_index, ambiguity_args)
+    return plan
+
+
+def clone(plan):
+    """Deep copy of a plan's tensors (fresh static buffers); views are cloned as contiguous tensors
+    except the loss stages' neighbour index, which keeps its idx[:, 1:] view layout."""
+    if torch.is_tensor(plan):
+        if plan.dim() == 2 and plan.stride(1) == 1 and plan.stride(0) == plan.shape[1] + 1 and plan.storage_offset() == 1:
+            full = torch.empty(plan.shape[0], plan.shape[1] + 1, dtype=plan.dtype, device=plan.device)
+            full[:, 1:].copy_(plan)
+            return full[:, 1:]
+        return plan.clone()
+    if isinstance(plan, dict):
+        return {k: clone(v) for k, v in plan.items()}
+    if isinstance(plan, (list, tuple)):
+        return type(plan)(clone(v) for v in plan)
+    return plan
 
 
 def _walk(obj, fn):

@@ -123,20 +123,24 @@ class SetAbstraction(nn.Module):
                 self.sample_fn = random_sample
 
     @torch.no_grad()
+    def plan_sample(self, p):
+        """FPS picks and the sub-sampled cloud (the serial part of the geometry)"""
+        if self.is_head or self.all_aggr:
+            return {'fps_idx': None, 'new_p': p}
+        idx = self.sample_fn(p, p.shape[1] // self.stride).long()
+        return {'fps_idx': idx, 'new_p': torch.gather(p, 1, idx.unsqueeze(-1).expand(-1, -1, 3))}
+
+    @torch.no_grad()
+    def plan_group(self, p, g):
+        """neighbour indices and relative positions around the sampled points (in place into g)"""
+        if not self.is_head and hasattr(self.grouper, 'query'):
+            g['idx'] = self.grouper.query(g['new_p'], p)
+            g['dp'] = self.grouper.relative_positions(g['idx'], g['new_p'], p)
+        return g
+
     def plan(self, p):
         """coordinate-only part: FPS picks, the sub-sampled cloud, neighbour indices, relative positions"""
-        if self.is_head:
-            return {'new_p': p}
-        if not self.all_aggr:
-            idx = self.sample_fn(p, p.shape[1] // self.stride).long()
-            new_p = torch.gather(p, 1, idx.unsqueeze(-1).expand(-1, -1, 3))
-        else:
-            idx, new_p = None, p
-        g = {'fps_idx': idx, 'new_p': new_p}
-        if hasattr(self.grouper, 'query'):
-            g['idx'] = self.grouper.query(new_p, p)
-            g['dp'] = self.grouper.relative_positions(g['idx'], new_p, p)
-        return g
+        return self.plan_group(p, self.plan_sample(p))
 
     def forward(self, pf, geom=None):
         p, f = pf

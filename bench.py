@@ -128,71 +128,100 @@ def main():
         out["loss"] = criterion(logits, data["y"], stage, 13, None, aargs)
         out["loss"].backward()
 
-    # Software pipeline over consecutive batches: the coordinate-only half of a step (FPS chain, ball
-    # queries, 3-NN, loss k-NN / masks / ambiguities: amcontrast3d_amd/geometry.py) of batch k+1 runs on
-    # a side stream while batch k runs its feature half; the FPS chain alone keeps 8 of 256 CUs busy for
-    # ~14 ms.  Every step still does one full geometry pass and one full feature pass inside the timed
-    # region (the synthetic "next batch" is the same resident batch).
+    # Software pipeline over consecutive batches.  The coordinate-only half of a step
+    # (amcontrast3d_amd/geometry.py) does not depend on features or weights, so it runs ahead, on two side
+    # streams, while the current batch runs its feature half on the main stream:
+    #     stream A  sampling geometry of batch t+2 : FPS chain (one workgroup per cloud: 8 of 256 CUs for
+    #               ~14 ms), ball queries, relative positions, 3-NN
+    #     stream B  loss geometry of batch t+1     : k-NN, class votes, positive masks, ambiguities
+    #     main      features of batch t            : forward, loss, backward (+ all-reduce, clip, AdamW)
+    # Every step still does one full pass of each inside the timed region (the synthetic "next batches" are
+    # the same resident batch).  Each part is its own hipGraph on its own stream: on ROCm 7.2 separate
+    # graphs on separate streams overlap, whereas branches inside ONE captured graph are serialised with
+    # heavy per-node overhead (scratch/graph_conc.py: 1.6 ms vs 4.8 ms for three 0.95 ms chains).
     from amcontrast3d_amd import geometry
     overlap = not args.no_overlap and not use_ddp
-    side = torch.cuda.Stream()
-    keep = []
+    main_s = torch.cuda.Stream()  # all work of this process runs on non-default streams (capture recipe)
+    main_s.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(main_s)
+    s_a, s_b = torch.cuda.Stream(), torch.cuda.Stream()
+    head = criterion.contrast_head
 
-    def make_plan():
-        return geometry.precompute(model, criterion.contrast_head, data, 13, None, aargs)
+    def geo_sampling():
+        return geometry.precompute_sampling(model, data)
 
-    def pipelined():
-        cur = torch.cuda.current_stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            nxt = make_plan()
-        fwd_bwd()
-        cur.wait_stream(side)
-        geometry.copy_into(data["_geometry"], nxt)
-        keep.append(nxt)
-        del keep[:-2]
+    def geo_loss(plan):
+        return geometry.precompute_loss(head, plan, data["y"], 13, None, aargs)
 
     if overlap:
-        data["_geometry"] = make_plan()
+        a_out = geo_sampling()                 # written by stream A (batch t+2)
+        a_stable = geometry.clone(a_out)       # batch t+1: read by stream B
+        b_out = geo_loss(a_stable)             # written by stream B (batch t+1)
+        cur = geometry.clone({"encoder": a_stable["encoder"], "decoder": a_stable["decoder"], "loss": b_out})
+        data["_geometry"] = cur                # batch t: read by the feature half
         torch.cuda.synchronize()
-    work = pipelined if overlap else fwd_bwd
+
+    def rotate():  # main stream, between steps: advance the pipeline buffers by one batch
+        geometry.copy_into({"encoder": cur["encoder"], "decoder": cur["decoder"]}, a_stable)
+        geometry.copy_into(cur["loss"], b_out)
+        geometry.copy_into(a_stable, a_out)
+
+    def body_a():
+        geometry.copy_into(a_out, geo_sampling())
+
+    def body_b():
+        geometry.copy_into(b_out, geo_loss(a_stable))
 
     def update():
         torch.nn.utils.clip_grad_norm_(params, 10, norm_type=2)
         opt.step()
 
-    def eager_step():
-        opt.zero_grad(set_to_none=True)
-        work()
+    def run_step(f_rotate, f_a, f_b, f_feat, f_update):
+        if overlap:
+            main_s.wait_stream(s_a)
+            main_s.wait_stream(s_b)
+            f_rotate()
+            s_a.wait_stream(main_s)
+            s_b.wait_stream(main_s)
+            with torch.cuda.stream(s_a):
+                f_a()
+            with torch.cuda.stream(s_b):
+                f_b()
+        f_feat()
         if world > 1 and not use_ddp:
             adist.allreduce_gradients(params)
-        update()
+        f_update()
+
+    def eager_step():
+        opt.zero_grad(set_to_none=True)
+        run_step(rotate, body_a, body_b, fwd_bwd, update)
 
     step = eager_step
     if use_graph:
-        # Whole-step hipGraph capture (PyTorch's whole-network recipe): warm up on a side stream,
-        # then capture forward + loss + backward as one graph and clip + AdamW as a second one; the
-        # only work between them is the RCCL gradient all-reduce (N > 1).  ~700 launches per step
-        # become two graph launches.
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                eager_step()
-        torch.cuda.current_stream().wait_stream(side)
+        # PyTorch's whole-network capture recipe, one graph per pipeline part: ~700 launches per step
+        # become 5 graph launches
+        for _ in range(3):
+            eager_step()
         torch.cuda.synchronize()
         opt.zero_grad(set_to_none=True)
-        g_fb, g_up = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_fb):
-            work()
-        with torch.cuda.graph(g_up, pool=g_fb.pool()):
+        graphs = {k: torch.cuda.CUDAGraph() for k in ("rotate", "a", "b", "feat", "update")}
+        cap = torch.cuda.Stream()
+        with torch.cuda.graph(graphs["feat"], stream=cap):
+            fwd_bwd()
+        with torch.cuda.graph(graphs["update"], stream=cap):
             update()
+        if overlap:
+            with torch.cuda.graph(graphs["rotate"], stream=cap):
+                rotate()
+            with torch.cuda.graph(graphs["a"], stream=cap):
+                body_a()
+            with torch.cuda.graph(graphs["b"], stream=cap):
+                body_b()
+        torch.cuda.synchronize()
 
         def step():
-            g_fb.replay()
-            if world > 1:
-                adist.allreduce_gradients(params)
-            g_up.replay()
+            run_step(graphs["rotate"].replay, graphs["a"].replay, graphs["b"].replay, graphs["feat"].replay,
+                     graphs["update"].replay)
 
     for _ in range(args.warmup):
         step()
@@ -209,11 +238,26 @@ def main():
     dt = adist.max_over_ranks(dt, dev)
     final_loss = float(out["loss"].detach())
 
+    parts = None
+    if use_graph and overlap and rank == 0:
+        # each pipeline part alone (back-to-back replays on its stream): what the overlap has to hide
+        def alone(fn, stream, reps=5):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            with torch.cuda.stream(stream):
+                for _ in range(reps):
+                    fn()
+            torch.cuda.synchronize()
+            return round((time.perf_counter() - t) / reps * 1e3, 3)
+        parts = {"features_ms": alone(graphs["feat"].replay, main_s), "update_ms": alone(graphs["update"].replay, main_s),
+                 "sampling_geometry_ms": alone(graphs["a"].replay, s_a), "loss_geometry_ms": alone(graphs["b"].replay, s_b),
+                 "rotate_ms": alone(graphs["rotate"].replay, main_s)}
+
     # per-operator HIP-event timing: the same step, launched eagerly so each C-ABI launch can be
     # bracketed by events on its stream (events cannot bracket nodes inside a graph replay)
     ksteps = min(args.steps, 3)
-    data.pop("_geometry", None)
-    work = fwd_bwd  # geometry inline on the main stream: events then bracket one launch each
+    data.pop("_geometry", None)  # geometry inline on the main stream: events then bracket one launch each
+    overlap_was, overlap = overlap, False
     timing.enable(True)
     for _ in range(ksteps):
         eager_step()
@@ -247,13 +291,14 @@ def main():
                        "global_batch": args.batch * world, "points": args.points,
                        "parallelism": f"dp{world}" + ("+syncbn+ddp" if use_ddp else ""),
                        "launch": "hipGraph replay (fwd+loss+bwd | clip+AdamW)" if use_graph else "eager",
-                       "pipeline": "geometry of batch k+1 on a side stream under the features of batch k"
-                                   if overlap else "none"},
+                       "pipeline": "3 streams: sampling geometry (t+2) | loss geometry (t+1) | features (t)"
+                                   if overlap_was else "none"},
             "loss": round(final_loss, 6),
             "roofline": roofline,
             "kernels": {k: {"ms_per_step": round(v["total_ms"] / args.steps, 4),
                             "launches_per_step": v["launches"] / args.steps} for k, v in kernels.items()},
             "native_ms_per_step": round(sum(v["total_ms"] for v in kernels.values()) / args.steps, 3),
+            "pipeline_parts_alone": parts,
         }
         if world == 1 and not args.no_cpu_baseline:
             b = args.cpu_baseline_batch or args.batch

@@ -156,7 +156,7 @@ def test_precomputed_geometry_is_the_same_computation():
         assert torch.equal(logits0, logits1)
         assert float(loss0) == float(loss1)
         # static-buffer refresh used under graph replay
-        plan2 = geometry.precompute(model, criterion.contrast_head, data, 13, None, aa)
+        plan2 = geometry.precompute(model, criterion.contrast_head, data, 13, None, aa, aux_stream=torch.cuda.Stream())
         geometry.copy_into(plan, plan2)
         logits2, _ = model(d2)
         assert torch.equal(logits0, logits2)
