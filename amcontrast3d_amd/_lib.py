@@ -59,6 +59,10 @@ def load():
         raise ImportError(
             f"{_SO} not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` or `make -C {_CSRC}`); there is no CPU fallback")
+    # PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64; import it first so this library binds
+    # to the SAME runtime instance (loading /opt/rocm's copy first leaves two HIP runtimes in one process
+    # and the kernels here then see "no ROCm-capable device")
+    import torch  # noqa: F401
     lib = ctypes.CDLL(_SO)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

@@ -121,6 +121,79 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_exact_kernel(
 }
 
 
+// One WORKGROUP per listed query (the grid path's tie fallback: a handful of queries per call, each of
+// which must see its whole segment in index order).  All 1024 threads test one candidate each per step;
+// the heap only changes on the rare steps where some candidate beats the current root (a conservative
+// test against the root at the start of the step: the root only decreases), and only then wave 0 replays
+// those candidates in ascending index order against the heap in LDS.
+__global__ __launch_bounds__(1024) void knn_exact_list_kernel(
+    int nsample, int nbatch, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const int *__restrict__ offset, const int *__restrict__ new_offset, int *__restrict__ idx,
+    float *__restrict__ dist2, const int *__restrict__ qlist, const int *__restrict__ qcount)
+{
+    __shared__ float hd[KNN_MAXK];
+    __shared__ int hi[KNN_MAXK];
+    __shared__ float s_d2[1024];
+    __shared__ unsigned long long s_mask[16];
+    __shared__ float s_root;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int total = *qcount;
+    for (int qi = blockIdx.x; qi < total; qi += gridDim.x) {
+        const int pt = qlist[qi];
+        int bt = 0;
+        while (bt < nbatch - 1 && !(pt < new_offset[bt])) bt++;
+        const int start = bt == 0 ? 0 : offset[bt - 1], end = offset[bt];
+        const float qx = new_xyz[(size_t)pt * 3], qy = new_xyz[(size_t)pt * 3 + 1], qz = new_xyz[(size_t)pt * 3 + 2];
+        __syncthreads();
+        for (int i = threadIdx.x; i < nsample; i += 1024) { hd[i] = 1e10f; hi[i] = start; }
+        if (threadIdx.x == 0) s_root = 1e10f;
+        __syncthreads();
+        for (int i0 = start; i0 < end; i0 += 1024) {
+            const int i = i0 + threadIdx.x;
+            const bool valid = i < end;
+            const int ii = valid ? i : start;
+            const float d2 = dist2_ref(qx, qy, qz, xyz[(size_t)ii * 3], xyz[(size_t)ii * 3 + 1], xyz[(size_t)ii * 3 + 2]);
+            const bool pass = valid && d2 < s_root;
+            if (__syncthreads_or(pass)) {
+                s_d2[threadIdx.x] = d2;
+                const unsigned long long m = __ballot(pass);
+                if (lane == 0) s_mask[wave] = m;
+                __syncthreads();
+                if (wave == 0) {  // ascending index order: wave by wave, bit by bit
+                    float root = s_root;
+                    for (int w = 0; w < 16; ++w) {
+                        unsigned long long mm = s_mask[w];
+                        while (mm) {
+                            const int b = (int)__builtin_ctzll(mm);
+                            mm &= mm - 1;
+                            const float cd = s_d2[w * 64 + b];
+                            if (cd < root) {  // knnquery_cuda_kernel.cu:97-101
+                                hd[0] = cd;
+                                hi[0] = i0 + w * 64 + b;
+                                reheap(hd, hi, nsample);
+                                root = hd[0];
+                            }
+                        }
+                    }
+                    if (lane == 0) s_root = root;
+                }
+                __syncthreads();
+            }
+        }
+        if (wave == 0) {
+            for (int i = nsample - 1; i > 0; i--) {  // knnquery_cuda_kernel.cu:39-48
+                const float tf = hd[0]; hd[0] = hd[i]; hd[i] = tf;
+                const int ti = hi[0]; hi[0] = hi[i]; hi[i] = ti;
+                reheap(hd, hi, i);
+            }
+            for (int i = lane; i < nsample; i += 64) {
+                idx[(size_t)pt * nsample + i] = hi[i];
+                dist2[(size_t)pt * nsample + i] = hd[i];
+            }
+        }
+    }
+}
+
 // =============================================================================================
 // Grid-accelerated path (k <= 64).
 //
@@ -139,10 +212,11 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_exact_kernel(
 // rejected distance equal to the k-th) and recomputed by knn_exact_kernel, which replays the
 // reference's heap.  Distances are always the reference's expression (dist2_ref).
 //
-// Cell size.  h is calibrated on the data, per call: 64 sample queries get their exact k-th
-// neighbour distance by brute force (one workgroup each), and h = 1.05 * the 80th percentile, so
-// that ~4 of 5 queries finish after the 3x3x3 block whatever the density or dimensionality of the
-// cloud (surfaces, volumes, 8 overlapping clouds in one segment...).
+// Cell size.  h is calibrated on the data, per call: 64 sample queries get an estimate of their k-th
+// neighbour distance from a brute-force scan of every 8th support point (one workgroup each), and
+// h = 1.1 * the 80th percentile, so that most queries finish after the 3x3x3 block whatever the
+// density or dimensionality of the cloud (surfaces, volumes, 8 overlapping clouds in one segment...).
+// h steers speed only; any h gives the same results.
 // =============================================================================================
 constexpr int KG_SAMPLES = 64;
 constexpr int KG_MAXK = 64;
@@ -282,7 +356,10 @@ __device__ __forceinline__ void ll_feed(LaneList &l, int k, int lane, bool valid
     }
 }
 
-// ---- calibration: exact k-th neighbour distance of KG_SAMPLES queries -----------------------------
+// ---- calibration: k-th neighbour distance of KG_SAMPLES queries, estimated on every 8th support point
+// (the (k/8)-th neighbour among 1/8 of the points sits at about the same radius; h only steers speed,
+// never results, so an estimate is enough) -----------------------------------------------------------
+constexpr int KG_SUB = 8;
 __global__ __launch_bounds__(1024) void kg_sample_kernel(int m, int k, int nb, const float *__restrict__ xyz,
                                                          const float *__restrict__ new_xyz,
                                                          const int *__restrict__ offset,
@@ -297,14 +374,15 @@ __global__ __launch_bounds__(1024) void kg_sample_kernel(int m, int k, int nb, c
     LaneList l;
     ll_init(l, start);
     float rl = 3.4e38f, ru = 3.4e38f;
-    const int span = (end - start + 15) / 16;
-    const int lo = start + wave * span, hi = min(end, lo + span);
+    const int nsub = (end - start + KG_SUB - 1) / KG_SUB;  // sub-sampled points start, start+8, ...
+    const int span = (nsub + 15) / 16;
+    const int lo = wave * span, hi = min(nsub, lo + span);
     for (int i0 = lo; i0 < hi; i0 += 64) {
         const int i = i0 + lane;
         const bool valid = i < hi;
-        const int ii = valid ? i : lo;
+        const int ii = start + (valid ? i : lo) * KG_SUB;
         const float d2 = dist2_ref(qx, qy, qz, xyz[(size_t)ii * 3], xyz[(size_t)ii * 3 + 1], xyz[(size_t)ii * 3 + 2]);
-        ll_feed(l, k, lane, valid, d2, i, rl, ru);
+        ll_feed(l, k, lane, valid, d2, ii, rl, ru);
     }
     if (lane < k) vals[wave * k + lane] = l.v;
     __syncthreads();
@@ -338,7 +416,7 @@ __global__ __launch_bounds__(64) void kg_params_kernel(int n, int nb, const int 
     const float ex = fmaxf(ord2f(bbox[3]) - minx, 0.f), ey = fmaxf(ord2f(bbox[4]) - miny, 0.f),
                 ez = fmaxf(ord2f(bbox[5]) - minz, 0.f);
     const float emax = fmaxf(fmaxf(ex, ey), fmaxf(ez, 1e-30f));
-    float h = 1.05f * sqrtf(r2);
+    float h = 1.1f * sqrtf(r2);
     if (!(r2 < 1e9f) || !(h > emax * 1e-6f)) h = emax;  // fewer than k points, or all points coincide
     const float cap = (float)(knn_cell_cap(n) / (nb > 0 ? nb : 1));
     // grow h until the grid fits the cell budget (float arithmetic: no int overflow on huge extents)
@@ -608,8 +686,8 @@ AMC_API int amc3d_knnquery(int m, int nsample, int n, int nbatch, const float *x
     if (int st = fill_i32(cursor, 0, cells, stream)) return st;
     hipLaunchKernelGGL(kg_init_kernel, dim3(1), dim3(64), 0, stream, bbox, fb_count);
     hipLaunchKernelGGL(kg_bbox_kernel, dim3(min(div_up(n, 256), 64)), dim3(256), 0, stream, n, xyz, bbox);
-    hipLaunchKernelGGL(kg_sample_kernel, dim3(KG_SAMPLES), dim3(1024), 0, stream, m, nsample, nbatch, xyz, new_xyz,
-                       offset, new_offset, samples);
+    hipLaunchKernelGGL(kg_sample_kernel, dim3(KG_SAMPLES), dim3(1024), 0, stream, m, (nsample + KG_SUB - 1) / KG_SUB + 1,
+                       nbatch, xyz, new_xyz, offset, new_offset, samples);
     hipLaunchKernelGGL(kg_params_kernel, dim3(1), dim3(64), 0, stream, n, nbatch, bbox, samples, gp);
     hipLaunchKernelGGL(kg_count_kernel, dim3(div_up(n, 256)), dim3(256), 0, stream, n, nbatch, xyz, offset, gp,
                        cell_start);
@@ -624,8 +702,7 @@ AMC_API int amc3d_knnquery(int m, int nsample, int n, int nbatch, const float *x
     hipLaunchKernelGGL(kg_query_kernel, dim3(min(div_up(m, 4), 256 * 32)), dim3(256), 0, stream, m, nsample, nbatch,
                        new_xyz, offset, new_offset, gp, cell_start, sorted, idx, dist2, fb_list, fb_count);
     // queries with equal distances among their k+1 nearest: replay the reference's heap
-    hipLaunchKernelGGL(knn_exact_kernel, dim3(min(exact_blocks, 512)), dim3(KNN_WAVES * 64), 0, stream, m, nsample,
-                       nbatch, xyz, new_xyz, offset, new_offset, idx, dist2, (const int *)fb_list,
-                       (const int *)fb_count);
+    hipLaunchKernelGGL(knn_exact_list_kernel, dim3(256), dim3(1024), 0, stream, nsample, nbatch, xyz, new_xyz, offset,
+                       new_offset, idx, dist2, (const int *)fb_list, (const int *)fb_count);
     return launch_status("amc3d_knnquery");
 }
