@@ -10,7 +10,7 @@ import subprocess
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _SO = os.environ.get("AMC3D_LIB") or os.path.join(_CSRC, "libamc3d_hip.so")  # AMC3D_LIB: diagnostic builds
 
-_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_vp, _i, _f, _sz, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_long
 
 # name -> (restype, argtypes); must list every symbol include/amc3d.h declares
 SIGNATURES = {
@@ -35,6 +35,11 @@ SIGNATURES = {
     "amc3d_ambiguity": (_i, [_i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_contrast_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_contrast_backward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_bn_workspace_bytes": (_sz, [_i]),
+    "amc3d_bn_stats": (_i, [_i, _i, _l, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "amc3d_bn_act": (_i, [_i, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_bn_max": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_bn_backward": (_i, [_i, _i, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 

@@ -1,0 +1,316 @@
+// Training-mode BatchNorm fused with what follows it in the PointNeXt blocks, for gfx950.
+//
+// The reference runs every 1x1-conv block as separate layers (models/layers/conv.py:24-102:
+// nn.Conv -> nn.BatchNorm -> nn.ReLU(inplace)) and the set-abstraction blocks follow the last one by
+// torch.max over the 32 neighbours (pointnext_AA.py:166): per block that is 5 passes over the
+// (B,C,M,32) activation forward and 7 backward.  The arithmetic is HBM-bound, so the kernels here fuse
+// passes, not math:
+//     forward   bn_stats  (1 read)  ->  bn_act: y = relu(bn(x)) (1 read, 1 write)
+//                                   or  bn_max: y = max_k bn(x) (1 read, a (B,C,M) write + arg-max byte)
+//     backward  *_bwd_stats (1 read) -> *_bwd_apply (1-2 reads, 1 write); the max variant never
+//               materialises the sparse gradient of the pooled tensor.
+// Layout is the reference's channel-major (B, C, L), L = M*K contiguous; statistics are over (B, L) per
+// channel, accumulated in fp64 (sums of up to 1.5M fp32 values), normalisation as PyTorch writes it:
+// ((x - mean) * invstd) * gamma + beta with the biased variance (torch.nn.BatchNorm semantics).
+#include "common.h"
+
+namespace amc {
+
+constexpr int BN_THREADS = 256;
+
+__device__ __forceinline__ double block_sum_f64(double v, double *s_buf)
+{
+    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_buf[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < BN_THREADS / 64; ++w) t += s_buf[w];
+    __syncthreads();
+    return t;
+}
+
+// partial[c][chunk] = {sum, sumsq} over the chunk's share of (b, l); grid (chunks, C)
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(int B, int C, long L, const float *__restrict__ x,
+                                                              double *__restrict__ partial)
+{
+    __shared__ double s_buf[BN_THREADS / 64];
+    const int c = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    double s1 = 0.0, s2 = 0.0;
+    const long total = (long)B * L;  // positions of this channel, enumerated as b * L + l
+    const long per = (total + nchunks - 1) / nchunks;
+    const long lo = chunk * per, hi = min(total, lo + per);
+    for (long i = lo + threadIdx.x; i < hi; i += BN_THREADS) {
+        const long b = i / L, l = i - b * L;
+        const float v = x[((size_t)b * C + c) * L + l];
+        s1 += (double)v;
+        s2 += (double)v * (double)v;
+    }
+    s1 = block_sum_f64(s1, s_buf);
+    s2 = block_sum_f64(s2, s_buf);
+    if (threadIdx.x == 0) {
+        partial[((size_t)c * nchunks + chunk) * 2 + 0] = s1;
+        partial[((size_t)c * nchunks + chunk) * 2 + 1] = s2;
+    }
+}
+
+// mean, biased var -> invstd; also the unbiased variance for the running estimate
+__global__ void bn_finalize_kernel(int C, int nchunks, double count, float eps, const double *__restrict__ partial,
+                                   float *__restrict__ mean, float *__restrict__ invstd, float *__restrict__ var_unbiased)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nchunks; ++k) {
+        s1 += partial[((size_t)c * nchunks + k) * 2 + 0];
+        s2 += partial[((size_t)c * nchunks + k) * 2 + 1];
+    }
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    var_unbiased[c] = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+}
+
+__device__ __forceinline__ float bn_val(float x, float mean, float invstd, float gamma, float beta)
+{
+    return __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(x, mean), invstd), gamma), beta);
+}
+
+// y = [relu](bn(x)), elementwise over (B, C, L); 4 elements per thread when L % 4 == 0
+__global__ __launch_bounds__(BN_THREADS) void bn_act_kernel(int C, long L, int relu, const float *__restrict__ x,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, float *__restrict__ y)
+{
+    const int bc = blockIdx.y;  // b * C + c
+    const int c = bc % C;
+    const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
+    const float *xr = x + (size_t)bc * L;
+    float *yr = y + (size_t)bc * L;
+    if ((L & 3) == 0) {
+        for (long i = ((long)blockIdx.x * BN_THREADS + threadIdx.x) * 4; i < L; i += (long)gridDim.x * BN_THREADS * 4) {
+            float4 v = *reinterpret_cast<const float4 *>(xr + i);
+            v.x = bn_val(v.x, m, is, g, bt); v.y = bn_val(v.y, m, is, g, bt);
+            v.z = bn_val(v.z, m, is, g, bt); v.w = bn_val(v.w, m, is, g, bt);
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4 *>(yr + i) = v;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < L; i += (long)gridDim.x * BN_THREADS) {
+            float v = bn_val(xr[i], m, is, g, bt);
+            yr[i] = relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
+// y[b,c,m] = max_k [relu](bn(x[b,c,m,k])), arg[b,c,m] = first k attaining it (torch.max returns the first)
+__global__ __launch_bounds__(BN_THREADS) void bn_max_kernel(int C, int M, int K, int relu, const float *__restrict__ x,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, float *__restrict__ y,
+                                                            unsigned char *__restrict__ arg)
+{
+    const int bc = blockIdx.y;
+    const int c = bc % C;
+    const int mi = blockIdx.x * BN_THREADS + threadIdx.x;
+    if (mi >= M) return;
+    const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
+    const float *xr = x + ((size_t)bc * M + mi) * K;
+    float best = -__builtin_inff();
+    int bk = 0;
+    if ((K & 3) == 0) {
+        for (int k = 0; k < K; k += 4) {
+            const float4 v4 = *reinterpret_cast<const float4 *>(xr + k);
+            const float vs[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = bn_val(vs[j], m, is, g, bt);
+                if (relu) v = fmaxf(v, 0.f);
+                if (v > best) { best = v; bk = k + j; }
+            }
+        }
+    } else {
+        for (int k = 0; k < K; ++k) {
+            float v = bn_val(xr[k], m, is, g, bt);
+            if (relu) v = fmaxf(v, 0.f);
+            if (v > best) { best = v; bk = k; }
+        }
+    }
+    y[(size_t)bc * M + mi] = best;
+    arg[(size_t)bc * M + mi] = (unsigned char)bk;
+}
+
+// ---- backward statistics: per channel  Sa = sum dq,  Sb = sum dq * xhat  (dq = upstream gradient w.r.t. the
+// BN output, after the ReLU mask resp. routed through the arg-max).  partial layout as in bn_stats.
+// mode 0: act.  dq = dy * (relu ? bn(x) > 0 : 1) over (B, C, L)
+// mode 1: max.  dq is nonzero only at the arg-max: dq = g[b,c,m] * (relu ? y > 0 : 1), xhat at the arg-max
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_kernel(
+    int mode, int B, int C, long L, int K, int relu, const float *__restrict__ x, const float *__restrict__ dy,
+    const unsigned char *__restrict__ arg, const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ gamma, const float *__restrict__ beta, double *__restrict__ partial)
+{
+    __shared__ double s_buf[BN_THREADS / 64];
+    const int c = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
+    double sa = 0.0, sb = 0.0;
+    const long Lq = mode == 0 ? L : L / K;  // positions carrying a gradient per (b, c)
+    const long total = (long)B * Lq;
+    const long per = (total + nchunks - 1) / nchunks;
+    const long lo = chunk * per, hi = min(total, lo + per);
+    for (long i = lo + threadIdx.x; i < hi; i += BN_THREADS) {
+        const long b = i / Lq, l = i - b * Lq;
+        const size_t q = ((size_t)b * C + c) * Lq + l;
+        float d = dy[q];
+        const float xv = mode == 0 ? x[q] : x[q * K + arg[q]];
+        const float xh = __fmul_rn(__fsub_rn(xv, m), is);
+        if (relu && !(__fadd_rn(__fmul_rn(xh, g), bt) > 0.f)) d = 0.f;
+        sa += (double)d;
+        sb += (double)d * (double)xh;
+    }
+    sa = block_sum_f64(sa, s_buf);
+    sb = block_sum_f64(sb, s_buf);
+    if (threadIdx.x == 0) {
+        partial[((size_t)c * nchunks + chunk) * 2 + 0] = sa;
+        partial[((size_t)c * nchunks + chunk) * 2 + 1] = sb;
+    }
+}
+
+// dgamma = Sb, dbeta = Sa, and the two per-channel coefficients of the dense term
+__global__ void bn_bwd_finalize_kernel(int C, int nchunks, double count, const double *__restrict__ partial,
+                                       float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                       float *__restrict__ mean_dq, float *__restrict__ mean_dq_xhat)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double sa = 0.0, sb = 0.0;
+    for (int k = 0; k < nchunks; ++k) {
+        sa += partial[((size_t)c * nchunks + k) * 2 + 0];
+        sb += partial[((size_t)c * nchunks + k) * 2 + 1];
+    }
+    dbeta[c] = (float)sa;
+    dgamma[c] = (float)sb;
+    mean_dq[c] = (float)(sa / count);
+    mean_dq_xhat[c] = (float)(sb / count);
+}
+
+// dx = gamma * invstd * (dq - mean(dq) - xhat * mean(dq * xhat))   (training-mode BN backward)
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
+    int mode, int C, long L, int K, int relu, const float *__restrict__ x, const float *__restrict__ dy,
+    const unsigned char *__restrict__ arg, const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ mean_dq,
+    const float *__restrict__ mean_dq_xhat, float *__restrict__ dx)
+{
+    const int bc = blockIdx.y;
+    const int c = bc % C;
+    const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
+    const float ma = mean_dq[c], mb = mean_dq_xhat[c], gi = __fmul_rn(g, is);
+    const float *xr = x + (size_t)bc * L;
+    float *dr = dx + (size_t)bc * L;
+    for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < L; i += (long)gridDim.x * BN_THREADS) {
+        const float xh = __fmul_rn(__fsub_rn(xr[i], m), is);
+        float d;
+        if (mode == 0) {
+            d = dy[(size_t)bc * L + i];
+            if (relu && !(__fadd_rn(__fmul_rn(xh, g), bt) > 0.f)) d = 0.f;
+        } else {
+            const long q = i / K;
+            const int k = (int)(i - q * K);
+            const size_t qq = (size_t)bc * (L / K) + q;
+            d = k == (int)arg[qq] ? dy[qq] : 0.f;
+            if (relu && !(__fadd_rn(__fmul_rn(xh, g), bt) > 0.f)) d = 0.f;
+        }
+        dr[i] = gi * (d - ma - xh * mb);
+    }
+}
+
+constexpr int BN_MAX_CHUNKS = 64;
+
+}  // namespace amc
+
+using namespace amc;
+
+AMC_API size_t amc3d_bn_workspace_bytes(int C) { return (size_t)C * BN_MAX_CHUNKS * 2 * sizeof(double); }
+
+static int bn_chunks(int B, int C, long L)
+{
+    // enough workgroups to fill the chip (>= ~1024) without making the per-channel tail pass long
+    long want = (1024 + C - 1) / C;
+    const long cap = ((long)B * L + 4095) / 4096;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    if (want > BN_MAX_CHUNKS) want = BN_MAX_CHUNKS;
+    return (int)want;
+}
+
+// statistics of x (B, C, L): mean, invstd = 1/sqrt(var_biased + eps), var_unbiased (for running_var)
+AMC_API int amc3d_bn_stats(int B, int C, long L, float eps, const float *x, float *mean, float *invstd,
+                           float *var_unbiased, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    if (B <= 0 || C <= 0 || L <= 0) return 0;
+    if (!x || !mean || !invstd || !var_unbiased || !workspace || workspace_bytes < amc3d_bn_workspace_bytes(C))
+        return bad_arg("amc3d_bn_stats: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int nchunks = bn_chunks(B, C, L);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nchunks, C), dim3(BN_THREADS), 0, stream, B, C, L, x, (double *)workspace);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(div_up(C, 64)), dim3(64), 0, stream, C, nchunks, (double)B * (double)L,
+                       eps, (const double *)workspace, mean, invstd, var_unbiased);
+    return launch_status("amc3d_bn_stats");
+}
+
+// y = [relu](bn(x)) over (B, C, L)
+AMC_API int amc3d_bn_act(int B, int C, long L, int relu, const float *x, const float *mean, const float *invstd,
+                         const float *gamma, const float *beta, float *y, void *stream)
+{
+    if (B <= 0 || C <= 0 || L <= 0) return 0;
+    if (!x || !mean || !invstd || !gamma || !beta || !y) return bad_arg("amc3d_bn_act: null pointer");
+    const long per_block = BN_THREADS * 4 * 4;
+    const int gx = (int)min((L + per_block - 1) / per_block, (long)4096);
+    hipLaunchKernelGGL(bn_act_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, (hipStream_t)stream, C, L, relu, x, mean,
+                       invstd, gamma, beta, y);
+    return launch_status("amc3d_bn_act");
+}
+
+// y (B, C, M) = max over the K neighbours of [relu](bn(x (B, C, M, K))); arg (B, C, M) bytes, K <= 255
+AMC_API int amc3d_bn_max(int B, int C, int M, int K, int relu, const float *x, const float *mean, const float *invstd,
+                         const float *gamma, const float *beta, float *y, unsigned char *arg, void *stream)
+{
+    if (B <= 0 || C <= 0 || M <= 0) return 0;
+    if (K <= 0 || K > 255 || !x || !mean || !invstd || !gamma || !beta || !y || !arg)
+        return bad_arg("amc3d_bn_max: bad argument (K must be in 1..255)");
+    hipLaunchKernelGGL(bn_max_kernel, dim3(div_up(M, BN_THREADS), B * C), dim3(BN_THREADS), 0, (hipStream_t)stream, C, M,
+                       K, relu, x, mean, invstd, gamma, beta, y, arg);
+    return launch_status("amc3d_bn_max");
+}
+
+// Backward of y = [relu](bn(x)) (arg == NULL, K = 1, dy (B,C,L)) or of y = max_K [relu](bn(x)) (arg given,
+// dy (B,C,L/K)): dx (B,C,L), dgamma (C), dbeta (C).  Training-mode BN (batch statistics).
+AMC_API int amc3d_bn_backward(int B, int C, long L, int K, int relu, const float *x, const float *dy,
+                              const unsigned char *arg, const float *mean, const float *invstd, const float *gamma,
+                              const float *beta, float *dx, float *dgamma, float *dbeta, void *workspace,
+                              size_t workspace_bytes, void *stream_)
+{
+    if (B <= 0 || C <= 0 || L <= 0) return 0;
+    const size_t need = amc3d_bn_workspace_bytes(C) + (size_t)C * 2 * sizeof(float);
+    if (!x || !dy || !mean || !invstd || !gamma || !beta || !dx || !dgamma || !dbeta || !workspace ||
+        workspace_bytes < need || K <= 0 || (arg && L % K != 0))
+        return bad_arg("amc3d_bn_backward: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int mode = arg ? 1 : 0;
+    const int nchunks = bn_chunks(B, C, mode ? L / K : L);
+    double *partial = (double *)workspace;
+    float *mean_dq = (float *)((char *)workspace + amc3d_bn_workspace_bytes(C));
+    float *mean_dqx = mean_dq + C;
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nchunks, C), dim3(BN_THREADS), 0, stream, mode, B, C, L, K, relu, x, dy,
+                       arg, mean, invstd, gamma, beta, partial);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(div_up(C, 64)), dim3(64), 0, stream, C, nchunks,
+                       (double)B * (double)L, (const double *)partial, dgamma, dbeta, mean_dq, mean_dqx);
+    const long per_block = BN_THREADS * 8;
+    const int gx = (int)min((L + per_block - 1) / per_block, (long)4096);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, stream, mode, C, L, K, relu, x, dy, arg,
+                       mean, invstd, gamma, beta, mean_dq, mean_dqx, dx);
+    return launch_status("amc3d_bn_backward");
+}

@@ -29,7 +29,8 @@ import torch.nn as nn
 
 from ..build import MODELS
 from ..layers import (CHANNEL_MAP, create_act, create_convblock1d, create_convblock2d, create_grouper,
-                      furthest_point_sample, get_aggregation_feautres, random_sample, three_interpolate, three_nn)
+                      furthest_point_sample, get_aggregation_feautres, random_sample, run_convblocks,
+                      three_interpolate, three_nn)
 
 
 def get_reduction_fn(reduction):
@@ -76,7 +77,9 @@ class LocalAggregation(nn.Module):
             geom = self.plan(p)
         dp, fj = self.grouper(p, p, f, geom=geom)
         fj = get_aggregation_feautres(p, dp, f, fj, self.feature_type)
-        return self.pool(self.convs(fj))
+        if self.reduction == 'max':
+            return run_convblocks(self.convs, fj, pool_max=True)
+        return self.pool(run_convblocks(self.convs, fj))
 
 
 class SetAbstraction(nn.Module):
@@ -145,7 +148,7 @@ class SetAbstraction(nn.Module):
     def forward(self, pf, geom=None):
         p, f = pf
         if self.is_head:
-            return p, self.convs(f)
+            return p, run_convblocks(self.convs, f)
         if geom is None:
             geom = self.plan(p)
         idx, new_p = geom['fps_idx'], geom['new_p']
@@ -156,7 +159,7 @@ class SetAbstraction(nn.Module):
                 identity = self.skipconv(fi)
         dp, fj = self.grouper(new_p, p, f, geom=geom if 'idx' in geom else None)
         fj = get_aggregation_feautres(new_p, dp, fi, fj, feature_type=self.feature_type)
-        f = self.pool(self.convs(fj))
+        f = run_convblocks(self.convs, fj, pool_max=True)  # conv/BN/ReLU stack + max over the neighbours
         if self.use_res:
             f = self.act(f + identity)
         return new_p, f
@@ -200,7 +203,7 @@ class FeaturePropogation(nn.Module):
         if geom is None:
             geom = self.plan(p1, p2)
         up = three_interpolate(f2, geom['idx'], geom['weight'])
-        return self.convs(up if f1 is None else torch.cat((f1, up), dim=1))
+        return run_convblocks(self.convs, up if f1 is None else torch.cat((f1, up), dim=1))
 
 
 class InvResMLP(nn.Module):
@@ -234,7 +237,7 @@ class InvResMLP(nn.Module):
     def forward(self, pf, geom=None):
         p, f = pf
         identity = f
-        f = self.pwconv(self.convs([p, f], geom=geom))
+        f = run_convblocks(self.pwconv, self.convs([p, f], geom=geom))
         if f.shape[-1] == identity.shape[-1] and self.use_res:
             f += identity
         return [p, self.act(f)]

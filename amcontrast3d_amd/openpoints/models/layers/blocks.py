@@ -8,6 +8,7 @@ the conv has no bias when a norm follows it.
 """
 import copy
 
+import torch
 import torch.nn as nn
 
 
@@ -103,6 +104,62 @@ def create_convblock2d(*args, norm_args=None, act_args=None, order='conv-norm-ac
 
 def create_convblock1d(*args, norm_args=None, act_args=None, order='conv-norm-act', **kwargs):
     return _convblock(Conv1d, '1d', args, norm_args, act_args, order, kwargs)
+
+
+def _fusable_bn(bn, x):
+    """plain training-mode BatchNorm1d/2d on a contiguous fp32 GPU tensor (SyncBatchNorm, eval mode and
+    other norms take the ordinary torch modules)"""
+    return (type(bn) in (nn.BatchNorm1d, nn.BatchNorm2d) and bn.training and bn.affine and bn.track_running_stats
+            and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled())
+
+
+def _update_running(bn, mean, var_unbiased):
+    # nn.BatchNorm bookkeeping (torch/nn/modules/batchnorm.py): momentum None = cumulative average
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+        mom = bn.momentum
+        if mom is None:
+            bn.running_mean += (mean - bn.running_mean) / bn.num_batches_tracked
+            bn.running_var += (var_unbiased - bn.running_var) / bn.num_batches_tracked
+        else:
+            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(var_unbiased, alpha=mom)
+
+
+def run_convblocks(blocks, x, pool_max=False):
+    """Evaluate a stack of conv blocks (the nn.Sequential the factories above build), optionally followed by
+    the max over the last (neighbour) dimension.  Where a block is conv -> plain BatchNorm [-> ReLU] in
+    training mode, BatchNorm statistics, normalisation, ReLU and (for the last block) the max-pool run as
+    fused gfx950 kernels (amcontrast3d_amd/csrc/bn.hip); everything else runs the stored modules as they are.
+    Parameters, buffers and their bookkeeping stay those of the nn modules."""
+    from amcontrast3d_amd.ops import BatchNormAct, BatchNormMax
+    mods = list(blocks)
+    pooled = False
+    for bi, blk in enumerate(mods):
+        last = bi == len(mods) - 1
+        sub = list(blk) if isinstance(blk, nn.Sequential) else None
+        if (sub is not None and len(sub) in (2, 3) and isinstance(sub[0], (nn.Conv1d, nn.Conv2d))
+                and isinstance(sub[1], nn.modules.batchnorm._BatchNorm)
+                and (len(sub) == 2 or type(sub[2]) is nn.ReLU)):
+            y = sub[0](x)
+            bn = sub[1]
+            if _fusable_bn(bn, y):
+                relu = len(sub) == 3
+                if last and pool_max and y.dim() == 4 and y.shape[-1] <= 255:
+                    x, mean, var_u = BatchNormMax.apply(y, bn.weight, bn.bias, bn.eps, relu)
+                    pooled = True
+                else:
+                    x, mean, var_u = BatchNormAct.apply(y, bn.weight, bn.bias, bn.eps, relu)
+                _update_running(bn, mean, var_u)
+            else:
+                x = bn(y)
+                if len(sub) == 3:
+                    x = sub[2](x)
+        else:
+            x = blk(x)
+    if pool_max and not pooled:
+        x = torch.max(x, dim=-1, keepdim=False)[0]
+    return x
 
 
 # input width of the first grouped conv for each neighbourhood feature recipe

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from ..build import MODELS, build_model_from_cfg
-from ..layers import create_convblock1d
+from ..layers import create_convblock1d, run_convblocks
 
 
 @MODELS.register_module()
@@ -83,4 +83,4 @@ class SegHead(nn.Module):
                     g.append(torch.mean(end_points, dim=-1, keepdim=True))
             g = torch.cat(g, dim=1).expand(-1, -1, end_points.shape[-1])
             end_points = torch.cat((end_points, g), dim=1)
-        return self.head(end_points)
+        return run_convblocks(self.head, end_points)

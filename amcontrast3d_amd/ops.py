@@ -356,3 +356,99 @@ class ContrastStage(Function):
 
 
 contrast_stage = ContrastStage.apply
+
+
+# ----------------------------------------------------------------------------------------------
+# training-mode BatchNorm fused with ReLU / neighbourhood max-pool (csrc/bn.hip)
+# ----------------------------------------------------------------------------------------------
+def _bn_ws(C, dev, extra=0):
+    n = int(_lib.load().amc3d_bn_workspace_bytes(C)) + extra
+    return torch.empty(n, dtype=torch.uint8, device=dev), n
+
+
+class BatchNormAct(Function):
+    """y = [relu](batch_norm(x)) with batch statistics; x (B, C, *) contiguous fp32.
+    Returns (y, batch mean, unbiased batch variance)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu):
+        _need_gpu(x, gamma, beta)
+        x = x.contiguous()
+        B, C = x.shape[0], x.shape[1]
+        L = x.numel() // (B * C)
+        dev = x.device
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty_like(mean)
+        var_u = torch.empty_like(mean)
+        y = torch.empty_like(x)
+        work, wb = _bn_ws(C, dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev), timing.span("bn_act_forward", x.numel() * 12):
+            _lib.check(lib.amc3d_bn_stats(B, C, L, float(eps), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(var_u), _ptr(work),
+                                          wb, _stream(x)), "bn_stats")
+            _lib.check(lib.amc3d_bn_act(B, C, L, int(bool(relu)), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                        _ptr(beta), _ptr(y), _stream(x)), "bn_act")
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.relu = bool(relu)
+        ctx.mark_non_differentiable(mean, var_u)
+        return y, mean, var_u
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        B, C = x.shape[0], x.shape[1]
+        L = x.numel() // (B * C)
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        work, wb = _bn_ws(C, x.device, extra=C * 8)
+        with torch.cuda.device(x.device), timing.span("bn_act_backward", x.numel() * 16):
+            _lib.check(_lib.load().amc3d_bn_backward(B, C, L, 1, int(ctx.relu), _ptr(x), _ptr(dy), None, _ptr(mean),
+                                                     _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dx), _ptr(dgamma),
+                                                     _ptr(dbeta), _ptr(work), wb, _stream(x)), "bn_backward")
+        return dx, dgamma, dbeta, None, None
+
+
+class BatchNormMax(Function):
+    """y (B,C,M) = max over the K neighbours of [relu](batch_norm(x (B,C,M,K))) with batch statistics.
+    Returns (y, batch mean, unbiased batch variance); the (B,C,M,K) normalised tensor is never written."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu):
+        _need_gpu(x, gamma, beta)
+        x = x.contiguous()
+        B, C, M, K = x.shape
+        dev = x.device
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty_like(mean)
+        var_u = torch.empty_like(mean)
+        y = torch.empty(B, C, M, dtype=torch.float32, device=dev)
+        arg = torch.empty(B, C, M, dtype=torch.uint8, device=dev)
+        work, wb = _bn_ws(C, dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev), timing.span("bn_max_forward", x.numel() * 8 + y.numel() * 5):
+            _lib.check(lib.amc3d_bn_stats(B, C, M * K, float(eps), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(var_u),
+                                          _ptr(work), wb, _stream(x)), "bn_stats")
+            _lib.check(lib.amc3d_bn_max(B, C, M, K, int(bool(relu)), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                        _ptr(beta), _ptr(y), _ptr(arg), _stream(x)), "bn_max")
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, arg)
+        ctx.relu = bool(relu)
+        ctx.mark_non_differentiable(mean, var_u)
+        return y, mean, var_u
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, gamma, beta, mean, invstd, arg = ctx.saved_tensors
+        B, C, M, K = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        work, wb = _bn_ws(C, x.device, extra=C * 8)
+        with torch.cuda.device(x.device), timing.span("bn_max_backward", x.numel() * 8 + dy.numel() * 5):
+            _lib.check(_lib.load().amc3d_bn_backward(B, C, M * K, K, int(ctx.relu), _ptr(x), _ptr(dy), _ptr(arg),
+                                                     _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dx),
+                                                     _ptr(dgamma), _ptr(dbeta), _ptr(work), wb, _stream(x)),
+                       "bn_backward")
+        return dx, dgamma, dbeta, None, None

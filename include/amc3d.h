@@ -164,6 +164,31 @@ int amc3d_contrast_backward(int m, int C, int k, int nbr_stride, const float *f,
                             float temperature, const float *sim, const float *mean_cnt, const float *grad_out,
                             float *grad_f, void *stream);
 
+/* ---- training-mode BatchNorm fused with ReLU / neighbourhood max-pool ---------------------------
+ * The reference runs nn.Conv -> nn.BatchNorm -> nn.ReLU(inplace) [-> torch.max over the neighbours]
+ * as separate torch layers (openpoints/models/layers/conv.py:24-102, backbone/pointnext_AA.py:166).
+ * Tensors are the reference's channel-major (B, C, L); statistics per channel over (B, L). */
+size_t amc3d_bn_workspace_bytes(int C);  /* for amc3d_bn_stats; amc3d_bn_backward needs this + 8*C bytes */
+
+/* mean (C), invstd = 1/sqrt(biased var + eps) (C), var_unbiased (C, for the running estimate) */
+int amc3d_bn_stats(int B, int C, long L, float eps, const float *x, float *mean, float *invstd,
+                   float *var_unbiased, void *workspace, size_t workspace_bytes, void *stream);
+
+/* y (B,C,L) = [relu](((x - mean) * invstd) * gamma + beta) */
+int amc3d_bn_act(int B, int C, long L, int relu, const float *x, const float *mean, const float *invstd,
+                 const float *gamma, const float *beta, float *y, void *stream);
+
+/* y (B,C,M) = max over K of [relu](bn(x (B,C,M,K))); arg (B,C,M) = first arg-max (bytes), K <= 255 */
+int amc3d_bn_max(int B, int C, int M, int K, int relu, const float *x, const float *mean, const float *invstd,
+                 const float *gamma, const float *beta, float *y, unsigned char *arg, void *stream);
+
+/* backward of amc3d_bn_act (arg = NULL, K = 1, dy (B,C,L)) or amc3d_bn_max (arg given, dy (B,C,L/K)) under
+ * batch statistics: dx (B,C,L), dgamma (C), dbeta (C) */
+int amc3d_bn_backward(int B, int C, long L, int K, int relu, const float *x, const float *dy,
+                      const unsigned char *arg, const float *mean, const float *invstd, const float *gamma,
+                      const float *beta, float *dx, float *dgamma, float *dbeta, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,94 @@
+"""Fused training-mode BatchNorm (+ReLU, + neighbourhood max) kernels against torch's own layers
+(nn.BatchNorm2d / ReLU / torch.max with autograd) on the same GPU tensors, fp64 as the arbiter."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("shape,relu", [((2, 32, 500, 32), True), ((3, 7, 65, 31), False), ((8, 64, 3000), True),
+                                        ((2, 5, 1), False), ((2, 16, 33, 4), True)])
+def test_bn_act_matches_torch(shape, relu):
+    from amcontrast3d_amd.ops import BatchNormAct
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(shape, generator=g) * 3 + 1.5).to(DEV)
+    C = shape[1]
+    gamma = (torch.rand(C, generator=g) - 0.3).to(DEV)
+    beta = torch.randn(C, generator=g).to(DEV)
+    go = torch.randn(shape, generator=g).to(DEV)
+
+    def ref(dtype):
+        xr = x.to(dtype).requires_grad_(True)
+        gr, br = gamma.to(dtype).requires_grad_(True), beta.to(dtype).requires_grad_(True)
+        y = torch.nn.functional.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+        if relu:
+            y = torch.relu(y)
+        y.backward(go.to(dtype))
+        return y.detach(), xr.grad, gr.grad, br.grad
+
+    xg = x.clone().requires_grad_(True)
+    gg, bg = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y, mean, var_u = BatchNormAct.apply(xg, gg, bg, 1e-5, relu)
+    y.backward(go)
+    y64, dx64, dg64, db64 = ref(torch.float64)
+    y32, dx32, dg32, db32 = ref(torch.float32)
+    for got, r64, r32 in ((y, y64, y32), (xg.grad, dx64, dx32), (gg.grad, dg64, dg32), (bg.grad, db64, db32)):
+        err = float((got.double() - r64).abs().max())
+        err_torch = float((r32.double() - r64).abs().max())
+        scale = max(1.0, float(r64.abs().max()))
+        assert err <= max(2 * err_torch, 1e-5 * scale), (err, err_torch)
+    dims = [0] + list(range(2, x.dim()))
+    assert torch.allclose(mean, x.mean(dims), atol=1e-5)
+    if x.numel() // C > 1:
+        assert torch.allclose(var_u, x.var(dims, unbiased=True), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape,relu", [((2, 32, 500, 32), False), ((2, 16, 100, 32), True), ((3, 9, 17, 5), False)])
+def test_bn_max_matches_torch(shape, relu):
+    from amcontrast3d_amd.ops import BatchNormMax
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(shape, generator=g) * 2 - 0.5).to(DEV)
+    x[:, :, :, -1] = x[:, :, :, 0]  # duplicated neighbours (ball-query padding): ties in the max
+    C = shape[1]
+    gamma = (torch.rand(C, generator=g) - 0.4).to(DEV)  # some negative gammas
+    beta = torch.randn(C, generator=g).to(DEV)
+    go = torch.randn(shape[:3], generator=g).to(DEV)
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y = torch.nn.functional.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    if relu:
+        y = torch.relu(y)
+    y = y.max(-1)[0]
+    y.backward(go.double())
+    xg = x.clone().requires_grad_(True)
+    gg, bg = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    out, _, _ = BatchNormMax.apply(xg, gg, bg, 1e-5, relu)
+    out.backward(go)
+    assert float((out.double() - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max()))
+    # the dense part of dx and the parameter gradients do not depend on which of two tied neighbours is taken
+    assert float((gg.grad.double() - gr.grad).abs().max()) <= 1e-4 * max(1.0, float(gr.grad.abs().max()))
+    assert float((bg.grad.double() - br.grad).abs().max()) <= 1e-4 * max(1.0, float(br.grad.abs().max()))
+    a, b = xg.grad.double(), xr.grad
+    pair = lambda t: torch.cat([t[..., 1:-1], (t[..., :1] + t[..., -1:])], -1)  # tied columns summed
+    assert float((pair(a) - pair(b)).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_run_convblocks_equals_module_stack_and_updates_running_stats():
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from openpoints.models.layers import create_convblock2d, run_convblocks
+    torch.manual_seed(0)
+    blocks = nn.Sequential(create_convblock2d(7, 16, norm_args={'norm': 'bn'}, act_args={'act': 'relu'}),
+                           create_convblock2d(16, 24, norm_args={'norm': 'bn'}, act_args=None)).to(DEV).train()
+    import copy
+    ref = copy.deepcopy(blocks)
+    x = torch.randn(2, 7, 300, 32, device=DEV)
+    got = run_convblocks(blocks, x, pool_max=True)
+    want = ref(x).max(-1)[0]
+    assert float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    for (k, a), (_, b) in zip(blocks.state_dict().items(), ref.state_dict().items()):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6), k
+    blocks.eval(); ref.eval()
+    assert torch.allclose(run_convblocks(blocks, x, pool_max=True), ref(x).max(-1)[0], atol=1e-5)
