@@ -58,6 +58,50 @@ def precompute_sampling(model, data, aux_stream=None, join=True):
     return {"encoder": enc, "decoder": dec}
 
 
+@torch.no_grad()
+def precompute_fps(model, data):
+    """The serial part only: per stage {'fps_idx', 'new_p'} (four dependent FPS launches + gathers)."""
+    m = _unwrap(model)
+    p, out = data["pos"], []
+    for stage in m.encoder.encoder:
+        g = stage[0].plan_sample(p)
+        out.append(g)
+        p = g["new_p"]
+    return out
+
+
+@torch.no_grad()
+def precompute_rest(model, contrast_head, data, fps, num_classes, ignore_index, ambiguity_args):
+    """Everything that hangs off a finished sampling `fps` (from precompute_fps): ball queries, relative
+    positions, 3-NN, loss geometry.  -> a full plan whose per-stage dicts also hold fps's tensors."""
+    m = _unwrap(model)
+    p, enc = [data["pos"]], []
+    for i, stage in enumerate(m.encoder.encoder):
+        g = dict(fps[i])
+        stage[0].plan_group(p[i], g)
+        blocks, cache = [g], {}
+        p.append(g["new_p"])
+        for blk in list(stage)[1:]:
+            grouper = blk.convs.grouper
+            key = (getattr(grouper, "radius", None), getattr(grouper, "nsample", None))
+            if key not in cache:
+                cache[key] = blk.plan(p[i + 1])
+            blocks.append(cache[key])
+        enc.append(blocks)
+    plan = {"encoder": enc, "decoder": m.decoder.plan_geometry(p)}
+    plan["loss"] = precompute_loss(contrast_head, plan, data["y"], num_classes, ignore_index, ambiguity_args)
+    return plan
+
+
+def split(plan):
+    """(fps part, rest part) of a full plan, as structures referencing the plan's own tensors."""
+    fps = [{"fps_idx": b[0]["fps_idx"], "new_p": b[0]["new_p"]} for b in plan["encoder"]]
+    rest = {"encoder": [[{k: v for k, v in b[0].items() if k not in ("fps_idx", "new_p")}] + list(b[1:])
+                        for b in plan["encoder"]],
+            "decoder": plan["decoder"], "loss": plan["loss"]}
+    return fps, rest
+
+
 def stage_points(plan):
     """The flattened clouds of the loss stages of a sampling plan: [{'p_out' (B*n,3), 'offset'}] x 4
     (what pointnext_AA.py:458-462 puts into stageACE_list)."""
@@ -119,7 +163,8 @@ def copy_into(dst, src):
     """In-place copy of every tensor of plan `src` into the same-shaped plan `dst` (static buffers
     for graph replay).  Views (e.g. idx[:, 1:]) are copied through their storage like any tensor."""
     if torch.is_tensor(dst):
-        dst.copy_(src)
+        if dst.data_ptr() != src.data_ptr():
+            dst.copy_(src)
     elif isinstance(dst, dict):
         for k in dst:
             copy_into(dst[k], src[k])

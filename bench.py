@@ -131,9 +131,10 @@ def main():
     # Software pipeline over consecutive batches.  The coordinate-only half of a step
     # (amcontrast3d_amd/geometry.py) does not depend on features or weights, so it runs ahead, on two side
     # streams, while the current batch runs its feature half on the main stream:
-    #     stream A  sampling geometry of batch t+2 : FPS chain (one workgroup per cloud: 8 of 256 CUs for
-    #               ~14 ms), ball queries, relative positions, 3-NN
-    #     stream B  loss geometry of batch t+1     : k-NN, class votes, positive masks, ambiguities
+    #     stream A  sampling of batch t+2            : the FPS chain (one workgroup per cloud: 8 of 256 CUs
+    #               for ~14 ms)
+    #     stream B  neighbourhoods of batch t+1      : ball queries, relative positions, 3-NN, and the loss
+    #               geometry (k-NN, class votes, positive masks, ambiguities)
     #     main      features of batch t            : forward, loss, backward (+ all-reduce, clip, AdamW)
     # Every step still does one full pass of each inside the timed region (the synthetic "next batches" are
     # the same resident batch).  Each part is its own hipGraph on its own stream: on ROCm 7.2 separate
@@ -147,30 +148,32 @@ def main():
     s_a, s_b = torch.cuda.Stream(), torch.cuda.Stream()
     head = criterion.contrast_head
 
-    def geo_sampling():
-        return geometry.precompute_sampling(model, data)
+    def geo_fps():
+        return geometry.precompute_fps(model, data)
 
-    def geo_loss(plan):
-        return geometry.precompute_loss(head, plan, data["y"], 13, None, aargs)
+    def geo_rest(fps):
+        return geometry.precompute_rest(model, head, data, fps, 13, None, aargs)
 
     if overlap:
-        a_out = geo_sampling()                 # written by stream A (batch t+2)
+        a_out = geo_fps()                      # written by stream A (batch t+2): the FPS chain only
         a_stable = geometry.clone(a_out)       # batch t+1: read by stream B
-        b_out = geo_loss(a_stable)             # written by stream B (batch t+1)
-        cur = geometry.clone({"encoder": a_stable["encoder"], "decoder": a_stable["decoder"], "loss": b_out})
-        data["_geometry"] = cur                # batch t: read by the feature half
+        b_full = geo_rest(a_stable)            # stream B (batch t+1): neighbourhoods, 3-NN, loss geometry
+        b_out = geometry.split(b_full)[1]
+        cur = geometry.clone(b_full)           # batch t: read by the feature half
+        cur_fps, cur_rest = geometry.split(cur)
+        data["_geometry"] = cur
         torch.cuda.synchronize()
 
     def rotate():  # main stream, between steps: advance the pipeline buffers by one batch
-        geometry.copy_into({"encoder": cur["encoder"], "decoder": cur["decoder"]}, a_stable)
-        geometry.copy_into(cur["loss"], b_out)
+        geometry.copy_into(cur_fps, a_stable)
+        geometry.copy_into(cur_rest, b_out)
         geometry.copy_into(a_stable, a_out)
 
     def body_a():
-        geometry.copy_into(a_out, geo_sampling())
+        geometry.copy_into(a_out, geo_fps())
 
     def body_b():
-        geometry.copy_into(b_out, geo_loss(a_stable))
+        geometry.copy_into(b_out, geometry.split(geo_rest(a_stable))[1])
 
     def update():
         torch.nn.utils.clip_grad_norm_(params, 10, norm_type=2)
@@ -250,7 +253,7 @@ def main():
             torch.cuda.synchronize()
             return round((time.perf_counter() - t) / reps * 1e3, 3)
         parts = {"features_ms": alone(graphs["feat"].replay, main_s), "update_ms": alone(graphs["update"].replay, main_s),
-                 "sampling_geometry_ms": alone(graphs["a"].replay, s_a), "loss_geometry_ms": alone(graphs["b"].replay, s_b),
+                 "fps_chain_ms": alone(graphs["a"].replay, s_a), "neighbourhood_geometry_ms": alone(graphs["b"].replay, s_b),
                  "rotate_ms": alone(graphs["rotate"].replay, main_s)}
 
     # per-operator HIP-event timing: the same step, launched eagerly so each C-ABI launch can be
@@ -291,7 +294,7 @@ def main():
                        "global_batch": args.batch * world, "points": args.points,
                        "parallelism": f"dp{world}" + ("+syncbn+ddp" if use_ddp else ""),
                        "launch": "hipGraph replay (fwd+loss+bwd | clip+AdamW)" if use_graph else "eager",
-                       "pipeline": "3 streams: sampling geometry (t+2) | loss geometry (t+1) | features (t)"
+                       "pipeline": "3 streams: FPS chain (t+2) | neighbourhood + loss geometry (t+1) | features (t)"
                                    if overlap_was else "none"},
             "loss": round(final_loss, 6),
             "roofline": roofline,
