@@ -35,6 +35,11 @@ SIGNATURES = {
     "amc3d_ambiguity": (_i, [_i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_contrast_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_contrast_backward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_grouped_conv_supported": (_i, [_i, _i]),
+    "amc3d_transpose_cn": (_i, [_i, _i, _i, _vp, _vp, _vp]),
+    "amc3d_grouped_conv_forward": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_grouped_conv_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "amc3d_grouped_conv_backward": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_bn_workspace_bytes": (_sz, [_i]),
     "amc3d_bn_stats": (_i, [_i, _i, _l, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_bn_act": (_i, [_i, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

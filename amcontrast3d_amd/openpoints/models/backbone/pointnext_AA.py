@@ -29,7 +29,8 @@ import torch.nn as nn
 
 from ..build import MODELS
 from ..layers import (CHANNEL_MAP, create_act, create_convblock1d, create_convblock2d, create_grouper,
-                      furthest_point_sample, get_aggregation_feautres, random_sample, run_convblocks,
+                      furthest_point_sample, fused_first_conv, get_aggregation_feautres, random_sample,
+                      run_convblocks,
                       three_interpolate, three_nn)
 
 
@@ -75,6 +76,10 @@ class LocalAggregation(nn.Module):
         p, f = pf
         if geom is None:
             geom = self.plan(p)
+        pre = fused_first_conv(self.convs, f, geom, self.feature_type)
+        if pre is not None:  # gather + concat + first conv in one MFMA kernel
+            y = run_convblocks(self.convs, None, pool_max=self.reduction == 'max', pre=pre)
+            return y if self.reduction == 'max' else self.pool(y)
         dp, fj = self.grouper(p, p, f, geom=geom)
         fj = get_aggregation_feautres(p, dp, f, fj, self.feature_type)
         if self.reduction == 'max':
@@ -157,9 +162,13 @@ class SetAbstraction(nn.Module):
             fi = torch.gather(f, -1, idx.unsqueeze(1).expand(-1, f.shape[1], -1))
             if self.use_res:
                 identity = self.skipconv(fi)
-        dp, fj = self.grouper(new_p, p, f, geom=geom if 'idx' in geom else None)
-        fj = get_aggregation_feautres(new_p, dp, fi, fj, feature_type=self.feature_type)
-        f = run_convblocks(self.convs, fj, pool_max=True)  # conv/BN/ReLU stack + max over the neighbours
+        pre = fused_first_conv(self.convs, f, geom, self.feature_type)
+        if pre is not None:  # gather + concat + first conv in one MFMA kernel
+            f = run_convblocks(self.convs, None, pool_max=True, pre=pre)
+        else:
+            dp, fj = self.grouper(new_p, p, f, geom=geom if 'idx' in geom else None)
+            fj = get_aggregation_feautres(new_p, dp, fi, fj, feature_type=self.feature_type)
+            f = run_convblocks(self.convs, fj, pool_max=True)  # conv/BN/ReLU stack + max over the neighbours
         if self.use_res:
             f = self.act(f + identity)
         return new_p, f

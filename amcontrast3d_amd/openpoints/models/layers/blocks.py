@@ -126,12 +126,13 @@ def _update_running(bn, mean, var_unbiased):
             bn.running_var.mul_(1 - mom).add_(var_unbiased, alpha=mom)
 
 
-def run_convblocks(blocks, x, pool_max=False):
+def run_convblocks(blocks, x, pool_max=False, pre=None):
     """Evaluate a stack of conv blocks (the nn.Sequential the factories above build), optionally followed by
     the max over the last (neighbour) dimension.  Where a block is conv -> plain BatchNorm [-> ReLU] in
     training mode, BatchNorm statistics, normalisation, ReLU and (for the last block) the max-pool run as
     fused gfx950 kernels (amcontrast3d_amd/csrc/bn.hip); everything else runs the stored modules as they are.
-    Parameters, buffers and their bookkeeping stay those of the nn modules."""
+    Parameters, buffers and their bookkeeping stay those of the nn modules.
+    `pre`: the already computed output of the first block's convolution (the fused gather+conv kernel)."""
     from amcontrast3d_amd.ops import BatchNormAct, BatchNormMax
     mods = list(blocks)
     pooled = False
@@ -141,7 +142,7 @@ def run_convblocks(blocks, x, pool_max=False):
         if (sub is not None and len(sub) in (2, 3) and isinstance(sub[0], (nn.Conv1d, nn.Conv2d))
                 and isinstance(sub[1], nn.modules.batchnorm._BatchNorm)
                 and (len(sub) == 2 or type(sub[2]) is nn.ReLU)):
-            y = sub[0](x)
+            y = pre if (bi == 0 and pre is not None) else sub[0](x)
             bn = sub[1]
             if _fusable_bn(bn, y):
                 relu = len(sub) == 3
@@ -156,10 +157,28 @@ def run_convblocks(blocks, x, pool_max=False):
                 if len(sub) == 3:
                     x = sub[2](x)
         else:
+            assert not (bi == 0 and pre is not None), "pre needs a conv -> norm block"
             x = blk(x)
     if pool_max and not pooled:
         x = torch.max(x, dim=-1, keepdim=False)[0]
     return x
+
+
+def fused_first_conv(blocks, f, geom, feature_type):
+    """Output of the first block's 1x1 conv on [dp ; f[idx]] from the fused gather+conv MFMA kernel, or None
+    when the layer is not of that form (then the caller groups, concatenates and convolves as usual)."""
+    from amcontrast3d_amd import ops
+    blk = blocks[0]
+    if (feature_type != 'dp_fj' or geom is None or 'idx' not in geom or f is None or not f.is_cuda
+            or f.dtype != torch.float32 or torch.is_autocast_enabled() or not isinstance(blk, nn.Sequential)
+            or len(blk) < 2 or not isinstance(blk[0], nn.Conv2d)
+            or not isinstance(blk[1], nn.modules.batchnorm._BatchNorm)):
+        return None
+    conv = blk[0]
+    if (conv.bias is not None or conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.groups != 1
+            or conv.in_channels != f.shape[1] + 3 or not ops.grouped_conv_supported(f.shape[1], conv.out_channels)):
+        return None
+    return ops.grouped_conv(f, geom['dp'], geom['idx'], conv.weight)
 
 
 # input width of the first grouped conv for each neighbourhood feature recipe

@@ -403,7 +403,7 @@ class BatchNormAct(Function):
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(beta)
         work, wb = _bn_ws(C, x.device, extra=C * 8)
-        with torch.cuda.device(x.device), timing.span("bn_act_backward", x.numel() * 16):
+        with torch.cuda.device(x.device), timing.span("bn_act_backward", x.numel() * 20):
             _lib.check(_lib.load().amc3d_bn_backward(B, C, L, 1, int(ctx.relu), _ptr(x), _ptr(dy), None, _ptr(mean),
                                                      _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dx), _ptr(dgamma),
                                                      _ptr(dbeta), _ptr(work), wb, _stream(x)), "bn_backward")
@@ -452,3 +452,64 @@ class BatchNormMax(Function):
                                                      _ptr(dgamma), _ptr(dbeta), _ptr(work), wb, _stream(x)),
                        "bn_backward")
         return dx, dgamma, dbeta, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# grouped 1x1 convolution fused with its gather, fp32 MFMA (csrc/gcc.hip)
+# ----------------------------------------------------------------------------------------------
+def grouped_conv_supported(cin, cout):
+    return bool(_lib.load().amc3d_grouped_conv_supported(int(cin), int(cout)))
+
+
+class GroupedConv(Function):
+    """y (B,Cout,M,K) = W . [dp ; features[:, :, idx]] -- grouping_operation + torch.cat + nn.Conv2d 1x1 of the
+    reference (group.py:244-255,323-325; pointnext_AA.py:164-166) without the (B,C+3,M,K) tensor.
+    features (B,C,N) fp32, dp (B,3,M,K), idx (B,M,K) int32, weight (Cout,C+3,1,1)."""
+
+    @staticmethod
+    def forward(ctx, features, dp, idx, weight):
+        _need_gpu(features, dp, idx, weight)
+        features, dp, idx = features.contiguous(), dp.contiguous(), idx.contiguous()
+        B, C, N = features.shape
+        _, M, K = idx.shape
+        Cout = weight.shape[0]
+        assert weight.shape[1] == C + 3 and idx.dtype == torch.int32
+        dev = features.device
+        f_pm = torch.empty(B, N, C, dtype=torch.float32, device=dev)
+        y = torch.empty(B, Cout, M, K, dtype=torch.float32, device=dev)
+        w2 = weight.reshape(Cout, C + 3).contiguous()
+        lib = _lib.load()
+        flops = 2.0 * B * M * K * (C + 3) * Cout
+        with torch.cuda.device(dev), timing.span("grouped_conv_forward", B * M * K * (4 * C + 16 + 4 * Cout), flops):
+            _lib.check(lib.amc3d_transpose_cn(B, C, N, _ptr(features), _ptr(f_pm), _stream(features)), "transpose_cn")
+            _lib.check(lib.amc3d_grouped_conv_forward(B, C, Cout, N, M, K, _ptr(f_pm), _ptr(dp), _ptr(idx), _ptr(w2),
+                                                      _ptr(y), _stream(features)), "grouped_conv_forward")
+        ctx.save_for_backward(f_pm, dp, idx, w2)
+        ctx.wshape = tuple(weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        f_pm, dp, idx, w2 = ctx.saved_tensors
+        B, N, C = f_pm.shape
+        _, M, K = idx.shape
+        Cout = w2.shape[0]
+        dy = dy.contiguous()
+        dev = dy.device
+        need_f, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[3]
+        df_pm = torch.zeros(B, N, C, dtype=torch.float32, device=dev) if need_f else None
+        dw = torch.empty(Cout, C + 3, dtype=torch.float32, device=dev) if need_w else None
+        lib = _lib.load()
+        wb = int(lib.amc3d_grouped_conv_workspace_bytes(B, C, Cout, M, K))
+        work = torch.empty(max(wb, 4), dtype=torch.uint8, device=dev)
+        flops = 2.0 * B * M * K * Cout * ((C if need_f else 0) + (C + 3 if need_w else 0))
+        with torch.cuda.device(dev), timing.span("grouped_conv_backward", B * M * K * (8 * C + 16 + 8 * Cout), flops):
+            _lib.check(lib.amc3d_grouped_conv_backward(B, C, Cout, N, M, K, _ptr(f_pm), _ptr(dp), _ptr(idx), _ptr(w2),
+                                                       _ptr(dy), _ptr(df_pm) if need_f else None,
+                                                       _ptr(dw) if need_w else None, _ptr(work), wb, _stream(dy)),
+                       "grouped_conv_backward")
+        df = df_pm.transpose(1, 2).contiguous() if need_f else None
+        return df, None, None, (dw.view(ctx.wshape) if need_w else None)
+
+
+grouped_conv = GroupedConv.apply

@@ -10,7 +10,7 @@ import collections
 import torch
 
 _enabled = False
-_records = []  # (name, start_event, end_event, algorithmic_bytes)
+_records = []  # (name, start_event, end_event, algorithmic_bytes, flops)
 
 
 def enable(flag=True):
@@ -26,10 +26,10 @@ def enabled():
 
 class span:
     """with timing.span('knnquery', bytes): launch(...)"""
-    __slots__ = ("name", "nbytes", "start")
+    __slots__ = ("name", "nbytes", "flops", "start")
 
-    def __init__(self, name, nbytes=0):
-        self.name, self.nbytes, self.start = name, nbytes, None
+    def __init__(self, name, nbytes=0, flops=0.0):
+        self.name, self.nbytes, self.flops, self.start = name, nbytes, flops, None
 
     def __enter__(self):
         if _enabled:
@@ -41,18 +41,19 @@ class span:
         if self.start is not None:
             end = torch.cuda.Event(enable_timing=True)
             end.record()
-            _records.append((self.name, self.start, end, self.nbytes))
+            _records.append((self.name, self.start, end, self.nbytes, self.flops))
         return False
 
 
 def collect():
     """-> {name: {'launches', 'total_ms', 'avg_ms', 'bytes_per_launch'}}; call after a device sync."""
     out = collections.OrderedDict()
-    for name, s, e, nbytes in _records:
-        d = out.setdefault(name, {"launches": 0, "total_ms": 0.0, "bytes": 0})
+    for name, s, e, nbytes, flops in _records:
+        d = out.setdefault(name, {"launches": 0, "total_ms": 0.0, "bytes": 0, "flops": 0.0})
         d["launches"] += 1
         d["total_ms"] += s.elapsed_time(e)
         d["bytes"] += nbytes
+        d["flops"] += flops
     for d in out.values():
         d["avg_ms"] = d["total_ms"] / d["launches"]
         d["bytes_per_launch"] = d["bytes"] / d["launches"]

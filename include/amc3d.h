@@ -164,6 +164,25 @@ int amc3d_contrast_backward(int m, int C, int k, int nbr_stride, const float *f,
                             float temperature, const float *sim, const float *mean_cnt, const float *grad_out,
                             float *grad_f, void *stream);
 
+/* ---- grouped 1x1 convolution fused with its gather (fp32 MFMA) ------------------------------------
+ * Replaces, for the first layer of a SetAbstraction / LocalAggregation MLP, the chain
+ *   grouping_operation(features, idx) -> torch.cat([dp, fj], 1) -> nn.Conv2d 1x1 (bias-free)
+ * (openpoints/models/layers/group.py:244-255,323-325; backbone/pointnext_AA.py:57-63,164-166) and its
+ * backward (conv backward, slice, group_points_grad) without materialising the (b,cin+3,npoints,nsample)
+ * input.  f_pm is the POINT-major (b,n,cin) copy of the features (amc3d_transpose_cn), dp the
+ * (b,3,npoints,nsample) relative positions, weight the (cout, cin+3) conv weight with the reference's
+ * channel order [dp, features].  Supported: cin <= 64, cout in {32,64,96,128}. */
+int amc3d_grouped_conv_supported(int cin, int cout);
+int amc3d_transpose_cn(int b, int c, int n, const float *src, float *dst, void *stream);
+int amc3d_grouped_conv_forward(int b, int cin, int cout, int n, int npoints, int nsample, const float *f_pm,
+                               const float *dp, const int *idx, const float *weight, float *y, void *stream);
+size_t amc3d_grouped_conv_workspace_bytes(int b, int cin, int cout, int npoints, int nsample);
+/* df_pm (b,n,cin) += scatter(W[:,3:]^T dy) (zero-initialised by the caller; NULL to skip),
+ * dweight (cout,cin+3) = dy . X^T (NULL to skip) */
+int amc3d_grouped_conv_backward(int b, int cin, int cout, int n, int npoints, int nsample, const float *f_pm,
+                                const float *dp, const int *idx, const float *weight, const float *dy,
+                                float *df_pm, float *dweight, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- training-mode BatchNorm fused with ReLU / neighbourhood max-pool ---------------------------
  * The reference runs nn.Conv -> nn.BatchNorm -> nn.ReLU(inplace) [-> torch.max over the neighbours]
  * as separate torch layers (openpoints/models/layers/conv.py:24-102, backbone/pointnext_AA.py:166).
