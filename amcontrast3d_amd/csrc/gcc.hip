@@ -277,14 +277,25 @@ __global__ __launch_bounds__(256) void gcc_bwd_weight_kernel(int cin, int cout, 
     for (int i = threadIdx.x; i < cout * 3; i += 256) out[(i / 3) * CP + i % 3] = redp[i];
 }
 
-// dW (Cout, Cin+3) = sum of the partials, in workgroup order (deterministic)
-__global__ void gcc_reduce_partials_kernel(int total, int nparts, const float *__restrict__ partial, float *__restrict__ dW)
+// dW (Cout, Cin+3) = sum of the partials in a fixed order (deterministic): a workgroup owns 64
+// consecutive elements, its 16 slices each sum every 16th partial, then the slices are added in order.
+__global__ __launch_bounds__(1024) void gcc_reduce_partials_kernel(int total, int nparts, const float *__restrict__ partial,
+                                                                   float *__restrict__ dW)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+    __shared__ float red[16][64];
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + e;
     float s = 0.f;
-    for (int k = 0; k < nparts; ++k) s += partial[(size_t)k * total + i];
-    dW[i] = s;
+    if (i < total)
+        for (int k = sl; k < nparts; k += 16) s += partial[(size_t)k * total + i];
+    red[sl][e] = s;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+        float t = red[0][e];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k][e];
+        dW[i] = t;
+    }
 }
 
 // opt in to large dynamic LDS allocations (gfx950: up to 160 KiB per workgroup)
@@ -369,7 +380,7 @@ AMC_API int amc3d_grouped_conv_backward(int b, int cin, int cout, int n, int npo
         }
 #undef AMC_WRW
         const int total = cout * (cin + 3);
-        hipLaunchKernelGGL(gcc_reduce_partials_kernel, dim3(div_up(total, 256)), dim3(256), 0, stream, total, groups * b,
+        hipLaunchKernelGGL(gcc_reduce_partials_kernel, dim3(div_up(total, 64)), dim3(1024), 0, stream, total, groups * b,
                            (const float *)partial, dweight);
     }
     return launch_status("amc3d_grouped_conv_backward");
