@@ -40,6 +40,9 @@ SIGNATURES = {
     "amc3d_grouped_conv_forward": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_grouped_conv_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "amc3d_grouped_conv_backward": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "amc3d_pointwise_conv_forward": (_i, [_i, _i, _i, _l, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_pointwise_conv_workspace_bytes": (_sz, [_i, _i, _i, _l]),
+    "amc3d_pointwise_conv_backward": (_i, [_i, _i, _i, _l, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_bn_workspace_bytes": (_sz, [_i]),
     "amc3d_bn_stats": (_i, [_i, _i, _l, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_bn_act": (_i, [_i, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -298,6 +298,12 @@ __global__ __launch_bounds__(1024) void gcc_reduce_partials_kernel(int total, in
     }
 }
 
+int reduce_partials(int total, int nparts, const float *partial, float *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(gcc_reduce_partials_kernel, dim3(div_up(total, 64)), dim3(1024), 0, stream, total, nparts, partial, out);
+    return launch_status("reduce_partials");
+}
+
 // opt in to large dynamic LDS allocations (gfx950: up to 160 KiB per workgroup)
 template <typename K>
 static void allow_lds(K kernel, size_t bytes)

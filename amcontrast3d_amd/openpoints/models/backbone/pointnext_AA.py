@@ -161,7 +161,7 @@ class SetAbstraction(nn.Module):
         if self.use_res or 'df' in self.feature_type:
             fi = torch.gather(f, -1, idx.unsqueeze(1).expand(-1, f.shape[1], -1))
             if self.use_res:
-                identity = self.skipconv(fi)
+                identity = run_convblocks((self.skipconv,), fi)
         pre = fused_first_conv(self.convs, f, geom, self.feature_type)
         if pre is not None:  # gather + concat + first conv in one MFMA kernel
             f = run_convblocks(self.convs, None, pool_max=True, pre=pre)

@@ -126,6 +126,27 @@ def _update_running(bn, mean, var_unbiased):
             bn.running_var.mul_(1 - mom).add_(var_unbiased, alpha=mom)
 
 
+def conv1x1(conv, x):
+    """conv(x); a plain 1x1 convolution on a contiguous fp32 GPU tensor runs on the MFMA kernels of
+    csrc/pwconv.hip (same parameters, same autograd contract), anything else on the stored torch module."""
+    if (type(conv) in (nn.Conv1d, nn.Conv2d, Conv1d, Conv2d) and x.is_cuda and x.dtype == torch.float32
+            and not torch.is_autocast_enabled() and conv.groups == 1 and conv.padding_mode == 'zeros'
+            and all(k == 1 for k in conv.kernel_size) and all(v == 1 for v in conv.stride)
+            and all(v == 0 for v in conv.padding) and x.dim() == conv.weight.dim() and _pw_pays(conv, x)):
+        from amcontrast3d_amd.ops import pointwise_conv
+        return pointwise_conv(x, conv.weight, conv.bias)
+    return conv(x)
+
+
+def _pw_pays(conv, x):
+    """Measured on MI355X (scratch/pw_bench.py): the kernel beats MIOpen/rocBLAS (which wrap the weight gradient
+    in NCHW<->NHWC transposes) on the wide, shallow layers -- stem, head, the two finest FeaturePropagation stages;
+    the deep, narrow ones (>= 128 channels over <= 10^5 positions) are MFMA-bound GEMMs the library does better."""
+    positions = x.numel() // x.shape[1]
+    cin, cout = conv.in_channels, conv.out_channels
+    return positions >= 131072 and max(cin, cout) <= 128 or (max(cin, cout) <= 64 and positions >= 32768)
+
+
 def run_convblocks(blocks, x, pool_max=False, pre=None):
     """Evaluate a stack of conv blocks (the nn.Sequential the factories above build), optionally followed by
     the max over the last (neighbour) dimension.  Where a block is conv -> plain BatchNorm [-> ReLU] in
@@ -142,7 +163,7 @@ def run_convblocks(blocks, x, pool_max=False, pre=None):
         if (sub is not None and len(sub) in (2, 3) and isinstance(sub[0], (nn.Conv1d, nn.Conv2d))
                 and isinstance(sub[1], nn.modules.batchnorm._BatchNorm)
                 and (len(sub) == 2 or type(sub[2]) is nn.ReLU)):
-            y = pre if (bi == 0 and pre is not None) else sub[0](x)
+            y = pre if (bi == 0 and pre is not None) else conv1x1(sub[0], x)
             bn = sub[1]
             if _fusable_bn(bn, y):
                 relu = len(sub) == 3
@@ -158,7 +179,12 @@ def run_convblocks(blocks, x, pool_max=False, pre=None):
                     x = sub[2](x)
         else:
             assert not (bi == 0 and pre is not None), "pre needs a conv -> norm block"
-            x = blk(x)
+            if sub is not None and len(sub) >= 1 and isinstance(sub[0], (nn.Conv1d, nn.Conv2d)):
+                x = conv1x1(sub[0], x)
+                for mod in sub[1:]:
+                    x = mod(x)
+            else:
+                x = blk(x)
     if pool_max and not pooled:
         x = torch.max(x, dim=-1, keepdim=False)[0]
     return x

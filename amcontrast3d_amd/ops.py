@@ -513,3 +513,56 @@ class GroupedConv(Function):
 
 
 grouped_conv = GroupedConv.apply
+
+
+class PointwiseConv(Function):
+    """y = conv1x1(x, weight, bias): nn.Conv1d / nn.Conv2d with kernel size 1 (models/layers/conv.py:8-21) on the
+    fp32 MFMA kernels of csrc/pwconv.hip.  x (B,Cin,*spatial) fp32, weight (Cout,Cin,1[,1]), bias (Cout) or None."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_gpu(x, weight)
+        x = x.contiguous()
+        B, Cin = x.shape[0], x.shape[1]
+        P = x[0, 0].numel()
+        Cout = weight.shape[0]
+        assert weight.numel() == Cout * Cin, "pointwise_conv needs a 1x1 kernel"
+        w2 = weight.reshape(Cout, Cin).contiguous()
+        y = torch.empty((B, Cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        lib = _lib.load()
+        with torch.cuda.device(x.device), timing.span("pointwise_conv_forward", 4 * B * P * (Cin + Cout),
+                                                      2.0 * B * P * Cin * Cout):
+            _lib.check(lib.amc3d_pointwise_conv_forward(B, Cin, Cout, P, _ptr(x), _ptr(w2),
+                                                        _ptr(bias.contiguous()) if bias is not None else None,
+                                                        _ptr(y), _stream(x)), "pointwise_conv_forward")
+        ctx.save_for_backward(x, w2)
+        ctx.wshape = tuple(weight.shape)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2 = ctx.saved_tensors
+        B, Cin = x.shape[0], x.shape[1]
+        P = x[0, 0].numel()
+        Cout = w2.shape[0]
+        dy = dy.contiguous()
+        dev = dy.device
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx = torch.empty_like(x) if need_x else None
+        dw = torch.empty(Cout, Cin, dtype=torch.float32, device=dev) if need_w else None
+        lib = _lib.load()
+        wb = int(lib.amc3d_pointwise_conv_workspace_bytes(B, Cin, Cout, P)) if need_w else 0
+        work = torch.empty(max(wb, 4), dtype=torch.uint8, device=dev)
+        flops = 2.0 * B * P * Cin * Cout * (int(need_x) + int(need_w))
+        with torch.cuda.device(dev), timing.span("pointwise_conv_backward",
+                                                 4 * B * P * ((Cin + Cout) * int(need_x) + (Cin + Cout) * int(need_w)), flops):
+            _lib.check(lib.amc3d_pointwise_conv_backward(B, Cin, Cout, P, _ptr(x), _ptr(w2), _ptr(dy),
+                                                         _ptr(dx) if need_x else None, _ptr(dw) if need_w else None,
+                                                         _ptr(work), wb, _stream(dy)), "pointwise_conv_backward")
+        db = dy.reshape(B, Cout, -1).sum(dim=(0, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, (dw.view(ctx.wshape) if need_w else None), db
+
+
+def pointwise_conv(x, weight, bias=None):
+    return PointwiseConv.apply(x, weight, bias)

@@ -183,6 +183,19 @@ int amc3d_grouped_conv_backward(int b, int cin, int cout, int n, int npoints, in
                                 const float *dp, const int *idx, const float *weight, const float *dy,
                                 float *df_pm, float *dweight, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- pointwise (1x1) convolution on fp32 MFMA -----------------------------------------------------
+ * Replaces the nn.Conv1d / nn.Conv2d (kernel size 1) layers of the path, which the reference builds in
+ * openpoints/models/layers/conv.py:8-21 and runs through cuDNN.  Channel-major tensors: x (b,cin,P),
+ * y (b,cout,P), weight (cout,cin), bias (cout) or NULL; P = points (Conv1d) or points*neighbours (Conv2d). */
+int amc3d_pointwise_conv_forward(int b, int cin, int cout, long P, const float *x, const float *weight,
+                                 const float *bias, float *y, void *stream);
+size_t amc3d_pointwise_conv_workspace_bytes(int b, int cin, int cout, long P);
+/* dx (b,cin,P) = weight^T . dy (NULL to skip); dweight (cout,cin) = sum_{b,p} dy x^T (NULL to skip; needs
+ * x and the workspace; summed in a fixed order -> deterministic) */
+int amc3d_pointwise_conv_backward(int b, int cin, int cout, long P, const float *x, const float *weight,
+                                  const float *dy, float *dx, float *dweight, void *workspace,
+                                  size_t workspace_bytes, void *stream);
+
 /* ---- training-mode BatchNorm fused with ReLU / neighbourhood max-pool ---------------------------
  * The reference runs nn.Conv -> nn.BatchNorm -> nn.ReLU(inplace) [-> torch.max over the neighbours]
  * as separate torch layers (openpoints/models/layers/conv.py:24-102, backbone/pointnext_AA.py:166).

@@ -1,0 +1,89 @@
+"""Pointwise (1x1) convolution on fp32 MFMA (csrc/pwconv.hip) against torch's conv1d/conv2d, forward and
+backward, with an fp64 evaluation as the arbiter: the kernel may be no further from fp64 than a few times
+what torch's own fp32 kernel is."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+SHAPES = [  # B, Cin, Cout, spatial, bias
+    (2, 4, 32, (1000,), False),      # stem
+    (2, 32, 13, (777,), True),       # head: bias, Cout not a multiple of 32, P % 4 != 0
+    (8, 96, 32, (3000,), False),     # FP
+    (2, 131, 256, (375, 32), False),  # SA3 (Conv2d)
+    (1, 259, 512, (93, 32), False),   # SA4
+    (3, 768, 256, (94,), False),     # deepest FP, ragged P
+    (1, 1, 1, (5,), True),
+    (2, 64, 64, (129,), False),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,spatial,bias", SHAPES)
+def test_pointwise_conv_matches_torch(B, Cin, Cout, spatial, bias):
+    from amcontrast3d_amd import ops
+    g = torch.Generator().manual_seed(Cin * 1000 + Cout)
+    x = torch.randn(B, Cin, *spatial, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, *([1] * len(spatial)), generator=g) * 0.1).to(DEV)
+    bvec = torch.randn(Cout, generator=g).to(DEV) if bias else None
+    go = torch.randn(B, Cout, *spatial, generator=g).to(DEV)
+    conv = F.conv1d if len(spatial) == 1 else F.conv2d
+
+    def ref(dtype):
+        xr, wr = x.to(dtype).requires_grad_(True), w.to(dtype).requires_grad_(True)
+        br = bvec.to(dtype).requires_grad_(True) if bias else None
+        y = conv(xr, wr, br)
+        y.backward(go.to(dtype))
+        return y.detach(), xr.grad, wr.grad, (br.grad if bias else None)
+
+    xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    bg = bvec.clone().requires_grad_(True) if bias else None
+    y = ops.pointwise_conv(xg, wg, bg)
+    assert y.shape == go.shape
+    y.backward(go)
+    r64, r32 = ref(torch.float64), ref(torch.float32)
+    got = (y, xg.grad, wg.grad, bg.grad if bias else None)
+    for a, b64, b32, what in zip(got, r64, r32, ("y", "dx", "dw", "db")):
+        if a is None:
+            continue
+        assert a.shape == b64.shape, what
+        err = float((a.double() - b64).abs().max())
+        err_torch = float((b32.double() - b64).abs().max())
+        scale = max(1.0, float(b64.abs().max()))
+        assert err <= max(4 * err_torch, 2e-6 * scale), (what, err, err_torch, scale)
+
+
+def test_pointwise_conv_weight_gradient_is_deterministic():
+    from amcontrast3d_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 96, 5000, generator=g).to(DEV)
+    w = (torch.randn(32, 96, 1, generator=g) * 0.1).to(DEV)
+    go = torch.randn(4, 32, 5000, generator=g).to(DEV)
+    grads = []
+    for _ in range(3):
+        wg = w.clone().requires_grad_(True)
+        ops.pointwise_conv(x, wg).backward(go)
+        grads.append(wg.grad.clone())
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+
+
+def test_model_blocks_route_1x1_convs_to_the_kernel():
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from amcontrast3d_amd import timing
+    from openpoints.models.layers import create_convblock1d, run_convblocks
+    blk = torch.nn.Sequential(create_convblock1d(8, 16, norm_args={'norm': 'bn'}, act_args={'act': 'relu'}),
+                              create_convblock1d(16, 5, norm_args=None, act_args=None)).to(DEV)
+    x = torch.randn(2, 8, 300, device=DEV)
+    timing.enable(True)
+    try:
+        y = run_convblocks(blk, x)
+        torch.cuda.synchronize()
+        names = set(timing.collect().keys())
+    finally:
+        timing.enable(False)
+    assert "pointwise_conv_forward" in names, names
+    blk.train()
+    ref = blk(x)
+    assert torch.allclose(y, ref, atol=1e-4, rtol=1e-4)
