@@ -30,27 +30,45 @@ __device__ __forceinline__ double block_sum_f64(double v, double *s_buf)
     return t;
 }
 
-// partial[c][chunk] = {sum, sumsq} over the chunk's share of (b, l); grid (chunks, C)
-__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(int B, int C, long L, const float *__restrict__ x,
-                                                              double *__restrict__ partial)
+// The (B, Lq) positions of a channel are cut into B * cps contiguous segments ("units") of `seg` positions
+// (a multiple of 4); workgroup `chunk` of a channel takes units chunk, chunk + nchunks, ...  One integer division
+// per unit, 16-byte loads inside.
+struct BnSplit {
+    int cps, units, nchunks;
+    long seg;
+};
+
+// partial[c][chunk] = {sum, sumsq} over the chunk's units; grid (nchunks, C)
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(int B, int C, long L, BnSplit sp, int vec,
+                                                              const float *__restrict__ x, double *__restrict__ partial)
 {
     __shared__ double s_buf[BN_THREADS / 64];
-    const int c = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int c = blockIdx.y, chunk = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    const long total = (long)B * L;  // positions of this channel, enumerated as b * L + l
-    const long per = (total + nchunks - 1) / nchunks;
-    const long lo = chunk * per, hi = min(total, lo + per);
-    for (long i = lo + threadIdx.x; i < hi; i += BN_THREADS) {
-        const long b = i / L, l = i - b * L;
-        const float v = x[((size_t)b * C + c) * L + l];
-        s1 += (double)v;
-        s2 += (double)v * (double)v;
+    for (int u = chunk; u < sp.units; u += sp.nchunks) {
+        const int b = u / sp.cps, sg = u - b * sp.cps;
+        const long l0 = sg * sp.seg, l1 = min(L, l0 + sp.seg);
+        const float *row = x + ((size_t)b * C + c) * L;
+        if (vec) {
+            for (long i = l0 + threadIdx.x * 4; i < l1; i += BN_THREADS * 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(row + i);
+                s1 += (double)v.x + (double)v.y + ((double)v.z + (double)v.w);
+                s2 += (double)v.x * (double)v.x + (double)v.y * (double)v.y +
+                      ((double)v.z * (double)v.z + (double)v.w * (double)v.w);
+            }
+        } else {
+            for (long i = l0 + threadIdx.x; i < l1; i += BN_THREADS) {
+                const float v = row[i];
+                s1 += (double)v;
+                s2 += (double)v * (double)v;
+            }
+        }
     }
     s1 = block_sum_f64(s1, s_buf);
     s2 = block_sum_f64(s2, s_buf);
     if (threadIdx.x == 0) {
-        partial[((size_t)c * nchunks + chunk) * 2 + 0] = s1;
-        partial[((size_t)c * nchunks + chunk) * 2 + 1] = s2;
+        partial[((size_t)c * sp.nchunks + chunk) * 2 + 0] = s1;
+        partial[((size_t)c * sp.nchunks + chunk) * 2 + 1] = s2;
     }
 }
 
@@ -144,38 +162,92 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_kernel(int C, int M, int K,
     arg[(size_t)bc * M + mi] = (unsigned char)bk;
 }
 
+// Same result, cooperative loads: LPR = K/4 consecutive lanes own one (b,c,m) row, a wave reads 1 KiB contiguous
+// per instruction instead of 64 separate 128-byte rows; the row arg-max is combined across the LPR lanes keeping
+// the first index among equal values (torch.max semantics).
+template <int LPR>
+__global__ __launch_bounds__(BN_THREADS) void bn_max_coop_kernel(int C, int M, int relu, const float *__restrict__ x,
+                                                                 const float *__restrict__ mean,
+                                                                 const float *__restrict__ invstd,
+                                                                 const float *__restrict__ gamma,
+                                                                 const float *__restrict__ beta, float *__restrict__ y,
+                                                                 unsigned char *__restrict__ arg)
+{
+    const int bc = blockIdx.y;
+    const int c = bc % C;
+    const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
+    const float4 *xr = reinterpret_cast<const float4 *>(x + (size_t)bc * M * (LPR * 4));
+    const long nf4 = (long)M * LPR;
+    for (long f = (long)blockIdx.x * BN_THREADS + threadIdx.x; f < ((nf4 + 63) & ~63L); f += (long)gridDim.x * BN_THREADS) {
+        const bool live = f < nf4;
+        const float4 v4 = live ? xr[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int sg = (int)(f & (LPR - 1));
+        const float vs[4] = {v4.x, v4.y, v4.z, v4.w};
+        float best = -__builtin_inff();
+        int bk = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = bn_val(vs[j], m, is, g, bt);
+            if (relu) v = fmaxf(v, 0.f);
+            if (v > best) { best = v; bk = sg * 4 + j; }
+        }
+#pragma unroll
+        for (int sft = 1; sft < LPR; sft <<= 1) {
+            const float ov = __shfl_xor(best, sft, 64);
+            const int ok = __shfl_xor(bk, sft, 64);
+            if (ov > best || (ov == best && ok < bk)) { best = ov; bk = ok; }
+        }
+        if (live && sg == 0) {
+            const long mi = f / LPR;
+            y[(size_t)bc * M + mi] = best;
+            arg[(size_t)bc * M + mi] = (unsigned char)bk;
+        }
+    }
+}
+
 // ---- backward statistics: per channel  Sa = sum dq,  Sb = sum dq * xhat  (dq = upstream gradient w.r.t. the
 // BN output, after the ReLU mask resp. routed through the arg-max).  partial layout as in bn_stats.
 // mode 0: act.  dq = dy * (relu ? bn(x) > 0 : 1) over (B, C, L)
 // mode 1: max.  dq is nonzero only at the arg-max: dq = g[b,c,m] * (relu ? y > 0 : 1), xhat at the arg-max
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_kernel(
-    int mode, int B, int C, long L, int K, int relu, const float *__restrict__ x, const float *__restrict__ dy,
-    const unsigned char *__restrict__ arg, const float *__restrict__ mean, const float *__restrict__ invstd,
-    const float *__restrict__ gamma, const float *__restrict__ beta, double *__restrict__ partial)
+    int mode, int B, int C, long L, int K, int relu, BnSplit sp, int vec, const float *__restrict__ x,
+    const float *__restrict__ dy, const unsigned char *__restrict__ arg, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta,
+    double *__restrict__ partial)
 {
     __shared__ double s_buf[BN_THREADS / 64];
-    const int c = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int c = blockIdx.y, chunk = blockIdx.x;
     const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
     double sa = 0.0, sb = 0.0;
     const long Lq = mode == 0 ? L : L / K;  // positions carrying a gradient per (b, c)
-    const long total = (long)B * Lq;
-    const long per = (total + nchunks - 1) / nchunks;
-    const long lo = chunk * per, hi = min(total, lo + per);
-    for (long i = lo + threadIdx.x; i < hi; i += BN_THREADS) {
-        const long b = i / Lq, l = i - b * Lq;
-        const size_t q = ((size_t)b * C + c) * Lq + l;
-        float d = dy[q];
-        const float xv = mode == 0 ? x[q] : x[q * K + arg[q]];
+    auto term = [&](float d, float xv) {
         const float xh = __fmul_rn(__fsub_rn(xv, m), is);
         if (relu && !(__fadd_rn(__fmul_rn(xh, g), bt) > 0.f)) d = 0.f;
         sa += (double)d;
         sb += (double)d * (double)xh;
+    };
+    for (int u = chunk; u < sp.units; u += sp.nchunks) {
+        const int b = u / sp.cps, sg = u - b * sp.cps;
+        const long l0 = sg * sp.seg, l1 = min(Lq, l0 + sp.seg);
+        const size_t base = ((size_t)b * C + c) * Lq;
+        if (mode == 0 && vec) {
+            for (long i = l0 + threadIdx.x * 4; i < l1; i += BN_THREADS * 4) {
+                const float4 d4 = *reinterpret_cast<const float4 *>(dy + base + i);
+                const float4 x4 = *reinterpret_cast<const float4 *>(x + base + i);
+                term(d4.x, x4.x); term(d4.y, x4.y); term(d4.z, x4.z); term(d4.w, x4.w);
+            }
+        } else {
+            for (long i = l0 + threadIdx.x; i < l1; i += BN_THREADS) {
+                const size_t q = base + i;
+                term(dy[q], mode == 0 ? x[q] : x[q * K + arg[q]]);
+            }
+        }
     }
     sa = block_sum_f64(sa, s_buf);
     sb = block_sum_f64(sb, s_buf);
     if (threadIdx.x == 0) {
-        partial[((size_t)c * nchunks + chunk) * 2 + 0] = sa;
-        partial[((size_t)c * nchunks + chunk) * 2 + 1] = sb;
+        partial[((size_t)c * sp.nchunks + chunk) * 2 + 0] = sa;
+        partial[((size_t)c * sp.nchunks + chunk) * 2 + 1] = sb;
     }
 }
 
@@ -199,7 +271,7 @@ __global__ void bn_bwd_finalize_kernel(int C, int nchunks, double count, const d
 
 // dx = gamma * invstd * (dq - mean(dq) - xhat * mean(dq * xhat))   (training-mode BN backward)
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
-    int mode, int C, long L, int K, int relu, const float *__restrict__ x, const float *__restrict__ dy,
+    int mode, int C, long L, int K, int relu, int vec, const float *__restrict__ x, const float *__restrict__ dy,
     const unsigned char *__restrict__ arg, const float *__restrict__ mean, const float *__restrict__ invstd,
     const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ mean_dq,
     const float *__restrict__ mean_dq_xhat, float *__restrict__ dx)
@@ -210,20 +282,43 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
     const float ma = mean_dq[c], mb = mean_dq_xhat[c], gi = __fmul_rn(g, is);
     const float *xr = x + (size_t)bc * L;
     float *dr = dx + (size_t)bc * L;
+    auto one = [&](float xv, float d) {
+        const float xh = __fmul_rn(__fsub_rn(xv, m), is);
+        if (relu && !(__fadd_rn(__fmul_rn(xh, g), bt) > 0.f)) d = 0.f;
+        return gi * (d - ma - xh * mb);
+    };
+    if (vec) {  // L % 4 == 0, K % 4 == 0 in mode 1: the four elements share their pooled position
+        const unsigned Lu = (unsigned)L, Ku = (unsigned)K;
+        for (unsigned i = (blockIdx.x * BN_THREADS + threadIdx.x) * 4u; i < Lu; i += gridDim.x * BN_THREADS * 4u) {
+            const float4 x4 = *reinterpret_cast<const float4 *>(xr + i);
+            float4 d4;
+            if (mode == 0) {
+                d4 = *reinterpret_cast<const float4 *>(dy + (size_t)bc * L + i);
+            } else {
+                const unsigned q = i / Ku, k0 = i - q * Ku;
+                const size_t qq = (size_t)bc * (Lu / Ku) + q;
+                const unsigned ak = arg[qq];
+                const float dv = (ak - k0) < 4u ? dy[qq] : 0.f;
+                d4.x = ak == k0 ? dv : 0.f; d4.y = ak == k0 + 1 ? dv : 0.f;
+                d4.z = ak == k0 + 2 ? dv : 0.f; d4.w = ak == k0 + 3 ? dv : 0.f;
+            }
+            float4 o;
+            o.x = one(x4.x, d4.x); o.y = one(x4.y, d4.y); o.z = one(x4.z, d4.z); o.w = one(x4.w, d4.w);
+            *reinterpret_cast<float4 *>(dr + i) = o;
+        }
+        return;
+    }
     for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < L; i += (long)gridDim.x * BN_THREADS) {
-        const float xh = __fmul_rn(__fsub_rn(xr[i], m), is);
         float d;
         if (mode == 0) {
             d = dy[(size_t)bc * L + i];
-            if (relu && !(__fadd_rn(__fmul_rn(xh, g), bt) > 0.f)) d = 0.f;
         } else {
             const long q = i / K;
             const int k = (int)(i - q * K);
             const size_t qq = (size_t)bc * (L / K) + q;
             d = k == (int)arg[qq] ? dy[qq] : 0.f;
-            if (relu && !(__fadd_rn(__fmul_rn(xh, g), bt) > 0.f)) d = 0.f;
         }
-        dr[i] = gi * (d - ma - xh * mb);
+        dr[i] = one(xr[i], d);
     }
 }
 
@@ -235,16 +330,23 @@ using namespace amc;
 
 AMC_API size_t amc3d_bn_workspace_bytes(int C) { return (size_t)C * BN_MAX_CHUNKS * 2 * sizeof(double); }
 
-static int bn_chunks(int B, int C, long L)
+static BnSplit bn_split(int B, int C, long Lq)
 {
-    // enough workgroups to fill the chip (>= ~1024) without making the per-channel tail pass long
-    long want = (1024 + C - 1) / C;
-    const long cap = ((long)B * L + 4095) / 4096;
-    if (want > cap) want = cap;
-    if (want < 1) want = 1;
-    if (want > BN_MAX_CHUNKS) want = BN_MAX_CHUNKS;
-    return (int)want;
+    // enough workgroups to fill the chip (>= ~2048) with segments of at least 4096 positions
+    BnSplit sp;
+    long want = (2048 + C - 1) / C;                  // workgroups per channel
+    long cps = (want + B - 1) / B;                   // segments per cloud
+    const long cap = Lq / 4096 > 1 ? Lq / 4096 : 1;
+    if (cps > cap) cps = cap;
+    if (cps < 1) cps = 1;
+    sp.seg = ((Lq + cps - 1) / cps + 3) & ~3L;
+    sp.cps = (int)((Lq + sp.seg - 1) / sp.seg);
+    sp.units = B * sp.cps;
+    sp.nchunks = sp.units < BN_MAX_CHUNKS ? sp.units : BN_MAX_CHUNKS;
+    return sp;
 }
+
+static int aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 // statistics of x (B, C, L): mean, invstd = 1/sqrt(var_biased + eps), var_unbiased (for running_var)
 AMC_API int amc3d_bn_stats(int B, int C, long L, float eps, const float *x, float *mean, float *invstd,
@@ -254,8 +356,11 @@ AMC_API int amc3d_bn_stats(int B, int C, long L, float eps, const float *x, floa
     if (!x || !mean || !invstd || !var_unbiased || !workspace || workspace_bytes < amc3d_bn_workspace_bytes(C))
         return bad_arg("amc3d_bn_stats: bad argument");
     hipStream_t stream = (hipStream_t)stream_;
-    const int nchunks = bn_chunks(B, C, L);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(nchunks, C), dim3(BN_THREADS), 0, stream, B, C, L, x, (double *)workspace);
+    const BnSplit sp = bn_split(B, C, L);
+    const int nchunks = sp.nchunks;
+    const int vec = (L % 4 == 0) && aligned16(x);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nchunks, C), dim3(BN_THREADS), 0, stream, B, C, L, sp, vec, x,
+                       (double *)workspace);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(div_up(C, 64)), dim3(64), 0, stream, C, nchunks, (double)B * (double)L,
                        eps, (const double *)workspace, mean, invstd, var_unbiased);
     return launch_status("amc3d_bn_stats");
@@ -281,6 +386,16 @@ AMC_API int amc3d_bn_max(int B, int C, int M, int K, int relu, const float *x, c
     if (B <= 0 || C <= 0 || M <= 0) return 0;
     if (K <= 0 || K > 255 || !x || !mean || !invstd || !gamma || !beta || !y || !arg)
         return bad_arg("amc3d_bn_max: bad argument (K must be in 1..255)");
+    const int lpr = K / 4;
+    if (K % 4 == 0 && (lpr == 2 || lpr == 4 || lpr == 8 || lpr == 16) && aligned16(x)) {
+        const int gx = (int)min((long)div_up((long)M * lpr, BN_THREADS * 4), 65535L);
+#define AMC_BNMAX(N)                                                                                                   \
+    hipLaunchKernelGGL(bn_max_coop_kernel<N>, dim3(gx, B * C), dim3(BN_THREADS), 0, (hipStream_t)stream, C, M, relu, x, \
+                       mean, invstd, gamma, beta, y, arg)
+        if (lpr == 2) AMC_BNMAX(2); else if (lpr == 4) AMC_BNMAX(4); else if (lpr == 8) AMC_BNMAX(8); else AMC_BNMAX(16);
+#undef AMC_BNMAX
+        return launch_status("amc3d_bn_max");
+    }
     hipLaunchKernelGGL(bn_max_kernel, dim3(div_up(M, BN_THREADS), B * C), dim3(BN_THREADS), 0, (hipStream_t)stream, C, M,
                        K, relu, x, mean, invstd, gamma, beta, y, arg);
     return launch_status("amc3d_bn_max");
@@ -300,17 +415,19 @@ AMC_API int amc3d_bn_backward(int B, int C, long L, int K, int relu, const float
         return bad_arg("amc3d_bn_backward: bad argument");
     hipStream_t stream = (hipStream_t)stream_;
     const int mode = arg ? 1 : 0;
-    const int nchunks = bn_chunks(B, C, mode ? L / K : L);
+    const BnSplit sp = bn_split(B, C, mode ? L / K : L);
+    const int nchunks = sp.nchunks;
+    const int vec = (L % 4 == 0) && (K % 4 == 0 || !mode) && aligned16(x) && aligned16(dy) && aligned16(dx) && L < (1L << 31);
     double *partial = (double *)workspace;
     float *mean_dq = (float *)((char *)workspace + amc3d_bn_workspace_bytes(C));
     float *mean_dqx = mean_dq + C;
-    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nchunks, C), dim3(BN_THREADS), 0, stream, mode, B, C, L, K, relu, x, dy,
-                       arg, mean, invstd, gamma, beta, partial);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nchunks, C), dim3(BN_THREADS), 0, stream, mode, B, C, L, K, relu, sp, vec, x,
+                       dy, arg, mean, invstd, gamma, beta, partial);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(div_up(C, 64)), dim3(64), 0, stream, C, nchunks,
                        (double)B * (double)L, (const double *)partial, dgamma, dbeta, mean_dq, mean_dqx);
-    const long per_block = BN_THREADS * 8;
+    const long per_block = BN_THREADS * 16;
     const int gx = (int)min((L + per_block - 1) / per_block, (long)4096);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, stream, mode, C, L, K, relu, x, dy, arg,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, stream, mode, C, L, K, relu, vec, x, dy, arg,
                        mean, invstd, gamma, beta, mean_dq, mean_dqx, dx);
     return launch_status("amc3d_bn_backward");
 }

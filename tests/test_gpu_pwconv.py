@@ -75,7 +75,7 @@ def test_model_blocks_route_1x1_convs_to_the_kernel():
     from openpoints.models.layers import create_convblock1d, run_convblocks
     blk = torch.nn.Sequential(create_convblock1d(8, 16, norm_args={'norm': 'bn'}, act_args={'act': 'relu'}),
                               create_convblock1d(16, 5, norm_args=None, act_args=None)).to(DEV)
-    x = torch.randn(2, 8, 300, device=DEV)
+    x = torch.randn(2, 8, 20000, device=DEV)  # wide enough for the shape heuristic (blocks._pw_pays)
     timing.enable(True)
     try:
         y = run_convblocks(blk, x)
