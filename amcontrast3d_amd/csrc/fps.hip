@@ -27,6 +27,8 @@
 // RB = opt_n_threads(n).  The sorted layout here has nothing to do with k, so whenever the maximum is
 // attained by more than one point (detected per lane, per wave and per workgroup) the iteration takes
 // a slow path that evaluates exactly that key order over all tied points.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace amc {
@@ -108,8 +110,8 @@ struct FpsRecord {  // one per wave and iteration parity, 32 bytes
     float x, y, z, pad2;
 };
 
-template <int PPT, int NG>
-__global__ __launch_bounds__(512) void fps_kernel(int n, int m, int log2rb, const float *__restrict__ dataset,
+template <int PPT, int NG, int MAXT = 512>
+__global__ __launch_bounds__(MAXT) void fps_kernel(int n, int m, int log2rb, const float *__restrict__ dataset,
                                                    float *__restrict__ temp, int *__restrict__ idxs,
                                                    int *__restrict__ perm_ws)
 {
@@ -329,6 +331,15 @@ __global__ __launch_bounds__(512) void fps_kernel(int n, int m, int log2rb, cons
             AMC_FPS_CASE(30) AMC_FPS_CASE(31) AMC_FPS_CASE(32) AMC_FPS_CASE(33) AMC_FPS_CASE(34) AMC_FPS_CASE(35)
             AMC_FPS_CASE(36) AMC_FPS_CASE(37) AMC_FPS_CASE(38) AMC_FPS_CASE(39) AMC_FPS_CASE(40) AMC_FPS_CASE(41)
             AMC_FPS_CASE(42) AMC_FPS_CASE(43) AMC_FPS_CASE(44) AMC_FPS_CASE(45) AMC_FPS_CASE(46) AMC_FPS_CASE(47)
+            AMC_FPS_CASE(48) AMC_FPS_CASE(49) AMC_FPS_CASE(50) AMC_FPS_CASE(51) AMC_FPS_CASE(52) AMC_FPS_CASE(53)
+            AMC_FPS_CASE(54) AMC_FPS_CASE(55) AMC_FPS_CASE(56) AMC_FPS_CASE(57) AMC_FPS_CASE(58) AMC_FPS_CASE(59)
+            AMC_FPS_CASE(60) AMC_FPS_CASE(61) AMC_FPS_CASE(62) AMC_FPS_CASE(63) AMC_FPS_CASE(64) AMC_FPS_CASE(65)
+            AMC_FPS_CASE(66) AMC_FPS_CASE(67) AMC_FPS_CASE(68) AMC_FPS_CASE(69) AMC_FPS_CASE(70) AMC_FPS_CASE(71)
+            AMC_FPS_CASE(72) AMC_FPS_CASE(73) AMC_FPS_CASE(74) AMC_FPS_CASE(75) AMC_FPS_CASE(76) AMC_FPS_CASE(77)
+            AMC_FPS_CASE(78) AMC_FPS_CASE(79) AMC_FPS_CASE(80) AMC_FPS_CASE(81) AMC_FPS_CASE(82) AMC_FPS_CASE(83)
+            AMC_FPS_CASE(84) AMC_FPS_CASE(85) AMC_FPS_CASE(86) AMC_FPS_CASE(87) AMC_FPS_CASE(88) AMC_FPS_CASE(89)
+            AMC_FPS_CASE(90) AMC_FPS_CASE(91) AMC_FPS_CASE(92) AMC_FPS_CASE(93) AMC_FPS_CASE(94) AMC_FPS_CASE(95)
+           
 #undef AMC_FPS_CASE
             default: break;
         }
@@ -470,11 +481,11 @@ __global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, const flo
     }
 }
 
-template <int PPT, int NG>
+template <int PPT, int NG, int MAXT = 512>
 static int launch_fps(int b, int n, int m, int waves, int log2rb, const float *dataset, float *temp, int *idxs,
                       int *perm, hipStream_t stream)
 {
-    hipLaunchKernelGGL((fps_kernel<PPT, NG>), dim3(b), dim3(waves * 64), 0, stream, n, m, log2rb, dataset, temp, idxs,
+    hipLaunchKernelGGL((fps_kernel<PPT, NG, MAXT>), dim3(b), dim3(waves * 64), 0, stream, n, m, log2rb, dataset, temp, idxs,
                        perm);
     return launch_status("amc3d_furthest_point_sampling");
 }
@@ -512,6 +523,8 @@ AMC_API int amc3d_furthest_point_sampling(int b, int n, int m, const float *data
         while (w < 8 && w * 64 * ppt < n) w <<= 1;
         return w;
     };
+    static const int variant = getenv("AMC3D_FPS_VARIANT") ? atoi(getenv("AMC3D_FPS_VARIANT")) : 0;
+    if (n > 12288 && variant == 1) return launch_fps<96, 12, 256>(b, n, m, 4, log2rb, dataset, temp, idxs, perm, stream);
     if (n > 12288) return launch_fps<48, 6>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
     if (n > 6144) return launch_fps<24, 3>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
     if (n > 3072) return launch_fps<12, 3>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);

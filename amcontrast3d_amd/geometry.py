@@ -71,6 +71,19 @@ def precompute_fps(model, data):
 
 
 @torch.no_grad()
+def precompute_fps_levels(model, p, first, last):
+    """Levels [first, last) of the sampling chain starting from the cloud `p` that level `first` samples
+    (data['pos'] for first == 0, the previous level's 'new_p' otherwise)."""
+    m = _unwrap(model)
+    out = []
+    for stage in list(m.encoder.encoder)[first:last]:
+        g = stage[0].plan_sample(p)
+        out.append(g)
+        p = g["new_p"]
+    return out
+
+
+@torch.no_grad()
 def precompute_rest(model, contrast_head, data, fps, num_classes, ignore_index, ambiguity_args):
     """Everything that hangs off a finished sampling `fps` (from precompute_fps): ball queries, relative
     positions, 3-NN, loss geometry.  -> a full plan whose per-stage dicts also hold fps's tensors."""

@@ -131,8 +131,9 @@ def main():
     # Software pipeline over consecutive batches.  The coordinate-only half of a step
     # (amcontrast3d_amd/geometry.py) does not depend on features or weights, so it runs ahead, on two side
     # streams, while the current batch runs its feature half on the main stream:
-    #     stream A  sampling of batch t+2            : the FPS chain (one workgroup per cloud: 8 of 256 CUs
-    #               for ~14 ms)
+    #     stream A1 first sampling level of batch t+3: FPS 24000 -> 6000 (one workgroup per cloud: 8 of the
+    #               256 CUs for ~12 ms, a chain of 6000 dependent iterations)
+    #     stream A2 sampling levels 2-4 of batch t+2   : FPS 6000 -> 1500 -> 375 -> 93 (~2.5 ms, same shape)
     #     stream B  neighbourhoods of batch t+1      : ball queries, relative positions, 3-NN, and the loss
     #               geometry (k-NN, class votes, positive masks, ambiguities)
     #     main      features of batch t            : forward, loss, backward (+ all-reduce, clip, AdamW)
@@ -145,18 +146,24 @@ def main():
     main_s = torch.cuda.Stream()  # all work of this process runs on non-default streams (capture recipe)
     main_s.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(main_s)
-    s_a, s_b = torch.cuda.Stream(), torch.cuda.Stream()
+    s_a, s_a2, s_b = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
     head = criterion.contrast_head
+    nlevels = len(list((model.module if hasattr(model, "module") else model).encoder.encoder))
 
-    def geo_fps():
-        return geometry.precompute_fps(model, data)
+    def geo_fps_first():  # encoder stage 0 is the stride-1 stem (no sampling); stage 1 holds the first FPS
+        return geometry.precompute_fps_levels(model, data["pos"], 0, 2)
+
+    def geo_fps_tail(first_level):
+        return geometry.precompute_fps_levels(model, first_level[-1]["new_p"], 2, nlevels)
 
     def geo_rest(fps):
         return geometry.precompute_rest(model, head, data, fps, 13, None, aargs)
 
     if overlap:
-        a_out = geo_fps()                      # written by stream A (batch t+2): the FPS chain only
-        a_stable = geometry.clone(a_out)       # batch t+1: read by stream B
+        a1_out = geo_fps_first()               # written by stream A1 (batch t+3): first FPS level
+        a1_stable = geometry.clone(a1_out)     # batch t+2: read by stream A2
+        a2_out = geo_fps_tail(a1_stable)       # written by stream A2 (batch t+2): FPS levels 2..4
+        a_stable = geometry.clone(a1_stable + a2_out)  # batch t+1: read by stream B
         b_full = geo_rest(a_stable)            # stream B (batch t+1): neighbourhoods, 3-NN, loss geometry
         b_out = geometry.split(b_full)[1]
         cur = geometry.clone(b_full)           # batch t: read by the feature half
@@ -167,10 +174,14 @@ def main():
     def rotate():  # main stream, between steps: advance the pipeline buffers by one batch
         geometry.copy_into(cur_fps, a_stable)
         geometry.copy_into(cur_rest, b_out)
-        geometry.copy_into(a_stable, a_out)
+        geometry.copy_into(a_stable, a1_stable + a2_out)
+        geometry.copy_into(a1_stable, a1_out)
 
     def body_a():
-        geometry.copy_into(a_out, geo_fps())
+        geometry.copy_into(a1_out, geo_fps_first())
+
+    def body_a2():
+        geometry.copy_into(a2_out, geo_fps_tail(a1_stable))
 
     def body_b():
         geometry.copy_into(b_out, geometry.split(geo_rest(a_stable))[1])
@@ -179,15 +190,19 @@ def main():
         torch.nn.utils.clip_grad_norm_(params, 10, norm_type=2)
         opt.step()
 
-    def run_step(f_rotate, f_a, f_b, f_feat, f_update):
+    def run_step(f_rotate, f_a, f_a2, f_b, f_feat, f_update):
         if overlap:
             main_s.wait_stream(s_a)
+            main_s.wait_stream(s_a2)
             main_s.wait_stream(s_b)
             f_rotate()
             s_a.wait_stream(main_s)
+            s_a2.wait_stream(main_s)
             s_b.wait_stream(main_s)
             with torch.cuda.stream(s_a):
                 f_a()
+            with torch.cuda.stream(s_a2):
+                f_a2()
             with torch.cuda.stream(s_b):
                 f_b()
         f_feat()
@@ -197,17 +212,17 @@ def main():
 
     def eager_step():
         opt.zero_grad(set_to_none=True)
-        run_step(rotate, body_a, body_b, fwd_bwd, update)
+        run_step(rotate, body_a, body_a2, body_b, fwd_bwd, update)
 
     step = eager_step
     if use_graph:
         # PyTorch's whole-network capture recipe, one graph per pipeline part: ~700 launches per step
-        # become 5 graph launches
+        # become 6 graph launches
         for _ in range(3):
             eager_step()
         torch.cuda.synchronize()
         opt.zero_grad(set_to_none=True)
-        graphs = {k: torch.cuda.CUDAGraph() for k in ("rotate", "a", "b", "feat", "update")}
+        graphs = {k: torch.cuda.CUDAGraph() for k in ("rotate", "a", "a2", "b", "feat", "update")}
         cap = torch.cuda.Stream()
         with torch.cuda.graph(graphs["feat"], stream=cap):
             fwd_bwd()
@@ -218,12 +233,14 @@ def main():
                 rotate()
             with torch.cuda.graph(graphs["a"], stream=cap):
                 body_a()
+            with torch.cuda.graph(graphs["a2"], stream=cap):
+                body_a2()
             with torch.cuda.graph(graphs["b"], stream=cap):
                 body_b()
         torch.cuda.synchronize()
 
         def step():
-            run_step(graphs["rotate"].replay, graphs["a"].replay, graphs["b"].replay, graphs["feat"].replay,
+            run_step(graphs["rotate"].replay, graphs["a"].replay, graphs["a2"].replay, graphs["b"].replay, graphs["feat"].replay,
                      graphs["update"].replay)
 
     for _ in range(args.warmup):
@@ -253,7 +270,8 @@ def main():
             torch.cuda.synchronize()
             return round((time.perf_counter() - t) / reps * 1e3, 3)
         parts = {"features_ms": alone(graphs["feat"].replay, main_s), "update_ms": alone(graphs["update"].replay, main_s),
-                 "fps_chain_ms": alone(graphs["a"].replay, s_a), "neighbourhood_geometry_ms": alone(graphs["b"].replay, s_b),
+                 "fps_level1_ms": alone(graphs["a"].replay, s_a), "fps_levels2to4_ms": alone(graphs["a2"].replay, s_a2),
+                 "neighbourhood_geometry_ms": alone(graphs["b"].replay, s_b),
                  "rotate_ms": alone(graphs["rotate"].replay, main_s)}
 
     # per-operator HIP-event timing: the same step, launched eagerly so each C-ABI launch can be
@@ -309,7 +327,8 @@ def main():
                        "global_batch": args.batch * world, "points": args.points,
                        "parallelism": f"dp{world}" + ("+syncbn+ddp" if use_ddp else ""),
                        "launch": "hipGraph replay (fwd+loss+bwd | clip+AdamW)" if use_graph else "eager",
-                       "pipeline": "3 streams: FPS chain (t+2) | neighbourhood + loss geometry (t+1) | features (t)"
+                       "pipeline": "4 streams: FPS level 1 (t+3) | FPS levels 2-4 (t+2) | neighbourhood + loss geometry (t+1) | "
+                                   "features (t)"
                                    if overlap_was else "none"},
             "loss": round(final_loss, 6),
             "roofline": roofline,
