@@ -16,6 +16,8 @@
 // later (the root only decreases), so the heap sees the same insert sequence as
 // the reference's sequential scan.  The 16 waves of a workgroup share LDS tiles
 // of the support cloud.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace amc {
@@ -122,10 +124,13 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_exact_kernel(
 
 
 // One WORKGROUP per listed query (the grid path's tie fallback: a handful of queries per call, each of
-// which must see its whole segment in index order).  All 1024 threads test one candidate each per step;
-// the heap only changes on the rare steps where some candidate beats the current root (a conservative
-// test against the root at the start of the step: the root only decreases), and only then wave 0 replays
-// those candidates in ascending index order against the heap in LDS.
+// which must see its whole segment in index order).  The segment is consumed in steps whose size doubles from
+// 64 up to 4096 candidates (4 per thread): every thread tests its candidates against the heap root as it was
+// at the start of the step (conservative: the root only decreases), and only the survivors are replayed by
+// wave 0 in ascending index order against the heap in LDS.  While a step is as long as everything seen
+// before it, about k of its candidates survive, so the serial part stays at ~k per step instead of the whole
+// first step; the loads of the next step are issued before the barriers of the current one.
+constexpr int KXL_PER = 4;  // candidates per thread and step
 __global__ __launch_bounds__(1024) void knn_exact_list_kernel(
     int nsample, int nbatch, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
     const int *__restrict__ offset, const int *__restrict__ new_offset, int *__restrict__ idx,
@@ -133,8 +138,8 @@ __global__ __launch_bounds__(1024) void knn_exact_list_kernel(
 {
     __shared__ float hd[KNN_MAXK];
     __shared__ int hi[KNN_MAXK];
-    __shared__ float s_d2[1024];
-    __shared__ unsigned long long s_mask[16];
+    __shared__ float s_d2[1024 * KXL_PER];
+    __shared__ unsigned long long s_mask[KXL_PER][16];
     __shared__ float s_root;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int total = *qcount;
@@ -148,30 +153,56 @@ __global__ __launch_bounds__(1024) void knn_exact_list_kernel(
         for (int i = threadIdx.x; i < nsample; i += 1024) { hd[i] = 1e10f; hi[i] = start; }
         if (threadIdx.x == 0) s_root = 1e10f;
         __syncthreads();
-        for (int i0 = start; i0 < end; i0 += 1024) {
-            const int i = i0 + threadIdx.x;
-            const bool valid = i < end;
-            const int ii = valid ? i : start;
-            const float d2 = dist2_ref(qx, qy, qz, xyz[(size_t)ii * 3], xyz[(size_t)ii * 3 + 1], xyz[(size_t)ii * 3 + 2]);
-            const bool pass = valid && d2 < s_root;
-            if (__syncthreads_or(pass)) {
-                s_d2[threadIdx.x] = d2;
-                const unsigned long long m = __ballot(pass);
-                if (lane == 0) s_mask[wave] = m;
+
+        auto step_len = [&](int pos) { return min(1024 * KXL_PER, max(64, pos - start)); };
+        float px[KXL_PER], py[KXL_PER], pz[KXL_PER];
+        auto load = [&](int pos, int len) {
+#pragma unroll
+            for (int j = 0; j < KXL_PER; ++j) {
+                const int o = j * 1024 + (int)threadIdx.x;
+                const int i = (o < len && pos + o < end) ? pos + o : start;
+                px[j] = xyz[(size_t)i * 3]; py[j] = xyz[(size_t)i * 3 + 1]; pz[j] = xyz[(size_t)i * 3 + 2];
+            }
+        };
+        int pos = start, len = step_len(start);
+        if (pos < end) load(pos, len);
+        while (pos < end) {
+            const float root0 = s_root;
+            float d2[KXL_PER];
+            bool pass[KXL_PER], any = false;
+#pragma unroll
+            for (int j = 0; j < KXL_PER; ++j) {
+                const int o = j * 1024 + (int)threadIdx.x;
+                d2[j] = dist2_ref(qx, qy, qz, px[j], py[j], pz[j]);
+                pass[j] = o < len && pos + o < end && d2[j] < root0;
+                any |= pass[j];
+            }
+            const int npos = pos + len, nlen = step_len(npos);
+            if (npos < end) load(npos, nlen);  // in flight across the barriers below
+            if (__syncthreads_or(any)) {
+#pragma unroll
+                for (int j = 0; j < KXL_PER; ++j) {
+                    s_d2[j * 1024 + threadIdx.x] = d2[j];
+                    const unsigned long long mk = __ballot(pass[j]);
+                    if (lane == 0) s_mask[j][wave] = mk;
+                }
                 __syncthreads();
-                if (wave == 0) {  // ascending index order: wave by wave, bit by bit
-                    float root = s_root;
-                    for (int w = 0; w < 16; ++w) {
-                        unsigned long long mm = s_mask[w];
-                        while (mm) {
-                            const int b = (int)__builtin_ctzll(mm);
-                            mm &= mm - 1;
-                            const float cd = s_d2[w * 64 + b];
-                            if (cd < root) {  // knnquery_cuda_kernel.cu:97-101
-                                hd[0] = cd;
-                                hi[0] = i0 + w * 64 + b;
-                                reheap(hd, hi, nsample);
-                                root = hd[0];
+                if (wave == 0) {  // ascending index order: slab by slab, wave by wave, bit by bit
+                    float root = root0;
+                    for (int j = 0; j < KXL_PER; ++j) {
+                        for (int w = 0; w < 16; ++w) {
+                            unsigned long long mm = s_mask[j][w];
+                            while (mm) {
+                                const int b = (int)__builtin_ctzll(mm);
+                                mm &= mm - 1;
+                                const int o = j * 1024 + w * 64 + b;
+                                const float cd = s_d2[o];
+                                if (cd < root) {  // knnquery_cuda_kernel.cu:97-101
+                                    hd[0] = cd;
+                                    hi[0] = pos + o;
+                                    reheap(hd, hi, nsample);
+                                    root = hd[0];
+                                }
                             }
                         }
                     }
@@ -179,6 +210,8 @@ __global__ __launch_bounds__(1024) void knn_exact_list_kernel(
                 }
                 __syncthreads();
             }
+            pos = npos;
+            len = nlen;
         }
         if (wave == 0) {
             for (int i = nsample - 1; i > 0; i--) {  // knnquery_cuda_kernel.cu:39-48
@@ -326,16 +359,24 @@ __device__ __forceinline__ void ll_init(LaneList &l, int start)
     l.tau = 1e10f;
 }
 
+// value of the lane below (lane 0 keeps its own): ONE v_mov_b32_dpp wave_shr:1 (the gfx9 whole-wave shift),
+// not a ds_bpermute round trip through the LDS crossbar -- the insertion below is a dependent chain
+__device__ __forceinline__ int lane_below_i32(int x)
+{
+    return __builtin_amdgcn_update_dpp(x, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float lane_below_f32(float x) { return __int_as_float(lane_below_i32(__float_as_int(x))); }
+
 // insert (cd, ci), cd < tau, keeping ascending order; returns the evicted k-th value
 __device__ __forceinline__ float ll_insert(LaneList &l, int k, int lane, float cd, int ci)
 {
     const float evicted = l.tau;
     const int p = (int)__popcll(__ballot(lane < k && l.v <= cd));  // first lane with v > cd
-    const float upv = __shfl_up(l.v, 1, 64);
-    const int upi = __shfl_up(l.id, 1, 64);
+    const float upv = lane_below_f32(l.v);
+    const int upi = lane_below_i32(l.id);
     if (lane > p) { l.v = upv; l.id = upi; }
     if (lane == p) { l.v = cd; l.id = ci; }
-    l.tau = __shfl(l.v, k - 1, 64);
+    l.tau = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l.v), k - 1));
     return evicted;
 }
 
@@ -349,8 +390,8 @@ __device__ __forceinline__ void ll_feed(LaneList &l, int k, int lane, bool valid
     while (mask) {
         const int b = (int)__builtin_ctzll(mask);
         mask &= mask - 1;
-        const float cd = __shfl(d2, b, 64);
-        const int cc = __shfl(ci, b, 64);
+        const float cd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), b));  // wave-uniform (SGPR)
+        const int cc = __builtin_amdgcn_readlane(ci, b);
         if (cd < l.tau) rej_uni = fminf(rej_uni, ll_insert(l, k, lane, cd, cc));
         else rej_uni = fminf(rej_uni, cd);
     }
@@ -359,8 +400,7 @@ __device__ __forceinline__ void ll_feed(LaneList &l, int k, int lane, bool valid
 // ---- calibration: k-th neighbour distance of KG_SAMPLES queries, estimated on every 8th support point
 // (the (k/8)-th neighbour among 1/8 of the points sits at about the same radius; h only steers speed,
 // never results, so an estimate is enough) -----------------------------------------------------------
-constexpr int KG_SUB = 8;
-__global__ __launch_bounds__(1024) void kg_sample_kernel(int m, int k, int nb, const float *__restrict__ xyz,
+__global__ __launch_bounds__(1024) void kg_sample_kernel(int m, int k, int nb, int KG_SUB, const float *__restrict__ xyz,
                                                          const float *__restrict__ new_xyz,
                                                          const int *__restrict__ offset,
                                                          const int *__restrict__ new_offset, float *__restrict__ samples)
@@ -399,7 +439,7 @@ __global__ __launch_bounds__(1024) void kg_sample_kernel(int m, int k, int nb, c
     }
 }
 
-__global__ __launch_bounds__(64) void kg_params_kernel(int n, int nb, const int *__restrict__ bbox,
+__global__ __launch_bounds__(64) void kg_params_kernel(int n, int nb, float hscale, const int *__restrict__ bbox,
                                                        const float *__restrict__ samples, GridParams *__restrict__ gp)
 {
     const int lane = threadIdx.x;
@@ -416,7 +456,7 @@ __global__ __launch_bounds__(64) void kg_params_kernel(int n, int nb, const int 
     const float ex = fmaxf(ord2f(bbox[3]) - minx, 0.f), ey = fmaxf(ord2f(bbox[4]) - miny, 0.f),
                 ez = fmaxf(ord2f(bbox[5]) - minz, 0.f);
     const float emax = fmaxf(fmaxf(ex, ey), fmaxf(ez, 1e-30f));
-    float h = 1.1f * sqrtf(r2);
+    float h = hscale * sqrtf(r2);
     if (!(r2 < 1e9f) || !(h > emax * 1e-6f)) h = emax;  // fewer than k points, or all points coincide
     const float cap = (float)(knn_cell_cap(n) / (nb > 0 ? nb : 1));
     // grow h until the grid fits the cell budget (float arithmetic: no int overflow on huge extents)
@@ -553,6 +593,36 @@ __device__ __forceinline__ void kg_scan_range(LaneList &l, int k, int lane, int 
     }
 }
 
+__device__ __forceinline__ void kg_scan_packed(LaneList &l, int k, int lane, int b, int len, float qx, float qy, float qz,
+                                               const float4 *__restrict__ sorted, float &rl, float &ru)
+{
+    int incl = len;
+    for (int s = 1; s < 64; s <<= 1) {
+        const int o = __shfl_up(incl, s, 64);
+        if (lane >= s) incl += o;
+    }
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    const int excl = incl - len;
+    const unsigned long long runs = __ballot(len > 0);
+    for (int c0 = 0; c0 < total; c0 += 64) {
+        const int c = c0 + lane;
+        int base = 0;
+        unsigned long long rm = runs;
+        while (rm) {
+            const int src = (int)__builtin_ctzll(rm);
+            rm &= rm - 1;
+            const int e0 = __builtin_amdgcn_readlane(excl, src);
+            if (e0 >= c0 + 64) break;  // later runs start beyond this step (wave-uniform)
+            const int b0 = __builtin_amdgcn_readlane(b, src);
+            base = c >= e0 ? b0 - e0 : base;
+        }
+        const bool valid = c < total;
+        const float4 p = sorted[valid ? base + c : __builtin_amdgcn_readfirstlane(base + c)];
+        const float d2 = dist2_ref(qx, qy, qz, p.x, p.y, p.z);
+        ll_feed(l, k, lane, valid, d2, __float_as_int(p.w), rl, ru);
+    }
+}
+
 __global__ __launch_bounds__(256) void kg_query_kernel(int m, int k, int nb, const float *__restrict__ new_xyz,
                                                        const int *__restrict__ offset,
                                                        const int *__restrict__ new_offset,
@@ -599,18 +669,11 @@ __global__ __launch_bounds__(256) void kg_query_kernel(int m, int k, int nb, con
                         }
                     }
                 }
-                unsigned long long mA = __ballot(eA > bA);
-                while (mA) {
-                    const int src = (int)__builtin_ctzll(mA);
-                    mA &= mA - 1;
-                    kg_scan_range(l, k, lane, __shfl(bA, src, 64), __shfl(eA, src, 64), qx, qy, qz, sorted, rl, ru);
-                }
-                unsigned long long mB = __ballot(eB > bB);
-                while (mB) {
-                    const int src = (int)__builtin_ctzll(mB);
-                    mB &= mB - 1;
-                    kg_scan_range(l, k, lane, __shfl(bB, src, 64), __shfl(eB, src, 64), qx, qy, qz, sorted, rl, ru);
-                }
+                // the runs are short (a few points per cell): feed them PACKED, 64 candidates per step, instead of
+                // one partly filled step per run.  Lane pi owns run pi; an exclusive scan of the run lengths gives
+                // every candidate slot c its run (the last one whose first slot is <= c) and its place in it.
+                kg_scan_packed(l, k, lane, bA, eA - bA, qx, qy, qz, sorted, rl, ru);
+                if (R > 1) kg_scan_packed(l, k, lane, bB, eB - bB, qx, qy, qz, sorted, rl, ru);
             }
             // everything outside the scanned block is at least `dmin` away (sides that coincide with
             // the grid boundary impose nothing: there are no points beyond it)
@@ -686,9 +749,12 @@ AMC_API int amc3d_knnquery(int m, int nsample, int n, int nbatch, const float *x
     if (int st = fill_i32(cursor, 0, cells, stream)) return st;
     hipLaunchKernelGGL(kg_init_kernel, dim3(1), dim3(64), 0, stream, bbox, fb_count);
     hipLaunchKernelGGL(kg_bbox_kernel, dim3(min(div_up(n, 256), 64)), dim3(256), 0, stream, n, xyz, bbox);
-    hipLaunchKernelGGL(kg_sample_kernel, dim3(KG_SAMPLES), dim3(1024), 0, stream, m, (nsample + KG_SUB - 1) / KG_SUB + 1,
-                       nbatch, xyz, new_xyz, offset, new_offset, samples);
-    hipLaunchKernelGGL(kg_params_kernel, dim3(1), dim3(64), 0, stream, n, nbatch, bbox, samples, gp);
+    static const int kg_sub = getenv("AMC3D_KG_SUB") ? atoi(getenv("AMC3D_KG_SUB")) : 8;
+    static const int kg_extra = getenv("AMC3D_KG_EXTRA") ? atoi(getenv("AMC3D_KG_EXTRA")) : 1;
+    static const float kg_scale = getenv("AMC3D_KG_SCALE") ? (float)atof(getenv("AMC3D_KG_SCALE")) : 1.1f;
+    hipLaunchKernelGGL(kg_sample_kernel, dim3(KG_SAMPLES), dim3(1024), 0, stream, m, (nsample + kg_sub - 1) / kg_sub + kg_extra,
+                       nbatch, kg_sub, xyz, new_xyz, offset, new_offset, samples);
+    hipLaunchKernelGGL(kg_params_kernel, dim3(1), dim3(64), 0, stream, n, nbatch, kg_scale, bbox, samples, gp);
     hipLaunchKernelGGL(kg_count_kernel, dim3(div_up(n, 256)), dim3(256), 0, stream, n, nbatch, xyz, offset, gp,
                        cell_start);
     int *tile_sums = (int *)(base + w.tile_sums);
