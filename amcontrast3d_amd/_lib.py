@@ -11,6 +11,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _SO = os.environ.get("AMC3D_LIB") or os.path.join(_CSRC, "libamc3d_hip.so")  # AMC3D_LIB: diagnostic builds
 
 _vp, _i, _f, _sz, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_long
+_ll = ctypes.c_longlong
 
 # name -> (restype, argtypes); must list every symbol include/amc3d.h declares
 SIGNATURES = {
@@ -40,11 +41,15 @@ SIGNATURES = {
     "amc3d_grouped_conv_forward": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_grouped_conv_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "amc3d_grouped_conv_backward": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "amc3d_cross_entropy_workspace_bytes": (_sz, [_i, _l]),
+    "amc3d_cross_entropy_forward": (_i, [_i, _i, _l, _vp, _vp, _ll, _vp, _vp, _vp, _sz, _vp]),
+    "amc3d_cross_entropy_backward": (_i, [_i, _i, _l, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_pointwise_conv_forward": (_i, [_i, _i, _i, _l, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_pointwise_conv_workspace_bytes": (_sz, [_i, _i, _i, _l]),
     "amc3d_pointwise_conv_backward": (_i, [_i, _i, _i, _l, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_bn_workspace_bytes": (_sz, [_i]),
     "amc3d_bn_stats": (_i, [_i, _i, _l, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "amc3d_bn_update_running": (_i, [_i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_bn_act": (_i, [_i, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_bn_max": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_bn_backward": (_i, [_i, _i, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

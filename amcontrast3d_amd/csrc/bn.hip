@@ -322,6 +322,28 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
     }
 }
 
+// nn.BatchNorm bookkeeping in ONE launch (torch/nn/modules/batchnorm.py: num_batches_tracked += 1, then the
+// exponential -- or, momentum < 0 standing for None, cumulative -- moving average of mean and unbiased variance)
+__global__ __launch_bounds__(1024) void bn_running_kernel(int C, float momentum, const float *__restrict__ mean,
+                                                          const float *__restrict__ var_unbiased,
+                                                          float *__restrict__ running_mean,
+                                                          float *__restrict__ running_var, long long *__restrict__ tracked)
+{
+    const long long nt = *tracked + 1;
+    const float f = momentum < 0.f ? 1.f / (float)nt : momentum;
+    for (int c = threadIdx.x; c < C; c += 1024) {
+        if (momentum < 0.f) {
+            running_mean[c] += (mean[c] - running_mean[c]) * f;
+            running_var[c] += (var_unbiased[c] - running_var[c]) * f;
+        } else {
+            running_mean[c] = running_mean[c] * (1.f - f) + f * mean[c];  // running.mul_(1 - m).add_(batch, alpha=m)
+            running_var[c] = running_var[c] * (1.f - f) + f * var_unbiased[c];
+        }
+    }
+    __syncthreads();  // every thread has read the old counter
+    if (threadIdx.x == 0) *tracked = nt;
+}
+
 constexpr int BN_MAX_CHUNKS = 64;
 
 }  // namespace amc
@@ -430,4 +452,16 @@ AMC_API int amc3d_bn_backward(int B, int C, long L, int K, int relu, const float
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, stream, mode, C, L, K, relu, vec, x, dy, arg,
                        mean, invstd, gamma, beta, mean_dq, mean_dqx, dx);
     return launch_status("amc3d_bn_backward");
+}
+
+// running_mean / running_var / num_batches_tracked update of nn.BatchNorm in training mode; momentum < 0 = None
+AMC_API int amc3d_bn_update_running(int C, float momentum, const float *mean, const float *var_unbiased,
+                                    float *running_mean, float *running_var, long long *num_batches_tracked, void *stream)
+{
+    if (C <= 0) return 0;
+    if (!mean || !var_unbiased || !running_mean || !running_var || !num_batches_tracked)
+        return bad_arg("amc3d_bn_update_running: null pointer");
+    hipLaunchKernelGGL(bn_running_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, C, momentum, mean, var_unbiased,
+                       running_mean, running_var, num_batches_tracked);
+    return launch_status("amc3d_bn_update_running");
 }

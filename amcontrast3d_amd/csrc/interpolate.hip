@@ -68,7 +68,7 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(int n, int m,
 // out[b,c,p] = w0*points[b,c,i0] + w1*points[b,c,i1] + w2*points[b,c,i2], evaluated
 // left to right without contraction (interpolate_gpu.cu:103).  One thread per
 // (b,p) keeps idx/weight in registers and walks the channels: coalesced stores.
-__global__ void three_interpolate_kernel(int c, int m, int n, const float *__restrict__ points,
+__global__ void three_interpolate_kernel(int c, int m, int n, int ch_per, const float *__restrict__ points,
                                          const int *__restrict__ idx, const float *__restrict__ weight,
                                          float *__restrict__ out)
 {
@@ -81,7 +81,9 @@ __global__ void three_interpolate_kernel(int c, int m, int n, const float *__res
     const float w0 = ww[0], w1 = ww[1], w2 = ww[2];
     const float *src = points + (size_t)bs * c * m;
     float *dst = out + (size_t)bs * c * n + pt;
-    for (int ch = 0; ch < c; ++ch) {
+    // blockIdx.z splits the channels so that coarse levels (few points, many channels) still fill the chip
+    const int ch0 = blockIdx.z * ch_per, ch1 = min(c, ch0 + ch_per);
+    for (int ch = ch0; ch < ch1; ++ch) {
         const float *row = src + (size_t)ch * m;
         const float v = __fadd_rn(__fadd_rn(__fmul_rn(w0, row[i0]), __fmul_rn(w1, row[i1])), __fmul_rn(w2, row[i2]));
         dst[(size_t)ch * n] = v;
@@ -130,8 +132,12 @@ AMC_API int amc3d_three_interpolate(int b, int c, int m, int n, const float *poi
 {
     if (b <= 0 || c <= 0 || n <= 0) return 0;
     if (!points || !idx || !weight || !out) return bad_arg("amc3d_three_interpolate: null pointer");
-    hipLaunchKernelGGL(three_interpolate_kernel, dim3(div_up(n, 256), b), dim3(256), 0, (hipStream_t)stream, c, m, n,
-                       points, idx, weight, out);
+    long chunks = 262144 / ((long)b * n);
+    if (chunks < 1) chunks = 1;
+    if (chunks > c) chunks = c;
+    const int ch_per = div_up(c, chunks);
+    hipLaunchKernelGGL(three_interpolate_kernel, dim3(div_up(n, 256), b, div_up(c, ch_per)), dim3(256), 0,
+                       (hipStream_t)stream, c, m, n, ch_per, points, idx, weight, out);
     return launch_status("amc3d_three_interpolate");
 }
 

@@ -290,6 +290,94 @@ __global__ __launch_bounds__(256) void contrast_backward_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Cross entropy over channel-major logits (B, C, N) with class targets (B, N), mean over the targets
+// != ignore_index: nn.CrossEntropyLoss() with its defaults, as loss/build.py:328,338 applies it after a
+// transpose + reshape copy of the logits to (B*N, C).  One thread per point walks the classes (coalesced
+// along N per class plane); the mean is reduced in two fixed-order stages (deterministic).
+// ---------------------------------------------------------------------------------------------
+constexpr int CE_THREADS = 256;
+__global__ __launch_bounds__(CE_THREADS) void ce_forward_kernel(int C, long N, const float *__restrict__ logits,
+                                                                const long long *__restrict__ target, long long ignore,
+                                                                float *__restrict__ lse, double *__restrict__ partial)
+{
+    __shared__ double s_sum[CE_THREADS / 64];
+    __shared__ int s_cnt[CE_THREADS / 64];
+    const int b = blockIdx.y;
+    const long n = (long)blockIdx.x * CE_THREADS + threadIdx.x;
+    double term = 0.0;
+    int cnt = 0;
+    if (n < N) {
+        const float *x = logits + (size_t)b * C * N + n;
+        float mx = -__builtin_inff();
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, x[(size_t)c * N]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += __expf(x[(size_t)c * N] - mx);
+        const float l = mx + __logf(se);
+        lse[(size_t)b * N + n] = l;
+        const long long t = target[(size_t)b * N + n];
+        if (t != ignore && t >= 0 && t < C) { term = (double)(l - x[(size_t)t * N]); cnt = 1; }
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        term += __shfl_xor(term, s, 64);
+        cnt += __shfl_xor(cnt, s, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = term; s_cnt[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        int c = 0;
+        for (int w = 0; w < CE_THREADS / 64; ++w) { t += s_sum[w]; c += s_cnt[w]; }
+        const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        partial[slot * 2] = t;
+        partial[slot * 2 + 1] = (double)c;
+    }
+}
+
+// out[0] = mean loss, out[1] = number of counted targets
+__global__ __launch_bounds__(1024) void ce_finalize_kernel(int nparts, const double *__restrict__ partial,
+                                                           float *__restrict__ out)
+{
+    __shared__ double s_sum[16], s_cnt[16];
+    double t = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 1024) { t += partial[(size_t)i * 2]; c += partial[(size_t)i * 2 + 1]; }
+    for (int s = 32; s >= 1; s >>= 1) {
+        t += __shfl_xor(t, s, 64);
+        c += __shfl_xor(c, s, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = t; s_cnt[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tt = 0.0, cc = 0.0;
+        for (int w = 0; w < 16; ++w) { tt += s_sum[w]; cc += s_cnt[w]; }
+        out[0] = (float)(tt / cc);  // 0/0 = NaN, as torch's mean over no targets
+        out[1] = (float)cc;
+    }
+}
+
+// dlogits[b,c,n] = g * (softmax_c - [c == target]) / count for counted targets, 0 otherwise
+__global__ __launch_bounds__(CE_THREADS) void ce_backward_kernel(int C, long N, const float *__restrict__ logits,
+                                                                 const long long *__restrict__ target, long long ignore,
+                                                                 const float *__restrict__ lse,
+                                                                 const float *__restrict__ mean_cnt,
+                                                                 const float *__restrict__ grad_out,
+                                                                 float *__restrict__ dlogits)
+{
+    const int b = blockIdx.y;
+    const long n = (long)blockIdx.x * CE_THREADS + threadIdx.x;
+    if (n >= N) return;
+    const float *x = logits + (size_t)b * C * N + n;
+    float *d = dlogits + (size_t)b * C * N + n;
+    const long long t = target[(size_t)b * N + n];
+    const bool counted = t != ignore && t >= 0 && t < C;
+    const float scale = counted ? grad_out[0] / mean_cnt[1] : 0.f;
+    const float l = lse[(size_t)b * N + n];
+    for (int c = 0; c < C; ++c) {
+        const float p = __expf(x[(size_t)c * N] - l);
+        d[(size_t)c * N] = scale * (p - (c == (int)t ? 1.f : 0.f));
+    }
+}
+
 }  // namespace amc
 
 using namespace amc;
@@ -374,4 +462,37 @@ AMC_API int amc3d_contrast_backward(int m, int C, int k, int nbr_stride, const f
     else AMC_BWD(64, 8);
 #undef AMC_BWD
     return launch_status("amc3d_contrast_backward");
+}
+
+AMC_API size_t amc3d_cross_entropy_workspace_bytes(int B, long N)
+{
+    return (size_t)(B > 0 ? B : 0) * (size_t)div_up(N > 0 ? N : 1, CE_THREADS) * 2 * sizeof(double);
+}
+
+AMC_API int amc3d_cross_entropy_forward(int B, int C, long N, const float *logits, const long long *target,
+                                        long long ignore_index, float *lse, float *mean_cnt, void *workspace,
+                                        size_t workspace_bytes, void *stream_)
+{
+    if (B <= 0 || N <= 0) return 0;
+    if (C <= 0 || !logits || !target || !lse || !mean_cnt || !workspace ||
+        workspace_bytes < amc3d_cross_entropy_workspace_bytes(B, N))
+        return bad_arg("amc3d_cross_entropy_forward: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int gx = div_up(N, CE_THREADS);
+    hipLaunchKernelGGL(ce_forward_kernel, dim3(gx, B), dim3(CE_THREADS), 0, stream, C, N, logits, target, ignore_index, lse,
+                       (double *)workspace);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, stream, gx * B, (const double *)workspace, mean_cnt);
+    return launch_status("amc3d_cross_entropy_forward");
+}
+
+AMC_API int amc3d_cross_entropy_backward(int B, int C, long N, const float *logits, const long long *target,
+                                         long long ignore_index, const float *lse, const float *mean_cnt,
+                                         const float *grad_out, float *dlogits, void *stream)
+{
+    if (B <= 0 || N <= 0) return 0;
+    if (C <= 0 || !logits || !target || !lse || !mean_cnt || !grad_out || !dlogits)
+        return bad_arg("amc3d_cross_entropy_backward: bad argument");
+    hipLaunchKernelGGL(ce_backward_kernel, dim3(div_up(N, CE_THREADS), B), dim3(CE_THREADS), 0, (hipStream_t)stream, C, N,
+                       logits, target, ignore_index, lse, mean_cnt, grad_out, dlogits);
+    return launch_status("amc3d_cross_entropy_backward");
 }

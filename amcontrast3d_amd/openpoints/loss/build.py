@@ -26,9 +26,18 @@ class CrossEntropyAce(torch.nn.Module):
         self.contrast_head = ContrastHead()
 
     def forward(self, logit, target, stageACE_list, num_classes, ignore_index, ambiguity_args):
-        logit = logit.transpose(1, 2).reshape(-1, logit.shape[1])  # (B,ncls,N) -> (B*N,ncls)
-        target = target.flatten()
-        ce = self.creterion(logit, target)
+        crit = self.creterion
+        if (type(crit) is CrossEntropyLoss and crit.weight is None and crit.label_smoothing == 0.0
+                and crit.reduction == 'mean' and logit.is_cuda and logit.dtype == torch.float32 and logit.dim() == 3
+                and not torch.is_autocast_enabled()):
+            # same value without the (B*N, ncls) transposed copy: one fused pass over the (B,ncls,N) logits
+            from amcontrast3d_amd.ops import cross_entropy_mean
+            ce = cross_entropy_mean(logit, target, crit.ignore_index)
+            target = target.flatten()
+        else:
+            logit = logit.transpose(1, 2).reshape(-1, logit.shape[1])  # (B,ncls,N) -> (B*N,ncls)
+            target = target.flatten()
+            ce = crit(logit, target)
         contrast, _, _ = self.contrast_head(logit, target, stageACE_list, num_classes, ignore_index, ambiguity_args)
         return ambiguity_args.w1 * ce + ambiguity_args.w2 * contrast
 

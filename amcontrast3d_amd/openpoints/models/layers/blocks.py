@@ -115,6 +115,10 @@ def _fusable_bn(bn, x):
 
 def _update_running(bn, mean, var_unbiased):
     # nn.BatchNorm bookkeeping (torch/nn/modules/batchnorm.py): momentum None = cumulative average
+    if mean.is_cuda and bn.running_mean.dtype == torch.float32 and bn.num_batches_tracked.dtype == torch.int64:
+        from amcontrast3d_amd.ops import bn_update_running
+        bn_update_running(bn, mean, var_unbiased)
+        return
     with torch.no_grad():
         bn.num_batches_tracked += 1
         mom = bn.momentum

@@ -410,6 +410,16 @@ class BatchNormAct(Function):
         return dx, dgamma, dbeta, None, None
 
 
+@torch.no_grad()
+def bn_update_running(bn, mean, var_unbiased):
+    """nn.BatchNorm's training-mode buffer update (num_batches_tracked, running_mean, running_var) in one launch."""
+    _need_gpu(mean, var_unbiased, bn.running_mean, bn.running_var, bn.num_batches_tracked)
+    mom = -1.0 if bn.momentum is None else float(bn.momentum)
+    _lib.check(_lib.load().amc3d_bn_update_running(mean.numel(), mom, _ptr(mean), _ptr(var_unbiased),
+                                                   _ptr(bn.running_mean), _ptr(bn.running_var),
+                                                   _ptr(bn.num_batches_tracked), _stream(mean)), "bn_update_running")
+
+
 class BatchNormMax(Function):
     """y (B,C,M) = max over the K neighbours of [relu](batch_norm(x (B,C,M,K))) with batch statistics.
     Returns (y, batch mean, unbiased batch variance); the (B,C,M,K) normalised tensor is never written."""
@@ -566,3 +576,47 @@ class PointwiseConv(Function):
 
 def pointwise_conv(x, weight, bias=None):
     return PointwiseConv.apply(x, weight, bias)
+
+
+class CrossEntropyMean(Function):
+    """nn.CrossEntropyLoss()(logits.transpose(1, 2).reshape(-1, C), target.flatten()) -- default arguments: mean
+    over the targets != ignore_index -- on the channel-major logits (B, C, N) as the model returns them
+    (loss/build.py:328,338-340), in one pass forward and one backward."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        _need_gpu(logits, target)
+        logits = logits.contiguous()
+        B, C = logits.shape[0], logits.shape[1]
+        N = logits[0, 0].numel()
+        target = target.reshape(B, N).contiguous()
+        assert target.dtype == torch.int64 and logits.dtype == torch.float32
+        dev = logits.device
+        lse = torch.empty(B, N, dtype=torch.float32, device=dev)
+        mean_cnt = torch.empty(2, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        wb = int(lib.amc3d_cross_entropy_workspace_bytes(B, N))
+        work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev), timing.span("cross_entropy_forward", B * N * (4 * C + 12)):
+            _lib.check(lib.amc3d_cross_entropy_forward(B, C, N, _ptr(logits), _ptr(target), int(ignore_index), _ptr(lse),
+                                                       _ptr(mean_cnt), _ptr(work), wb, _stream(logits)), "cross_entropy_forward")
+        ctx.save_for_backward(logits, target, lse, mean_cnt)
+        ctx.ignore_index = int(ignore_index)
+        return mean_cnt[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, lse, mean_cnt = ctx.saved_tensors
+        B, C = logits.shape[0], logits.shape[1]
+        N = logits[0, 0].numel()
+        g = g.contiguous().to(torch.float32)
+        d = torch.empty_like(logits)
+        with torch.cuda.device(logits.device), timing.span("cross_entropy_backward", B * N * (8 * C + 12)):
+            _lib.check(_lib.load().amc3d_cross_entropy_backward(B, C, N, _ptr(logits), _ptr(target), ctx.ignore_index,
+                                                                _ptr(lse), _ptr(mean_cnt), _ptr(g), _ptr(d),
+                                                                _stream(logits)), "cross_entropy_backward")
+        return d, None, None
+
+
+def cross_entropy_mean(logits, target, ignore_index=-100):
+    return CrossEntropyMean.apply(logits, target, ignore_index)

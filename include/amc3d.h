@@ -183,6 +183,19 @@ int amc3d_grouped_conv_backward(int b, int cin, int cout, int n, int npoints, in
                                 const float *dp, const int *idx, const float *weight, const float *dy,
                                 float *df_pm, float *dweight, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- cross entropy over channel-major logits -----------------------------------------------------
+ * nn.CrossEntropyLoss() with its defaults (mean over targets != ignore_index) as CrossEntropyAce applies it
+ * (openpoints/loss/build.py:328,338-340), without the (B*N, C) transposed copy of the logits.
+ * logits (B,C,N) fp32, target (B,N) int64, lse (B,N) out (saved for backward), mean_cnt[2] = {loss, count}. */
+size_t amc3d_cross_entropy_workspace_bytes(int B, long N);
+int amc3d_cross_entropy_forward(int B, int C, long N, const float *logits, const long long *target,
+                                long long ignore_index, float *lse, float *mean_cnt, void *workspace,
+                                size_t workspace_bytes, void *stream);
+/* dlogits (B,C,N) = grad_out[0] * (softmax - onehot) / count, zero rows for ignored targets */
+int amc3d_cross_entropy_backward(int B, int C, long N, const float *logits, const long long *target,
+                                 long long ignore_index, const float *lse, const float *mean_cnt,
+                                 const float *grad_out, float *dlogits, void *stream);
+
 /* ---- pointwise (1x1) convolution on fp32 MFMA -----------------------------------------------------
  * Replaces the nn.Conv1d / nn.Conv2d (kernel size 1) layers of the path, which the reference builds in
  * openpoints/models/layers/conv.py:8-21 and runs through cuDNN.  Channel-major tensors: x (b,cin,P),
@@ -205,6 +218,10 @@ size_t amc3d_bn_workspace_bytes(int C);  /* for amc3d_bn_stats; amc3d_bn_backwar
 /* mean (C), invstd = 1/sqrt(biased var + eps) (C), var_unbiased (C, for the running estimate) */
 int amc3d_bn_stats(int B, int C, long L, float eps, const float *x, float *mean, float *invstd,
                    float *var_unbiased, void *workspace, size_t workspace_bytes, void *stream);
+/* nn.BatchNorm's training-mode bookkeeping in one launch: num_batches_tracked += 1 and the moving average of
+ * mean / unbiased variance (torch/nn/modules/batchnorm.py); momentum < 0 stands for momentum=None (cumulative) */
+int amc3d_bn_update_running(int C, float momentum, const float *mean, const float *var_unbiased,
+                            float *running_mean, float *running_var, long long *num_batches_tracked, void *stream);
 
 /* y (B,C,L) = [relu](((x - mean) * invstd) * gamma + beta) */
 int amc3d_bn_act(int B, int C, long L, int relu, const float *x, const float *mean, const float *invstd,

@@ -122,3 +122,26 @@ def test_contrast_stage_no_positive_anchor_is_constant():
     assert abs(float(loss) - 27.631021) < 1e-4
     loss.backward()
     assert float(f.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,C,N,ignored", [(2, 13, 1000, 0.0), (3, 20, 777, 0.3), (1, 2, 5, 0.0), (2, 13, 64, 1.0)])
+def test_cross_entropy_matches_torch(B, C, N, ignored):
+    """fused CE on (B,C,N) logits == nn.CrossEntropyLoss() on the transposed (B*N,C) copy (loss/build.py:338-340),
+    value and gradient, including ignore_index = -100 targets (the ScanNet-shaped set) and the all-ignored NaN."""
+    from amcontrast3d_amd import ops
+    g = torch.Generator().manual_seed(C * 100 + N)
+    logits = (torch.randn(B, C, N, generator=g) * 3).to(DEV)
+    target = torch.randint(0, C, (B, N), generator=g).to(DEV)
+    if ignored > 0:
+        target[torch.rand(B, N, generator=g).to(DEV) < ignored] = -100
+    lg = logits.clone().requires_grad_(True)
+    lr = logits.clone().requires_grad_(True)
+    got = ops.cross_entropy_mean(lg, target, -100)
+    want = torch.nn.CrossEntropyLoss()(lr.transpose(1, 2).reshape(-1, C), target.flatten())
+    if ignored >= 1.0:
+        assert torch.isnan(got) and torch.isnan(want)
+        return
+    assert abs(float(got) - float(want)) <= 1e-5 * max(1.0, abs(float(want)))
+    (got * 0.7).backward()
+    (want * 0.7).backward()
+    assert float((lg.grad - lr.grad).abs().max()) <= 1e-6 * max(1.0, float(lr.grad.abs().max()) * 10)
