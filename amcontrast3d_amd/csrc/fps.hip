@@ -12,11 +12,13 @@
 //
 //  * Sweep -- exact pruning.  The workgroup first sorts its cloud by the Morton index of a 16^3 grid
 //    (LDS counting sort) and deals consecutive runs of 64*GS points ("groups") round-robin to its
-//    waves.  Every group carries a bounding sphere (c, r) and M = max running minimum inside it.  A
-//    new sample q cannot lower any running minimum of the group when |c-q| - r >= sqrt(M), so the
+//    waves.  Every group carries its axis-aligned bounding box and M = max running minimum inside it.  A
+//    new sample q cannot lower any running minimum of the group when dist(q, box)^2 >= M, so the
 //    group is skipped and its cached per-lane maximum stays valid.  Late in the sampling only the few
-//    groups around q are swept (measured on S3DIS-shaped clouds: ~18 % of the groups per iteration).
-//    Skipping never changes a value, so the result is the brute-force result.
+//    groups around q are swept (simulated on S3DIS-shaped clouds, scratch/fps_prune_sim2.py: 8.9 % of the
+//    groups per iteration; a bounding sphere needs 18 % -- the groups are flat patches of surfaces, whose
+//    boxes are thin where their spheres are not).  Skipping never changes a value, so the result is the
+//    brute-force result.
 //  * Arg-max -- DPP wave reduction, one LDS record per wave that already carries the wave winner's
 //    coordinates (read from the owner lane's VGPRs under a wave-uniform switch), ONE barrier, a
 //    16-lane reduction; no dependent global load and no second barrier on the critical path.
@@ -210,41 +212,32 @@ __global__ __launch_bounds__(MAXT) void fps_kernel(int n, int m, int log2rb, con
         // running minimum: the caller's fill value (1e10, subsample.py:95); -2 marks an empty slot
         pt[j] = ok ? (temp ? temp[(size_t)blockIdx.x * n + k] : 1e10f) : -2.f;
     }
-    // group g's sphere and skip threshold live in lane g (one distance test serves all groups)
-    float pcx = 0.f, pcy = 0.f, pcz = 0.f, prad = 0.f, pthr = -1.f;
+    // group g's bounding box and M = max running minimum live in lane g (one distance test serves all groups)
+    float blx = 0.f, bly = 0.f, blz = 0.f, bhx = 0.f, bhy = 0.f, bhz = 0.f, pthr = -2.f;
     float gb[NG];                                          // per lane: best running minimum in the group
     int gsl[NG];                                           // per lane: its slot
     unsigned tiebits = 0;                                  // per lane: group maximum attained twice
-    auto thr_of = [](float rad, float mx) {
-        if (mx < 0.f) return -1.f;  // empty group: always skipped
-        const float t = rad + __builtin_amdgcn_sqrtf(mx) * 1.00001f;  // v_sqrt_f32 (1 ulp): the margin covers it
-        return t * t * 1.00001f;
-    };
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        float sx = 0.f, sy = 0.f, sz = 0.f, cnt = 0.f, mx = -2.f;
+        float lx = 3.4e38f, ly = 3.4e38f, lz = 3.4e38f, hx = -3.4e38f, hy = -3.4e38f, hz = -3.4e38f, mx = -2.f;
 #pragma unroll
         for (int jj = 0; jj < GS; ++jj) {
             const int j = g * GS + jj;
             const bool ok = pt[j] > -1.f;
-            sx += ok ? px[j] : 0.f; sy += ok ? py[j] : 0.f; sz += ok ? pz[j] : 0.f;
-            cnt += ok ? 1.f : 0.f;
+            lx = fminf(lx, ok ? px[j] : 3.4e38f); hx = fmaxf(hx, ok ? px[j] : -3.4e38f);
+            ly = fminf(ly, ok ? py[j] : 3.4e38f); hy = fmaxf(hy, ok ? py[j] : -3.4e38f);
+            lz = fminf(lz, ok ? pz[j] : 3.4e38f); hz = fmaxf(hz, ok ? pz[j] : -3.4e38f);
             mx = fmaxf(mx, pt[j]);
         }
-        cnt = wave_sum_f32(cnt);
-        const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
-        const float cx = uniform_f32(wave_sum_f32(sx) * inv), cy = uniform_f32(wave_sum_f32(sy) * inv),
-                    cz = uniform_f32(wave_sum_f32(sz) * inv);
-        float r2 = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < GS; ++jj) {
-            const int j = g * GS + jj;
-            const float d = dist2_ref(px[j], py[j], pz[j], cx, cy, cz);
-            r2 = fmaxf(r2, pt[j] > -1.f ? d : 0.f);
+        lx = -wave_max_f32(-lx); ly = -wave_max_f32(-ly); lz = -wave_max_f32(-lz);
+        hx = wave_max_f32(hx); hy = wave_max_f32(hy); hz = wave_max_f32(hz);
+        const float thr = wave_max_f32(mx);  // -2: empty group, never swept
+        if (lane == g) {
+            const bool any = thr > -1.f;
+            blx = any ? lx : 0.f; bly = any ? ly : 0.f; blz = any ? lz : 0.f;
+            bhx = any ? hx : 0.f; bhy = any ? hy : 0.f; bhz = any ? hz : 0.f;
+            pthr = thr;
         }
-        const float rad = sqrtf(wave_max_f32(r2)) * 1.00001f + 1e-30f;
-        const float thr = thr_of(rad, wave_max_f32(mx));
-        if (lane == g) { pcx = cx; pcy = cy; pcz = cz; prad = rad; pthr = thr; }
         gb[g] = -1.f;
         gsl[g] = g * GS;
     }
@@ -268,8 +261,12 @@ __global__ __launch_bounds__(MAXT) void fps_kernel(int n, int m, int log2rb, con
     for (int it = 1; it < m; ++it) {
         const int buf = it & 1;
         // ---- 1. sweep the groups the new sample can affect --------------------------------------
-        const float d2c = dist2_ref(pcx, pcy, pcz, x1, y1, z1);
-        const unsigned sweep = (unsigned)__ballot(lane < NG && !(d2c > pthr));
+        // squared distance from the new sample to the group's box: no point of the group is nearer.  The group
+        // is skipped when even that cannot lower its largest running minimum (0.99999: fp32 rounding of either side)
+        const float ex = fmaxf(fmaxf(blx - x1, x1 - bhx), 0.f), ey = fmaxf(fmaxf(bly - y1, y1 - bhy), 0.f),
+                    ez = fmaxf(fmaxf(blz - z1, z1 - bhz), 0.f);
+        const float d2box = (ex * ex + ey * ey) + ez * ez;
+        const unsigned sweep = (unsigned)__ballot(lane < NG && !(d2box * 0.99999f > pthr));
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if ((sweep >> g) & 1u) {  // wave-uniform: group g is not provably untouched
@@ -291,7 +288,7 @@ __global__ __launch_bounds__(MAXT) void fps_kernel(int n, int m, int log2rb, con
                 gb[g] = b;
                 gsl[g] = sl;
                 tiebits = tie ? (tiebits | (1u << g)) : (tiebits & ~(1u << g));
-                const float nthr = thr_of(prad, wave_max_f32(b));  // evaluated in every lane, kept by lane g
+                const float nthr = wave_max_f32(b);  // the group's new M; evaluated in every lane, kept by lane g
                 pthr = lane == g ? nthr : pthr;
             }
         }
@@ -524,7 +521,8 @@ AMC_API int amc3d_furthest_point_sampling(int b, int n, int m, const float *data
         return w;
     };
     static const int variant = getenv("AMC3D_FPS_VARIANT") ? atoi(getenv("AMC3D_FPS_VARIANT")) : 0;
-    if (n > 12288 && variant == 1) return launch_fps<96, 12, 256>(b, n, m, 4, log2rb, dataset, temp, idxs, perm, stream);
+    if (n > 12288 && variant == 2) return launch_fps<48, 12>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
+    if (n > 12288 && variant == 3) return launch_fps<48, 8>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
     if (n > 12288) return launch_fps<48, 6>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
     if (n > 6144) return launch_fps<24, 3>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
     if (n > 3072) return launch_fps<12, 3>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
