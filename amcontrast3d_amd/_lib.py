@@ -17,7 +17,8 @@ _ll = ctypes.c_longlong
 SIGNATURES = {
     "amc3d_version": (ctypes.c_char_p, []),
     "amc3d_last_error": (ctypes.c_char_p, []),
-    "amc3d_ball_query": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "amc3d_grid_search_workspace_bytes": (_sz, [_i, _i, _i]),
+    "amc3d_ball_query": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_group_points": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "amc3d_scatter_workspace_bytes": (_sz, [_i, _i, _i]),
     "amc3d_group_points_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -25,7 +26,7 @@ SIGNATURES = {
     "amc3d_gather_points_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "amc3d_fps_workspace_bytes": (_sz, [_i, _i]),
     "amc3d_furthest_point_sampling": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "amc3d_three_nn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_three_nn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_three_interpolate": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_three_interpolate_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_knnquery_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -34,8 +34,14 @@ def _call(name, dev_tensor, *args):
         _lib.check(getattr(_lib.load(), name)(*args, _s(dev_tensor)), name)
 
 
+def _grid_ws(b, n_support, m_queries, device):
+    wb = int(_lib.load().amc3d_grid_search_workspace_bytes(b, n_support, m_queries))
+    return torch.empty(max(wb, 4), dtype=torch.uint8, device=device), wb
+
+
 def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
-    _call("amc3d_ball_query", xyz, b, n, m, float(radius), nsample, _p(new_xyz), _p(xyz), _p(idx))
+    work, wb = _grid_ws(b, n, m, xyz.device)
+    _call("amc3d_ball_query", xyz, b, n, m, float(radius), nsample, _p(new_xyz), _p(xyz), _p(idx), _p(work), wb)
     return 1
 
 
@@ -68,7 +74,8 @@ def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
 
 
 def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
-    _call("amc3d_three_nn", unknown, b, n, m, _p(unknown), _p(known), _p(dist2), _p(idx))
+    work, wb = _grid_ws(b, m, n, unknown.device)
+    _call("amc3d_three_nn", unknown, b, n, m, _p(unknown), _p(known), _p(dist2), _p(idx), _p(work), wb)
 
 
 def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):

@@ -136,11 +136,27 @@ __global__ void group_points_grad_kernel(int c, int n, int ps, const float *__re
 
 using namespace amc;
 
+namespace amc {
+bool grid_search_pays(int b, int n, int m);
+size_t grid_search_workspace_bytes(int b, int n, int m);
+int ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx,
+                    void *workspace, hipStream_t stream);
+}
+
+AMC_API size_t amc3d_grid_search_workspace_bytes(int b, int n_support, int m_queries)
+{
+    if (b <= 0 || n_support <= 0 || m_queries <= 0) return 0;
+    return grid_search_workspace_bytes(b, n_support, m_queries);
+}
+
 AMC_API int amc3d_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
-                             const float *xyz, int *idx, void *stream)
+                             const float *xyz, int *idx, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (b <= 0 || m <= 0) return 0;
     if (n < 0 || nsample <= 0 || !new_xyz || !xyz || !idx) return bad_arg("amc3d_ball_query: bad argument");
+    if (workspace && n > 0 && nsample <= 64 && radius > 0.f && grid_search_pays(b, n, m) &&
+        workspace_bytes >= grid_search_workspace_bytes(b, n, m))
+        return ball_query_grid(b, n, m, radius, nsample, new_xyz, xyz, idx, workspace, (hipStream_t)stream);
     dim3 grid(div_up(m, BQ_WAVES * BQ_QPW), b);
     const float radius2 = radius * radius;  // ball_query_gpu.cu:31
     hipLaunchKernelGGL(ball_query_kernel, grid, dim3(BQ_WAVES * 64), 0, (hipStream_t)stream, n, m, radius2,

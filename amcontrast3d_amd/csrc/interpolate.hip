@@ -117,11 +117,20 @@ __global__ void three_interpolate_grad_kernel(int c, int n, int m, const float *
 
 using namespace amc;
 
+namespace amc {
+bool grid_search_pays(int b, int n, int m);
+size_t grid_search_workspace_bytes(int b, int n, int m);
+int three_nn_grid(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx, void *workspace,
+                  hipStream_t stream);
+}
+
 AMC_API int amc3d_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
-                           int *idx, void *stream)
+                           int *idx, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (b <= 0 || n <= 0) return 0;
     if (m < 0 || !unknown || !known || !dist2 || !idx) return bad_arg("amc3d_three_nn: bad argument");
+    if (workspace && m >= 3 && grid_search_pays(b, m, n) && workspace_bytes >= grid_search_workspace_bytes(b, m, n))
+        return three_nn_grid(b, n, m, unknown, known, dist2, idx, workspace, (hipStream_t)stream);
     hipLaunchKernelGGL(three_nn_kernel, dim3(div_up(n, NN_THREADS), b), dim3(NN_THREADS), 0, (hipStream_t)stream, n,
                        m, unknown, known, dist2, idx);
     return launch_status("amc3d_three_nn");

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(1024) void kg_sample_kernel(int m, int k, int nb, i
     }
 }
 
-__global__ __launch_bounds__(64) void kg_params_kernel(int n, int nb, float hscale, const int *__restrict__ bbox,
+__global__ __launch_bounds__(64) void kg_params_kernel(int n, int nb, float hscale, float fixed_h, const int *__restrict__ bbox,
                                                        const float *__restrict__ samples, GridParams *__restrict__ gp)
 {
     const int lane = threadIdx.x;
@@ -458,6 +458,7 @@ __global__ __launch_bounds__(64) void kg_params_kernel(int n, int nb, float hsca
     const float emax = fmaxf(fmaxf(ex, ey), fmaxf(ez, 1e-30f));
     float h = hscale * sqrtf(r2);
     if (!(r2 < 1e9f) || !(h > emax * 1e-6f)) h = emax;  // fewer than k points, or all points coincide
+    if (fixed_h > 0.f) h = fixed_h;                      // radius searches bring their own cell size (a lower bound)
     const float cap = (float)(knn_cell_cap(n) / (nb > 0 ? nb : 1));
     // grow h until the grid fits the cell budget (float arithmetic: no int overflow on huge extents)
     for (int it = 0; it < 400 && (ex / h + 1.f) * (ey / h + 1.f) * (ez / h + 1.f) > cap; ++it) h *= 1.26f;
@@ -705,6 +706,270 @@ __global__ __launch_bounds__(256) void kg_query_kernel(int m, int k, int nb, con
     }
 }
 
+// Grid construction shared by the k-NN, ball-query and 3-NN searches: bounding box, cell size (calibrated on
+// `ksample`-th neighbour distances of 64 sample queries, or `fixed_h` when > 0), counting sort of the support
+// points into cell order.  Leaves GridParams, cell_start[] and sorted[] in the workspace.
+static int kg_build(const KnnWorkspace &w, char *base, int n, int m, int nbatch, const float *xyz, const float *new_xyz,
+                    const int *offset, const int *new_offset, int ksample, int sub, float hscale, float fixed_h,
+                    hipStream_t stream)
+{
+    GridParams *gp = (GridParams *)(base + w.params);
+    int *bbox = (int *)(base + w.bbox);
+    float *samples = (float *)(base + w.samples);
+    int *fb_count = (int *)(base + w.fb_count);
+    int *cell_start = (int *)(base + w.cell_start);
+    int *cursor = (int *)(base + w.cursor);
+    float4 *sorted = (float4 *)(base + w.sorted);
+    const size_t cells = (size_t)knn_cell_cap(n) + 1;
+    if (int st = fill_i32(cell_start, 0, cells, stream)) return st;
+    if (int st = fill_i32(cursor, 0, cells, stream)) return st;
+    hipLaunchKernelGGL(kg_init_kernel, dim3(1), dim3(64), 0, stream, bbox, fb_count);
+    hipLaunchKernelGGL(kg_bbox_kernel, dim3(min(div_up(n, 256), 64)), dim3(256), 0, stream, n, xyz, bbox);
+    if (!(fixed_h > 0.f))
+        hipLaunchKernelGGL(kg_sample_kernel, dim3(KG_SAMPLES), dim3(1024), 0, stream, m, ksample, nbatch, sub, xyz, new_xyz,
+                           offset, new_offset, samples);
+    hipLaunchKernelGGL(kg_params_kernel, dim3(1), dim3(64), 0, stream, n, nbatch, hscale, fixed_h, bbox, samples, gp);
+    hipLaunchKernelGGL(kg_count_kernel, dim3(div_up(n, 256)), dim3(256), 0, stream, n, nbatch, xyz, offset, gp,
+                       cell_start);
+    int *tile_sums = (int *)(base + w.tile_sums);
+    const int ntiles = div_up(knn_cell_cap(n), KG_SCAN_TILE);  // <= 1024
+    hipLaunchKernelGGL(kg_scan_sums_kernel, dim3(ntiles), dim3(256), 0, stream, nbatch, gp, cell_start, tile_sums);
+    hipLaunchKernelGGL(kg_scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, ntiles, tile_sums);
+    hipLaunchKernelGGL(kg_scan_apply_kernel, dim3(ntiles), dim3(256), 0, stream, nbatch, gp, cell_start, tile_sums,
+                       ntiles);
+    hipLaunchKernelGGL(kg_scatter_kernel, dim3(div_up(n, 256)), dim3(256), 0, stream, n, nbatch, xyz, offset, gp,
+                       cell_start, cursor, sorted);
+    return launch_status("grid build");
+}
+
+// ---- batched (B, N, 3) searches on the same grid: ball query and 3-NN --------------------------------
+// cumulative ends of the uniform segments of a (B, N, 3) / (B, M, 3) pair
+__global__ void kg_uniform_offsets_kernel(int nb, int n_per, int m_per, int *__restrict__ off_s, int *__restrict__ off_q)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nb) { off_s[i] = (i + 1) * n_per; off_q[i] = (i + 1) * m_per; }
+}
+
+// The (dz,dy) x-runs of the 3x3x3 block around cell (cx,cy,cz): lane pi < 9 gets run pi as [b, e)
+__device__ __forceinline__ void kg_block_runs(const GridParams &g, const int *__restrict__ cs, int cx, int cy, int cz, int lane,
+                                              int &b, int &e)
+{
+    b = 0; e = 0;
+    if (lane < 9) {
+        const int z = cz + lane / 3 - 1, y = cy + lane % 3 - 1;
+        if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+            const int row = (z * g.ny + y) * g.nx;
+            b = cs[row + max(cx - 1, 0)];
+            e = cs[row + min(cx + 1, g.nx - 1) + 1];
+        }
+    }
+}
+
+// Ball query (ball_query_gpu.cu:15-51) on the grid, cell edge >= radius: every point within the radius of a query
+// lies in the 3x3x3 block around the query's cell.  One wavefront per query keeps the `nsample` SMALLEST hit
+// indices sorted in its lanes (the reference returns the first nsample hits of an ascending index scan), then
+// pads with the first hit exactly as the reference does; a query without a hit yields zeros.
+__global__ __launch_bounds__(256) void bq_grid_kernel(int nq, int n, int m, float radius2, int nsample,
+                                                      const float *__restrict__ new_xyz,
+                                                      const GridParams *__restrict__ gp,
+                                                      const int *__restrict__ cell_start,
+                                                      const float4 *__restrict__ sorted, int *__restrict__ idx)
+{
+    const int lane = threadIdx.x & 63;
+    const GridParams g = *gp;
+    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < nq; q += gridDim.x * 4) {
+        const int bs = q / m;
+        const float qx = new_xyz[(size_t)q * 3], qy = new_xyz[(size_t)q * 3 + 1], qz = new_xyz[(size_t)q * 3 + 2];
+        const int cx = cell_coord(qx, g.minx, g.inv_h, g.nx), cy = cell_coord(qy, g.miny, g.inv_h, g.ny),
+                  cz = cell_coord(qz, g.minz, g.inv_h, g.nz);
+        int b, e;
+        kg_block_runs(g, cell_start + (size_t)bs * g.ncell, cx, cy, cz, lane, b, e);
+        const int len = e - b;
+        int incl = len;
+        for (int s = 1; s < 16; s <<= 1) {  // only lanes 0..8 hold runs
+            const int o = __shfl_up(incl, s, 64);
+            if (lane >= s) incl += o;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, 8);
+        const int excl = incl - len;
+        int key = 0x7fffffff;  // this lane's entry of the ascending list of the smallest hit indices
+        int tau = 0x7fffffff;  // its nsample-th entry (wave-uniform)
+        int have = 0;
+        for (int c0 = 0; c0 < total; c0 += 64) {
+            const int c = c0 + lane;
+            int base = 0;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const int e0 = __builtin_amdgcn_readlane(excl, r), b0 = __builtin_amdgcn_readlane(b, r);
+                const int l0 = __builtin_amdgcn_readlane(len, r);
+                base = (l0 > 0 && c >= e0) ? b0 - e0 : base;
+            }
+            const bool valid = c < total;
+            const float4 p = sorted[valid ? base + c : __builtin_amdgcn_readfirstlane(base + c)];
+            const float d2 = dist2_ref(qx, qy, qz, p.x, p.y, p.z);
+            const int pi = __float_as_int(p.w);
+            unsigned long long hits = __ballot(valid && d2 < radius2 && pi < tau);
+            while (hits) {
+                const int src = (int)__builtin_ctzll(hits);
+                hits &= hits - 1;
+                const int ci = __builtin_amdgcn_readlane(pi, src);
+                if (ci < tau) {
+                    const int pos = (int)__popcll(__ballot(lane < nsample && key < ci));
+                    const int up = lane_below_i32(key);
+                    if (lane > pos) key = up;
+                    if (lane == pos) key = ci;
+                    tau = __builtin_amdgcn_readlane(key, nsample - 1);
+                    have = min(have + 1, nsample);
+                }
+            }
+        }
+        const int first = have > 0 ? __builtin_amdgcn_readlane(key, 0) - bs * n : 0;
+        if (lane < nsample) idx[(size_t)q * nsample + lane] = lane < have ? key - bs * n : first;
+    }
+}
+
+// three_nn (interpolate_gpu.cu:16-59) on the grid: the 3 nearest known points of every unknown point, ties
+// resolved as the reference's ascending strict-'<' scan does (the lower index ranks first), i.e. the list is
+// ordered by (distance, index) -- exact without a replay.  Shell expansion and stopping rule as in kg_query.
+__global__ __launch_bounds__(256) void nn3_grid_kernel(int nq, int n, int m, const float *__restrict__ unknown,
+                                                       const GridParams *__restrict__ gp,
+                                                       const int *__restrict__ cell_start,
+                                                       const float4 *__restrict__ sorted, float *__restrict__ dist2,
+                                                       int *__restrict__ idx)
+{
+    const int lane = threadIdx.x & 63;
+    const GridParams g = *gp;
+    const float inf = __builtin_inff();
+    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < nq; q += gridDim.x * 4) {
+        const int bs = q / n;
+        const float qx = unknown[(size_t)q * 3], qy = unknown[(size_t)q * 3 + 1], qz = unknown[(size_t)q * 3 + 2];
+        const int cx = cell_coord(qx, g.minx, g.inv_h, g.nx), cy = cell_coord(qy, g.miny, g.inv_h, g.ny),
+                  cz = cell_coord(qz, g.minz, g.inv_h, g.nz);
+        const int *cs = cell_start + (size_t)bs * g.ncell;
+        float v = inf;            // lanes 0..2: ascending (distance, index)
+        int id = bs * m;          // -> local index 0, the reference's initial besti
+        float tau = inf;
+        int tau_id = 0x7fffffff;
+        auto feed = [&](int b0, int len) {
+            int incl = len;
+            for (int s = 1; s < 64; s <<= 1) {
+                const int o = __shfl_up(incl, s, 64);
+                if (lane >= s) incl += o;
+            }
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            const int excl = incl - len;
+            const unsigned long long runs = __ballot(len > 0);
+            for (int c0 = 0; c0 < total; c0 += 64) {
+                const int c = c0 + lane;
+                int base = 0;
+                unsigned long long rm = runs;
+                while (rm) {
+                    const int src = (int)__builtin_ctzll(rm);
+                    rm &= rm - 1;
+                    const int e0 = __builtin_amdgcn_readlane(excl, src);
+                    if (e0 >= c0 + 64) break;
+                    base = c >= e0 ? __builtin_amdgcn_readlane(b0, src) - e0 : base;
+                }
+                const bool valid = c < total;
+                const float4 p = sorted[valid ? base + c : __builtin_amdgcn_readfirstlane(base + c)];
+                const float d2 = dist2_ref(qx, qy, qz, p.x, p.y, p.z);
+                const int pi = __float_as_int(p.w);
+                unsigned long long pass = __ballot(valid && (d2 < tau || (d2 == tau && pi < tau_id)));
+                while (pass) {
+                    const int src = (int)__builtin_ctzll(pass);
+                    pass &= pass - 1;
+                    const float cd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), src));
+                    const int ci = __builtin_amdgcn_readlane(pi, src);
+                    if (cd < tau || (cd == tau && ci < tau_id)) {
+                        const int pos = (int)__popcll(__ballot(lane < 3 && (v < cd || (v == cd && id < ci))));
+                        const float upv = lane_below_f32(v);
+                        const int upi = lane_below_i32(id);
+                        if (lane > pos) { v = upv; id = upi; }
+                        if (lane == pos) { v = cd; id = ci; }
+                        tau = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 2));
+                        tau_id = __builtin_amdgcn_readlane(id, 2);
+                    }
+                }
+            }
+        };
+        for (int R = 1;; ++R) {
+            const int side = 2 * R + 1, npairs = side * side;
+            for (int p0 = 0; p0 < npairs; p0 += 64) {
+                const int pi = p0 + lane;
+                int bA = 0, eA = 0, bB = 0, eB = 0;
+                if (pi < npairs) {
+                    const int dz = pi / side - R, dy = pi % side - R;
+                    const int z = cz + dz, y = cy + dy;
+                    if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+                        const int row = (z * g.ny + y) * g.nx;
+                        const bool rim = R == 1 || dz == -R || dz == R || dy == -R || dy == R;
+                        if (rim) {
+                            bA = cs[row + max(cx - R, 0)];
+                            eA = cs[row + min(cx + R, g.nx - 1) + 1];
+                        } else {
+                            if (cx - R >= 0) { bA = cs[row + cx - R]; eA = cs[row + cx - R + 1]; }
+                            if (cx + R < g.nx) { bB = cs[row + cx + R]; eB = cs[row + cx + R + 1]; }
+                        }
+                    }
+                }
+                feed(bA, eA - bA);
+                if (R > 1) feed(bB, eB - bB);
+            }
+            float dmin = 3.4e38f;
+            bool whole = true;
+            if (cx - R > 0) { dmin = fminf(dmin, qx - (g.minx + (float)(cx - R) * g.h)); whole = false; }
+            if (cx + R + 1 < g.nx) { dmin = fminf(dmin, (g.minx + (float)(cx + R + 1) * g.h) - qx); whole = false; }
+            if (cy - R > 0) { dmin = fminf(dmin, qy - (g.miny + (float)(cy - R) * g.h)); whole = false; }
+            if (cy + R + 1 < g.ny) { dmin = fminf(dmin, (g.miny + (float)(cy + R + 1) * g.h) - qy); whole = false; }
+            if (cz - R > 0) { dmin = fminf(dmin, qz - (g.minz + (float)(cz - R) * g.h)); whole = false; }
+            if (cz + R + 1 < g.nz) { dmin = fminf(dmin, (g.minz + (float)(cz + R + 1) * g.h) - qz); whole = false; }
+            if (whole) break;
+            dmin -= g.margin;
+            if (dmin > 0.f && tau < dmin * dmin * 0.99999f) break;  // strictly nearer than anything unseen
+        }
+        if (lane < 3) {
+            dist2[(size_t)q * 3 + lane] = v;
+            idx[(size_t)q * 3 + lane] = id - bs * m;
+        }
+    }
+}
+
+bool grid_search_pays(int b, int n, int m) { return b <= 64 && (long)n * m >= (1L << 21) && (long)b * n >= 4 * KG_SAMPLES; }
+
+size_t grid_search_workspace_bytes(int b, int n, int m) { return knn_layout(b * n, b * m).total; }
+
+// xyz (b,n,3) support, new_xyz (b,m,3) queries
+int ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx,
+                    void *workspace, hipStream_t stream)
+{
+    const KnnWorkspace w = knn_layout(b * n, b * m);
+    char *base = (char *)workspace;
+    int *off_s = (int *)(base + 768), *off_q = (int *)(base + 6400);
+    hipLaunchKernelGGL(kg_uniform_offsets_kernel, dim3(1), dim3(64), 0, stream, b, n, m, off_s, off_q);
+    // cell edge 1 % above the radius: a point within the radius is at most one cell away whatever fp32 does
+    if (int st = kg_build(w, base, b * n, b * m, b, xyz, new_xyz, off_s, off_q, 1, 1, 1.f, radius * 1.01f + 1e-30f, stream))
+        return st;
+    hipLaunchKernelGGL(bq_grid_kernel, dim3(min(div_up((long)b * m, 4), 256 * 32)), dim3(256), 0, stream, b * m, n, m,
+                       radius * radius, nsample, new_xyz, (const GridParams *)(base + w.params),
+                       (const int *)(base + w.cell_start), (const float4 *)(base + w.sorted), idx);
+    return launch_status("amc3d_ball_query");
+}
+
+// unknown (b,n,3) queries, known (b,m,3) support
+int three_nn_grid(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx, void *workspace,
+                  hipStream_t stream)
+{
+    const KnnWorkspace w = knn_layout(b * m, b * n);
+    char *base = (char *)workspace;
+    int *off_s = (int *)(base + 768), *off_q = (int *)(base + 6400);
+    hipLaunchKernelGGL(kg_uniform_offsets_kernel, dim3(1), dim3(64), 0, stream, b, m, n, off_s, off_q);
+    if (int st = kg_build(w, base, b * m, b * n, b, known, unknown, off_s, off_q, 2, 2, 1.0f, 0.f, stream)) return st;
+    hipLaunchKernelGGL(nn3_grid_kernel, dim3(min(div_up((long)b * n, 4), 256 * 32)), dim3(256), 0, stream, b * n, n, m,
+                       unknown, (const GridParams *)(base + w.params), (const int *)(base + w.cell_start),
+                       (const float4 *)(base + w.sorted), dist2, idx);
+    return launch_status("amc3d_three_nn");
+}
+
 }  // namespace amc
 
 using namespace amc;
@@ -735,36 +1000,17 @@ AMC_API int amc3d_knnquery(int m, int nsample, int n, int nbatch, const float *x
     const KnnWorkspace w = knn_layout(n, m);
     if (!workspace || workspace_bytes < w.total) return bad_arg("amc3d_knnquery: workspace too small");
     char *base = (char *)workspace;
-    GridParams *gp = (GridParams *)(base + w.params);
-    int *bbox = (int *)(base + w.bbox);
-    float *samples = (float *)(base + w.samples);
-    int *fb_count = (int *)(base + w.fb_count);
-    int *cell_start = (int *)(base + w.cell_start);
-    int *cursor = (int *)(base + w.cursor);
-    float4 *sorted = (float4 *)(base + w.sorted);
-    int *fb_list = (int *)(base + w.fb_list);
-    const size_t cells = (size_t)knn_cell_cap(n) + 1;
-
-    if (int st = fill_i32(cell_start, 0, cells, stream)) return st;
-    if (int st = fill_i32(cursor, 0, cells, stream)) return st;
-    hipLaunchKernelGGL(kg_init_kernel, dim3(1), dim3(64), 0, stream, bbox, fb_count);
-    hipLaunchKernelGGL(kg_bbox_kernel, dim3(min(div_up(n, 256), 64)), dim3(256), 0, stream, n, xyz, bbox);
     static const int kg_sub = getenv("AMC3D_KG_SUB") ? atoi(getenv("AMC3D_KG_SUB")) : 8;
     static const int kg_extra = getenv("AMC3D_KG_EXTRA") ? atoi(getenv("AMC3D_KG_EXTRA")) : 1;
     static const float kg_scale = getenv("AMC3D_KG_SCALE") ? (float)atof(getenv("AMC3D_KG_SCALE")) : 1.1f;
-    hipLaunchKernelGGL(kg_sample_kernel, dim3(KG_SAMPLES), dim3(1024), 0, stream, m, (nsample + kg_sub - 1) / kg_sub + kg_extra,
-                       nbatch, kg_sub, xyz, new_xyz, offset, new_offset, samples);
-    hipLaunchKernelGGL(kg_params_kernel, dim3(1), dim3(64), 0, stream, n, nbatch, kg_scale, bbox, samples, gp);
-    hipLaunchKernelGGL(kg_count_kernel, dim3(div_up(n, 256)), dim3(256), 0, stream, n, nbatch, xyz, offset, gp,
-                       cell_start);
-    int *tile_sums = (int *)(base + w.tile_sums);
-    const int ntiles = div_up(knn_cell_cap(n), KG_SCAN_TILE);  // <= 1024
-    hipLaunchKernelGGL(kg_scan_sums_kernel, dim3(ntiles), dim3(256), 0, stream, nbatch, gp, cell_start, tile_sums);
-    hipLaunchKernelGGL(kg_scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, ntiles, tile_sums);
-    hipLaunchKernelGGL(kg_scan_apply_kernel, dim3(ntiles), dim3(256), 0, stream, nbatch, gp, cell_start, tile_sums,
-                       ntiles);
-    hipLaunchKernelGGL(kg_scatter_kernel, dim3(div_up(n, 256)), dim3(256), 0, stream, n, nbatch, xyz, offset, gp,
-                       cell_start, cursor, sorted);
+    if (int st = kg_build(w, base, n, m, nbatch, xyz, new_xyz, offset, new_offset, (nsample + kg_sub - 1) / kg_sub + kg_extra,
+                          kg_sub, kg_scale, 0.f, stream))
+        return st;
+    GridParams *gp = (GridParams *)(base + w.params);
+    int *fb_count = (int *)(base + w.fb_count);
+    int *cell_start = (int *)(base + w.cell_start);
+    float4 *sorted = (float4 *)(base + w.sorted);
+    int *fb_list = (int *)(base + w.fb_list);
     hipLaunchKernelGGL(kg_query_kernel, dim3(min(div_up(m, 4), 256 * 32)), dim3(256), 0, stream, m, nsample, nbatch,
                        new_xyz, offset, new_offset, gp, cell_start, sorted, idx, dist2, fb_list, fb_count);
     // queries with equal distances among their k+1 nearest: replay the reference's heap

@@ -35,6 +35,13 @@ def _need_gpu(*ts):
                                "there is no CPU fallback" % t.device)
 
 
+def _grid_ws(b, n_support, m_queries, device):
+    """caller-owned scratch of the grid searches (ball query, 3-NN); the library falls back to the all-pairs
+    kernels by itself where a grid does not pay (small clouds)"""
+    wb = int(_lib.load().amc3d_grid_search_workspace_bytes(b, n_support, m_queries))
+    return torch.empty(max(wb, 4), dtype=torch.uint8, device=device), wb
+
+
 class BallQuery(Function):
     @staticmethod
     def forward(ctx, radius, nsample, xyz, new_xyz):
@@ -45,9 +52,10 @@ class BallQuery(Function):
         B, N, _ = xyz.size()
         npoint = new_xyz.size(1)
         idx = torch.empty(B, npoint, nsample, dtype=torch.int32, device=xyz.device)
+        work, wb = _grid_ws(B, N, npoint, xyz.device)
         with torch.cuda.device(xyz.device), timing.span("ball_query", (B * N + B * npoint) * 12 + idx.numel() * 4):
             _lib.check(_lib.load().amc3d_ball_query(B, N, npoint, float(radius), int(nsample), _ptr(new_xyz),
-                                                    _ptr(xyz), _ptr(idx), _stream(xyz)), "ball_query")
+                                                    _ptr(xyz), _ptr(idx), _ptr(work), wb, _stream(xyz)), "ball_query")
         ctx.mark_non_differentiable(idx)
         return idx
 
@@ -166,9 +174,10 @@ class ThreeNN(Function):
         m = known.size(1)
         dist2 = torch.empty(B, N, 3, dtype=torch.float32, device=unknown.device)
         idx = torch.empty(B, N, 3, dtype=torch.int32, device=unknown.device)
+        work, wb = _grid_ws(B, m, N, unknown.device)
         with torch.cuda.device(unknown.device), timing.span("three_nn", (B * N + B * m) * 12 + B * N * 24):
             _lib.check(_lib.load().amc3d_three_nn(B, N, m, _ptr(unknown), _ptr(known), _ptr(dist2), _ptr(idx),
-                                                  _stream(unknown)), "three_nn")
+                                                  _ptr(work), wb, _stream(unknown)), "three_nn")
         ctx.mark_non_differentiable(idx)
         return torch.sqrt(dist2), idx
 

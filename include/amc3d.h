@@ -47,9 +47,14 @@ const char *amc3d_last_error(void);
  * new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample): the first `nsample`
  * support indices (ascending) with d2 < radius*radius, padded with the first
  * hit; a row with no hit is written as zeros (the reference relies on the
- * caller's zero-fill, group.py:194). */
+ * caller's zero-fill, group.py:194).
+ * With a workspace of amc3d_grid_search_workspace_bytes(b, n, m) the search runs on a uniform grid of cell
+ * edge >= radius (27 cells per query instead of all n points); NULL / too small = the all-pairs scan.
+ * Both give the reference's result exactly. */
+size_t amc3d_grid_search_workspace_bytes(int b, int n_support, int m_queries);
 int amc3d_ball_query(int b, int n, int m, float radius, int nsample,
-                     const float *new_xyz, const float *xyz, int *idx, void *stream);
+                     const float *new_xyz, const float *xyz, int *idx,
+                     void *workspace, size_t workspace_bytes, void *stream);
 
 /* replaces group_points_wrapper_fast (group_points.cpp, group_points_gpu.cu:53-92):
  * points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample) */
@@ -91,8 +96,9 @@ int amc3d_furthest_point_sampling(int b, int n, int m, const float *dataset,
 
 /* replaces three_nn_wrapper_fast (interpolate_gpu.cu:16-81):
  * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) squared distances, idx (b,n,3) */
+/* workspace: amc3d_grid_search_workspace_bytes(b, m, n) (support = known) selects the grid search; NULL = all pairs */
 int amc3d_three_nn(int b, int n, int m, const float *unknown, const float *known,
-                   float *dist2, int *idx, void *stream);
+                   float *dist2, int *idx, void *workspace, size_t workspace_bytes, void *stream);
 
 /* replaces three_interpolate_wrapper_fast (interpolate_gpu.cu:84-124):
  * points (b,c,m), idx/weight (b,n,3) -> out (b,c,n) */

@@ -55,7 +55,10 @@ def test_ball_query_golden(dev, ops_fix, tag):
 @pytest.mark.parametrize("B,N,M,r,ns,kind", [
     (2, 1000, 250, 0.2, 32, "room"), (3, 1031, 517, 0.15, 16, "uniform"), (1, 300, 300, 0.3, 32, "lattice"),
     (2, 64, 7, 0.05, 8, "uniform"), (1, 5000, 1250, 0.1, 32, "room"), (2, 700, 100, 10.0, 32, "dup"),
-    (1, 1, 1, 0.5, 4, "uniform"), (2, 2100, 33, 0.25, 70, "uniform"), (1, 3000, 20, 1e-6, 32, "uniform")])
+    (1, 1, 1, 0.5, 4, "uniform"), (2, 2100, 33, 0.25, 70, "uniform"), (1, 3000, 20, 1e-6, 32, "uniform"),
+    # n*m >= 2^21: the grid search (cell edge >= radius) instead of the all-pairs scan
+    (2, 4096, 1024, 0.3, 32, "lattice"), (1, 6000, 1500, 10.0, 32, "dup"), (2, 3000, 1000, 1e-6, 32, "uniform"),
+    (1, 8000, 600, 0.12, 64, "room"), (3, 2500, 900, 0.4, 5, "uniform"), (1, 2200, 1000, 0.25, 70, "uniform")])
 def test_ball_query_vs_oracle(dev, B, N, M, r, ns, kind):
     from amcontrast3d_amd import ops
     from oracle import pointops_ref as K
@@ -184,7 +187,10 @@ def test_three_nn_and_interpolation_golden(dev, ops_fix, tag):
 
 
 @pytest.mark.parametrize("B,N,M,kind", [(2, 1000, 250, "room"), (1, 517, 3, "uniform"), (2, 300, 2, "uniform"),
-                                        (1, 2000, 1031, "lattice"), (2, 6000, 1500, "room"), (1, 50, 1, "dup")])
+                                        (1, 2000, 1031, "lattice"), (2, 6000, 1500, "room"), (1, 50, 1, "dup"),
+                                        # n*m >= 2^21: grid search; lattice/dup = equal distances everywhere
+                                        (1, 4000, 1000, "lattice"), (2, 5000, 700, "dup"), (1, 3000, 800, "uniform"),
+                                        (3, 1500, 1500, "room")])
 def test_three_nn_vs_oracle(dev, B, N, M, kind):
     from amcontrast3d_amd import _lib, ops
     from oracle import pointops_ref as K
