@@ -123,110 +123,6 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_exact_kernel(
 }
 
 
-// One WORKGROUP per listed query (the grid path's tie fallback: a handful of queries per call, each of
-// which must see its whole segment in index order).  The segment is consumed in steps whose size doubles from
-// 64 up to 4096 candidates (4 per thread): every thread tests its candidates against the heap root as it was
-// at the start of the step (conservative: the root only decreases), and only the survivors are replayed by
-// wave 0 in ascending index order against the heap in LDS.  While a step is as long as everything seen
-// before it, about k of its candidates survive, so the serial part stays at ~k per step instead of the whole
-// first step; the loads of the next step are issued before the barriers of the current one.
-constexpr int KXL_PER = 4;  // candidates per thread and step
-__global__ __launch_bounds__(1024) void knn_exact_list_kernel(
-    int nsample, int nbatch, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
-    const int *__restrict__ offset, const int *__restrict__ new_offset, int *__restrict__ idx,
-    float *__restrict__ dist2, const int *__restrict__ qlist, const int *__restrict__ qcount)
-{
-    __shared__ float hd[KNN_MAXK];
-    __shared__ int hi[KNN_MAXK];
-    __shared__ float s_d2[1024 * KXL_PER];
-    __shared__ unsigned long long s_mask[KXL_PER][16];
-    __shared__ float s_root;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int total = *qcount;
-    for (int qi = blockIdx.x; qi < total; qi += gridDim.x) {
-        const int pt = qlist[qi];
-        int bt = 0;
-        while (bt < nbatch - 1 && !(pt < new_offset[bt])) bt++;
-        const int start = bt == 0 ? 0 : offset[bt - 1], end = offset[bt];
-        const float qx = new_xyz[(size_t)pt * 3], qy = new_xyz[(size_t)pt * 3 + 1], qz = new_xyz[(size_t)pt * 3 + 2];
-        __syncthreads();
-        for (int i = threadIdx.x; i < nsample; i += 1024) { hd[i] = 1e10f; hi[i] = start; }
-        if (threadIdx.x == 0) s_root = 1e10f;
-        __syncthreads();
-
-        auto step_len = [&](int pos) { return min(1024 * KXL_PER, max(64, pos - start)); };
-        float px[KXL_PER], py[KXL_PER], pz[KXL_PER];
-        auto load = [&](int pos, int len) {
-#pragma unroll
-            for (int j = 0; j < KXL_PER; ++j) {
-                const int o = j * 1024 + (int)threadIdx.x;
-                const int i = (o < len && pos + o < end) ? pos + o : start;
-                px[j] = xyz[(size_t)i * 3]; py[j] = xyz[(size_t)i * 3 + 1]; pz[j] = xyz[(size_t)i * 3 + 2];
-            }
-        };
-        int pos = start, len = step_len(start);
-        if (pos < end) load(pos, len);
-        while (pos < end) {
-            const float root0 = s_root;
-            float d2[KXL_PER];
-            bool pass[KXL_PER], any = false;
-#pragma unroll
-            for (int j = 0; j < KXL_PER; ++j) {
-                const int o = j * 1024 + (int)threadIdx.x;
-                d2[j] = dist2_ref(qx, qy, qz, px[j], py[j], pz[j]);
-                pass[j] = o < len && pos + o < end && d2[j] < root0;
-                any |= pass[j];
-            }
-            const int npos = pos + len, nlen = step_len(npos);
-            if (npos < end) load(npos, nlen);  // in flight across the barriers below
-            if (__syncthreads_or(any)) {
-#pragma unroll
-                for (int j = 0; j < KXL_PER; ++j) {
-                    s_d2[j * 1024 + threadIdx.x] = d2[j];
-                    const unsigned long long mk = __ballot(pass[j]);
-                    if (lane == 0) s_mask[j][wave] = mk;
-                }
-                __syncthreads();
-                if (wave == 0) {  // ascending index order: slab by slab, wave by wave, bit by bit
-                    float root = root0;
-                    for (int j = 0; j < KXL_PER; ++j) {
-                        for (int w = 0; w < 16; ++w) {
-                            unsigned long long mm = s_mask[j][w];
-                            while (mm) {
-                                const int b = (int)__builtin_ctzll(mm);
-                                mm &= mm - 1;
-                                const int o = j * 1024 + w * 64 + b;
-                                const float cd = s_d2[o];
-                                if (cd < root) {  // knnquery_cuda_kernel.cu:97-101
-                                    hd[0] = cd;
-                                    hi[0] = pos + o;
-                                    reheap(hd, hi, nsample);
-                                    root = hd[0];
-                                }
-                            }
-                        }
-                    }
-                    if (lane == 0) s_root = root;
-                }
-                __syncthreads();
-            }
-            pos = npos;
-            len = nlen;
-        }
-        if (wave == 0) {
-            for (int i = nsample - 1; i > 0; i--) {  // knnquery_cuda_kernel.cu:39-48
-                const float tf = hd[0]; hd[0] = hd[i]; hd[i] = tf;
-                const int ti = hi[0]; hi[0] = hi[i]; hi[i] = ti;
-                reheap(hd, hi, i);
-            }
-            for (int i = lane; i < nsample; i += 64) {
-                idx[(size_t)pt * nsample + i] = hi[i];
-                dist2[(size_t)pt * nsample + i] = hd[i];
-            }
-        }
-    }
-}
-
 // =============================================================================================
 // Grid-accelerated path (k <= 64).
 //
@@ -395,6 +291,33 @@ __device__ __forceinline__ void ll_feed(LaneList &l, int k, int lane, bool valid
         if (cd < l.tau) rej_uni = fminf(rej_uni, ll_insert(l, k, lane, cd, cc));
         else rej_uni = fminf(rej_uni, cd);
     }
+}
+
+// The first 64 candidates of a query go through a bitonic sorting network instead of up to 64 list insertions
+// (21 compare-exchange stages ~ 200 instructions, against ~23 per insertion and ~45 insertions): afterwards the
+// list is exact for those candidates and tau is already close to final, so few later candidates pass.
+// Lanes without a candidate carry the reference's placeholder (1e10, start) and sort to the tail.
+__device__ __forceinline__ void ll_sort_first(LaneList &l, int k, int lane, bool valid, float d2, int ci, int start,
+                                              float &rej_uni)
+{
+    float v = valid ? d2 : 1e10f;
+    int id = valid ? ci : start;
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const float ov = __shfl_xor(v, stride, 64);
+            const int oi = __shfl_xor(id, stride, 64);
+            const bool take_min = ((lane & stride) == 0) == ((lane & size) == 0);
+            const bool swap = take_min ? (ov < v) : (ov > v);
+            v = swap ? ov : v;
+            id = swap ? oi : id;
+        }
+    }
+    l.v = v;
+    l.id = id;
+    l.tau = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k - 1));
+    if (k < 64) rej_uni = fminf(rej_uni, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)));  // best dropped
 }
 
 // ---- calibration: k-th neighbour distance of KG_SAMPLES queries, estimated on every 8th support point
@@ -582,20 +505,9 @@ __global__ void kg_scatter_kernel(int n, int nb, const float *__restrict__ xyz, 
 }
 
 // ---- queries --------------------------------------------------------------------------------------
-__device__ __forceinline__ void kg_scan_range(LaneList &l, int k, int lane, int b, int e, float qx, float qy, float qz,
-                                              const float4 *__restrict__ sorted, float &rl, float &ru)
-{
-    for (int i0 = b; i0 < e; i0 += 64) {
-        const int i = i0 + lane;
-        const bool valid = i < e;
-        const float4 p = sorted[valid ? i : b];
-        const float d2 = dist2_ref(qx, qy, qz, p.x, p.y, p.z);
-        ll_feed(l, k, lane, valid, d2, __float_as_int(p.w), rl, ru);
-    }
-}
-
 __device__ __forceinline__ void kg_scan_packed(LaneList &l, int k, int lane, int b, int len, float qx, float qy, float qz,
-                                               const float4 *__restrict__ sorted, float &rl, float &ru)
+                                               const float4 *__restrict__ sorted, float &rl, float &ru, bool &fresh,
+                                               int start)
 {
     int incl = len;
     for (int s = 1; s < 64; s <<= 1) {
@@ -620,11 +532,16 @@ __device__ __forceinline__ void kg_scan_packed(LaneList &l, int k, int lane, int
         const bool valid = c < total;
         const float4 p = sorted[valid ? base + c : __builtin_amdgcn_readfirstlane(base + c)];
         const float d2 = dist2_ref(qx, qy, qz, p.x, p.y, p.z);
-        ll_feed(l, k, lane, valid, d2, __float_as_int(p.w), rl, ru);
+        if (fresh) {  // wave-uniform: nothing in the list yet
+            ll_sort_first(l, k, lane, valid, d2, __float_as_int(p.w), start, ru);
+            fresh = false;
+        } else {
+            ll_feed(l, k, lane, valid, d2, __float_as_int(p.w), rl, ru);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void kg_query_kernel(int m, int k, int nb, const float *__restrict__ new_xyz,
+__global__ __launch_bounds__(256) void kg_query_kernel(int m, int k, int nb, int self, const float *__restrict__ new_xyz,
                                                        const int *__restrict__ offset,
                                                        const int *__restrict__ new_offset,
                                                        const GridParams *__restrict__ gp,
@@ -635,7 +552,10 @@ __global__ __launch_bounds__(256) void kg_query_kernel(int m, int k, int nb, con
 {
     const int lane = threadIdx.x & 63;
     const GridParams g = *gp;
-    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < m; q += gridDim.x * 4) {
+    for (int t = blockIdx.x * 4 + (threadIdx.x >> 6); t < m; t += gridDim.x * 4) {
+        // when the queries are the support points themselves they are taken in cell order: the waves of a
+        // workgroup then walk the same cells and share their candidates' cache lines
+        const int q = self ? __float_as_int(sorted[t].w) : t;
         const int seg = nb > 1 ? seg_of(q, new_offset, nb) : 0;
         const int start = seg == 0 ? 0 : offset[seg - 1];
         const float qx = new_xyz[(size_t)q * 3], qy = new_xyz[(size_t)q * 3 + 1], qz = new_xyz[(size_t)q * 3 + 2];
@@ -645,6 +565,7 @@ __global__ __launch_bounds__(256) void kg_query_kernel(int m, int k, int nb, con
         LaneList l;
         ll_init(l, start);
         float rl = 3.4e38f, ru = 3.4e38f;
+        bool fresh = true;
 
         for (int R = 1;; ++R) {
             // (dz,dy) pairs of this shell, one per lane, in batches of 64: a pair on the shell's
@@ -673,8 +594,8 @@ __global__ __launch_bounds__(256) void kg_query_kernel(int m, int k, int nb, con
                 // the runs are short (a few points per cell): feed them PACKED, 64 candidates per step, instead of
                 // one partly filled step per run.  Lane pi owns run pi; an exclusive scan of the run lengths gives
                 // every candidate slot c its run (the last one whose first slot is <= c) and its place in it.
-                kg_scan_packed(l, k, lane, bA, eA - bA, qx, qy, qz, sorted, rl, ru);
-                if (R > 1) kg_scan_packed(l, k, lane, bB, eB - bB, qx, qy, qz, sorted, rl, ru);
+                kg_scan_packed(l, k, lane, bA, eA - bA, qx, qy, qz, sorted, rl, ru, fresh, start);
+                if (R > 1) kg_scan_packed(l, k, lane, bB, eB - bB, qx, qy, qz, sorted, rl, ru, fresh, start);
             }
             // everything outside the scanned block is at least `dmin` away (sides that coincide with
             // the grid boundary impose nothing: there are no points beyond it)
@@ -702,6 +623,279 @@ __global__ __launch_bounds__(256) void kg_query_kernel(int m, int k, int nb, con
         } else if (lane < k) {
             idx[(size_t)q * k + lane] = l.id;
             dist2[(size_t)q * k + lane] = l.v;
+        }
+    }
+}
+
+// One WORKGROUP per listed query (the grid path's tie fallback: a handful of queries per call).  The reference's
+// output for such a query depends on its heap history, i.e. on every ACCEPTED candidate of an ascending index scan
+// (a candidate is accepted iff fewer than k earlier candidates are at most as far).  Two things keep the replay
+// short:
+//  * Pruning by the grid.  Let S be the points of the query's 3x3x3 cell block nearer than the block's
+//    boundary (nothing outside the block is that near), and T the k-th smallest INDEX in S.  Beyond T every
+//    point outside S already has k nearer predecessors and is rejected, so the replay is: all of [start, T) in
+//    index order, then the members of S with index >= T in index order.  T is ~ k/|S| of the segment.
+//  * The prefix [start, T) is consumed in steps whose size doubles from 64 up to 4096 candidates (4 per
+//    thread): every thread tests its candidates against the heap root as it was at the start of the step
+//    (conservative: the root only decreases), and only the survivors (~k per doubling) are replayed by wave 0
+//    against the heap in LDS; the loads of the next step are issued before the barriers of the current one.
+// The replayed max-heap of wave 0 lives in LANES (node i in lane i; the grid path has k <= 64).  Replacing the
+// root is then mostly lane-parallel: every lane finds its larger child (two cross-lane reads), the sift-down path
+// is walked with one v_readlane per level, and all nodes on the path take their child's entry at once.
+// Same result as the reference's reheap (knnquery_cuda_kernel.cu:21-36) after `dist[0] = cd; idx[0] = ci`:
+// the right child is preferred only when strictly larger; the moving value stops when it is strictly larger
+// than the larger child.
+struct LaneHeap {
+    float d;
+    int id;
+};
+__device__ __forceinline__ float lh_root(const LaneHeap &h) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.d), 0)); }
+
+__device__ __forceinline__ void lh_replace_root(LaneHeap &h, int k, int lane, float cd, int ci)
+{
+    const int c1 = 2 * lane + 1, c2 = 2 * lane + 2;
+    const float d1 = __shfl(h.d, c1 & 63, 64), d2 = __shfl(h.d, c2 & 63, 64);
+    const bool right = c2 < k && d2 > d1;
+    const int big = right ? c2 : c1;      // meaningful where c1 < k
+    const float dbig = right ? d2 : d1;
+    int p = 0;
+    unsigned long long path = 0;          // nodes that take their larger child's entry
+    while (2 * p + 1 < k) {
+        const float dc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dbig), p));
+        if (cd > dc) break;
+        path |= 1ull << p;
+        p = __builtin_amdgcn_readlane(big, p);
+    }
+    const int ibig = __shfl(h.id, big & 63, 64);
+    const bool on = (path >> lane) & 1ull;
+    h.d = on ? dbig : h.d;
+    h.id = on ? ibig : h.id;
+    if (lane == p) { h.d = cd; h.id = ci; }
+}
+
+constexpr int KXL_PER = 8;   // candidates per thread and step
+constexpr int KXL_MAXR = 2;  // largest cell block (2R+1)^3 tried for the pruning set
+__global__ __launch_bounds__(1024) void knn_exact_list_kernel(
+    int nsample, int nbatch, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const int *__restrict__ offset, const int *__restrict__ new_offset, int *__restrict__ idx,
+    float *__restrict__ dist2, const int *__restrict__ qlist, const int *__restrict__ qcount,
+    const GridParams *__restrict__ gp, const int *__restrict__ cell_start, const float4 *__restrict__ sorted)
+{
+    __shared__ float s_d2[1024 * KXL_PER];
+    __shared__ float s_rd[1024];  // S by index rank: distance
+    __shared__ int s_ri[1024];    //                  index
+    __shared__ unsigned long long s_mask[KXL_PER][16];
+    __shared__ float s_root;
+    __shared__ int s_run_b[(2 * KXL_MAXR + 1) * (2 * KXL_MAXR + 1)], s_run_e[(2 * KXL_MAXR + 1) * (2 * KXL_MAXR + 1)], s_T, s_cnt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int total = *qcount;
+    for (int qi = blockIdx.x; qi < total; qi += gridDim.x) {
+        const int pt = qlist[qi];
+        int bt = 0;
+        while (bt < nbatch - 1 && !(pt < new_offset[bt])) bt++;
+        const int start = bt == 0 ? 0 : offset[bt - 1], seg_end = offset[bt];
+        const float qx = new_xyz[(size_t)pt * 3], qy = new_xyz[(size_t)pt * 3 + 1], qz = new_xyz[(size_t)pt * 3 + 2];
+        __syncthreads();
+        LaneHeap hp;  // used by wave 0 only
+        hp.d = 1e10f;
+        hp.id = start;
+        if (threadIdx.x == 0) { s_root = 1e10f; s_T = seg_end; s_cnt = 0; }
+        __syncthreads();
+
+        // ---- grid pruning: S and T -------------------------------------------------------------------
+        int *s_si = (int *)(s_d2 + 1024);      // S by candidate slot: index      (s_d2[0..1023]: distance)
+        int ns = 0;                            // |S| when the pruning applies, else 0
+        if (gp) {
+            const GridParams g = *gp;
+            const int cx = cell_coord(qx, g.minx, g.inv_h, g.nx), cy = cell_coord(qy, g.miny, g.inv_h, g.ny),
+                      cz = cell_coord(qz, g.minz, g.inv_h, g.nz);
+            const int *cs = cell_start + (size_t)bt * g.ncell;
+            // the (2R+1)^3 block for R = 1, then 2: the first whose S holds at least k points is used
+            for (int R = 1; R <= KXL_MAXR && ns == 0; ++R) {
+                const int side = 2 * R + 1, nruns = side * side;
+                __syncthreads();
+                if ((int)threadIdx.x < nruns) {
+                    int b = 0, e = 0;
+                    const int z = cz + (int)threadIdx.x / side - R, y = cy + (int)threadIdx.x % side - R;
+                    if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+                        const int row = (z * g.ny + y) * g.nx;
+                        b = cs[row + max(cx - R, 0)];
+                        e = cs[row + min(cx + R, g.nx - 1) + 1];
+                    }
+                    s_run_b[threadIdx.x] = b;
+                    s_run_e[threadIdx.x] = e;
+                }
+                if (threadIdx.x == 0) s_cnt = 0;
+                __syncthreads();
+                float dmin = 3.4e38f;  // distance to the nearest face of the block that has cells beyond it
+                if (cx - R > 0) dmin = fminf(dmin, qx - (g.minx + (float)(cx - R) * g.h));
+                if (cx + R + 1 < g.nx) dmin = fminf(dmin, (g.minx + (float)(cx + R + 1) * g.h) - qx);
+                if (cy - R > 0) dmin = fminf(dmin, qy - (g.miny + (float)(cy - R) * g.h));
+                if (cy + R + 1 < g.ny) dmin = fminf(dmin, (g.miny + (float)(cy + R + 1) * g.h) - qy);
+                if (cz - R > 0) dmin = fminf(dmin, qz - (g.minz + (float)(cz - R) * g.h));
+                if (cz + R + 1 < g.nz) dmin = fminf(dmin, (g.minz + (float)(cz + R + 1) * g.h) - qz);
+                dmin -= g.margin;
+                const float r0 = dmin > 0.f ? dmin * dmin * 0.99999f : 0.f;  // nothing outside the block is nearer
+                int tot = 0;
+                for (int r = 0; r < nruns; ++r) tot += s_run_e[r] - s_run_b[r];
+                if (tot > 1024 * KXL_PER) break;  // workgroup-uniform: too dense for the LDS staging -> full scan
+                // up to KXL_PER block candidates per thread; members of S are appended to the slot arrays
+                float cd[KXL_PER];
+                int ci[KXL_PER];
+                bool in_s[KXL_PER];
+#pragma unroll
+                for (int u = 0; u < KXL_PER; ++u) {
+                    const int c = u * 1024 + (int)threadIdx.x;
+                    in_s[u] = false;
+                    cd[u] = 0.f;
+                    ci[u] = 0;
+                    if (c < tot) {
+                        int acc = 0, src = 0;
+                        for (int r = 0; r < nruns; ++r) {
+                            const int len = s_run_e[r] - s_run_b[r];
+                            if (c >= acc && c < acc + len) src = s_run_b[r] + (c - acc);
+                            acc += len;
+                        }
+                        const float4 p = sorted[src];
+                        cd[u] = dist2_ref(qx, qy, qz, p.x, p.y, p.z);
+                        ci[u] = __float_as_int(p.w);
+                        in_s[u] = cd[u] < r0;
+                    }
+                    if (in_s[u]) {
+                        const int slot = atomicAdd(&s_cnt, 1);
+                        if (slot < 1024) { s_d2[slot] = cd[u]; s_si[slot] = ci[u]; }
+                    }
+                }
+                __syncthreads();
+                const int cnt = s_cnt;
+                if (cnt >= nsample && cnt <= 1024) {
+                    // rank of every member's index within S (indices are distinct)
+#pragma unroll
+                    for (int u = 0; u < KXL_PER; ++u) {
+                        if (in_s[u]) {
+                            int rank = 0;
+                            for (int j = 0; j < cnt; ++j) rank += s_si[j] < ci[u] ? 1 : 0;
+                            s_rd[rank] = cd[u];
+                            s_ri[rank] = ci[u];
+                            if (rank == nsample - 1) s_T = ci[u] + 1;  // the k-th smallest index of S closes the prefix
+                        }
+                    }
+                    ns = cnt;
+                }
+                __syncthreads();
+            }
+        }
+        const int end = s_T;  // == seg_end without pruning
+#ifdef AMC_KNN_DIAG
+        long long t_a = clock64(), t_surv = 0;
+        int n_steps = 0, n_surv = 0, n_acc = 0, n_survsteps = 0;
+#endif
+
+        auto step_len = [&](int pos) { return min(1024 * KXL_PER, max(64, pos - start)); };
+        float px[KXL_PER], py[KXL_PER], pz[KXL_PER];
+        auto load = [&](int pos, int len) {
+#pragma unroll
+            for (int j = 0; j < KXL_PER; ++j) {
+                const int o = j * 1024 + (int)threadIdx.x;
+                const int i = (o < len && pos + o < end) ? pos + o : start;
+                px[j] = xyz[(size_t)i * 3]; py[j] = xyz[(size_t)i * 3 + 1]; pz[j] = xyz[(size_t)i * 3 + 2];
+            }
+        };
+        constexpr int per = KXL_PER;
+        auto step_len2 = [&](int pos) { return step_len(pos); };
+        int pos = start, len = step_len2(start);
+        if (pos < end) load(pos, len);
+        while (pos < end) {
+            const float root0 = s_root;
+            float d2[KXL_PER];
+            bool pass[KXL_PER], any = false;
+#pragma unroll
+            for (int j = 0; j < KXL_PER; ++j) {
+                const int o = j * 1024 + (int)threadIdx.x;
+                d2[j] = dist2_ref(qx, qy, qz, px[j], py[j], pz[j]);
+                pass[j] = o < len && pos + o < end && d2[j] < root0;
+                any |= pass[j];
+            }
+            const int npos = pos + len, nlen = step_len2(npos);
+            if (npos < end) load(npos, nlen);  // in flight across the barriers below
+#ifdef AMC_KNN_DIAG
+            n_steps++;
+            long long t_s0 = clock64();
+#endif
+            if (__syncthreads_or(any)) {
+#ifdef AMC_KNN_DIAG
+                n_survsteps++;
+#endif
+#pragma unroll
+                for (int j = 0; j < KXL_PER; ++j) {
+                    if (j < per) s_d2[j * 1024 + threadIdx.x] = d2[j];
+                    const unsigned long long mk = __ballot(pass[j]);
+                    if (lane == 0) s_mask[j][wave] = mk;
+                }
+                __syncthreads();
+                if (wave == 0) {  // ascending index order: slab by slab, wave by wave, bit by bit
+                    float root = root0;
+                    // lane (j*16 + w) fetches mask word (j, w); only the non-empty words are visited
+                    // (KXL_PER * 16 = 128 words: two per lane, slabs 0-3 then 4-7)
+                  for (int half = 0; half < KXL_PER / 4; ++half) {
+                    const unsigned long long mine = s_mask[half * 4 + (lane >> 4)][lane & 15];
+                    unsigned long long words = __ballot(mine != 0);
+                    while (words) {
+                        const int wsel = (int)__builtin_ctzll(words);
+                        words &= words - 1;
+                        unsigned long long mm = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), wsel) << 32) |
+                                                (unsigned)__builtin_amdgcn_readlane((int)(mine & 0xffffffffu), wsel);
+                        while (mm) {
+                            const int b = (int)__builtin_ctzll(mm);
+                            mm &= mm - 1;
+                            const int o = half * 4096 + wsel * 64 + b;  // == j*1024 + w*64 + b
+                            const float cd = s_d2[o];
+#ifdef AMC_KNN_DIAG
+                            n_surv++;
+                            if (cd < root) n_acc++;
+#endif
+                            if (cd < root) {  // knnquery_cuda_kernel.cu:97-101
+                                lh_replace_root(hp, nsample, lane, cd, pos + o);
+                                root = lh_root(hp);
+                            }
+                        }
+                    }
+                  }
+                    if (lane == 0) s_root = root;
+                }
+                __syncthreads();
+#ifdef AMC_KNN_DIAG
+                t_surv += clock64() - t_s0;
+#endif
+            }
+            pos = npos;
+            len = nlen;
+        }
+#ifdef AMC_KNN_DIAG
+        if (threadIdx.x == 0)
+            printf("replay q=%d T=%d |S|=%d steps=%d survsteps=%d surv=%d acc=%d  prefix_clk=%lld surv_clk=%lld\n", pt, end, ns,
+                   n_steps, n_survsteps, n_surv, n_acc, (long long)(clock64() - t_a), t_surv);
+#endif
+        if (wave == 0) {
+            // the members of S beyond the prefix, in index order (ranks nsample.. hold the indices >= T)
+            float root = s_root;
+            for (int r = nsample; r < ns; ++r) {
+                const float cd = s_rd[r];
+                if (cd < root) {
+                    lh_replace_root(hp, nsample, lane, cd, s_ri[r]);
+                    root = lh_root(hp);
+                }
+            }
+            for (int i = nsample - 1; i > 0; i--) {  // knnquery_cuda_kernel.cu:39-48: swap(0, i); reheap(i)
+                const float d0 = lh_root(hp), di = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hp.d), i));
+                const int j0 = __builtin_amdgcn_readlane(hp.id, 0), ji = __builtin_amdgcn_readlane(hp.id, i);
+                if (lane == i) { hp.d = d0; hp.id = j0; }
+                lh_replace_root(hp, i, lane, di, ji);
+            }
+            if (lane < nsample) {
+                idx[(size_t)pt * nsample + lane] = hp.id;
+                dist2[(size_t)pt * nsample + lane] = hp.d;
+            }
         }
     }
 }
@@ -1011,10 +1205,12 @@ AMC_API int amc3d_knnquery(int m, int nsample, int n, int nbatch, const float *x
     int *cell_start = (int *)(base + w.cell_start);
     float4 *sorted = (float4 *)(base + w.sorted);
     int *fb_list = (int *)(base + w.fb_list);
-    hipLaunchKernelGGL(kg_query_kernel, dim3(min(div_up(m, 4), 256 * 32)), dim3(256), 0, stream, m, nsample, nbatch,
+    const int self = (new_xyz == xyz && m == n && new_offset == offset) ? 1 : 0;
+    hipLaunchKernelGGL(kg_query_kernel, dim3(min(div_up(m, 4), 256 * 32)), dim3(256), 0, stream, m, nsample, nbatch, self,
                        new_xyz, offset, new_offset, gp, cell_start, sorted, idx, dist2, fb_list, fb_count);
     // queries with equal distances among their k+1 nearest: replay the reference's heap
     hipLaunchKernelGGL(knn_exact_list_kernel, dim3(256), dim3(1024), 0, stream, nsample, nbatch, xyz, new_xyz, offset,
-                       new_offset, idx, dist2, (const int *)fb_list, (const int *)fb_count);
+                       new_offset, idx, dist2, (const int *)fb_list, (const int *)fb_count, (const GridParams *)gp,
+                       (const int *)cell_start, (const float4 *)sorted);
     return launch_status("amc3d_knnquery");
 }
