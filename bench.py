@@ -76,7 +76,7 @@ def build(variant, dev, world, ddp):
     for p in model.parameters():
         (no_decay if p.ndim <= 1 else decay).append(p)
     opt = torch.optim.AdamW([{"params": decay, "weight_decay": 1e-4}, {"params": no_decay, "weight_decay": 0.0}],
-                            lr=0.01, capturable=True)
+                            lr=0.01, capturable=True, fused=True)
     return cfg, model, criterion, aargs, opt
 
 
