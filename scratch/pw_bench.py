@@ -3,7 +3,7 @@ sys.path.insert(0,'.')
 import torch.nn.functional as F
 from amcontrast3d_amd import ops
 DEV='cuda:0'
-shapes=[(8,4,32,(24000,)),(8,96,32,(24000,)),(8,32,32,(24000,)),(8,32,13,(24000,)),(8,192,64,(6000,)),(8,64,64,(6000,)),
+shapes=[(8,32,64,(6000,32)),(8,64,128,(1500,32)),(8,128,256,(375,32)),(8,256,512,(93,32)),(8,4,32,(24000,)),(8,96,32,(24000,)),(8,32,32,(24000,)),(8,32,13,(24000,)),(8,192,64,(6000,)),(8,64,64,(6000,)),
         (8,384,128,(1500,)),(8,128,128,(1500,)),(8,768,256,(375,)),(8,256,256,(375,)),(8,131,256,(375,32)),(8,259,512,(93,32))]
 def tm(fn,n=20):
     for _ in range(3): fn()
