@@ -296,11 +296,20 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = points_per_step * world / (dt / args.steps)
         dom_name, dom = max(kernels.items(), key=lambda kv: kv[1]["total_ms"]) if kernels else (None, None)
+        # HBM bytes per launch from the PMC passes committed under profiles/ (collected with rocprofv3 --pmc in
+        # separate runs, as gpurun requires; None for operators that were not measured)
+        traffic = {}
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")) as fh:
+                traffic = json.load(fh)
+        except OSError:
+            pass
         roofline = None
         if dom is not None:
             achieved = dom["bytes_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                        "traffic": traffic.get(dom_name, {}).get("bytes_per_launch"),
                         "avg_launch_ms": round(dom["avg_ms"], 4), "launches_per_step": dom["launches"] / args.steps,
                         "algorithmic_bytes_per_launch": int(dom["bytes_per_launch"])}
         # the largest bandwidth-bound native kernel family next to it (FPS is a latency chain: its HBM
@@ -313,7 +322,9 @@ def main():
             hv = kernels[hk]
             ach = hv["bytes"] / (hv["total_ms"] * 1e-3) / 1e9
             roofline_hbm = {"bound": "hbm", "kernel": hk, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                            "frac": round(ach / HBM_PEAK_GBS, 4),
+                            "traffic": traffic.get(hk, {}).get("bytes_per_launch"),
+                            "algorithmic_bytes_per_launch": int(hv["bytes_per_launch"]),
                             "ms_per_step": round(hv["total_ms"] / args.steps, 3),
                             "launches_per_step": hv["launches"] / args.steps,
                             "note": "algorithmic bytes of all launches of this operator / their summed HIP-event time"}
