@@ -242,6 +242,14 @@ static void launch_pw_wgrad(const PwSplit &s, int M, int K, long P, const float 
                        s.tiles_per_cloud, s.ntiles, s.tiles_per_wg, dy, x, partial, vec);
 }
 
+// gemm.hip: the MFMA-bound variant for layers with >= 64 channels on both sides
+bool gemm_conv_pays(int cin, int cout);
+int gemm_conv_forward(int b, int cin, int cout, long P, const float *x, const float *w, float *y, hipStream_t stream);
+int gemm_conv_backward_data(int b, int cin, int cout, long P, const float *dy, const float *w, float *dx, hipStream_t stream);
+size_t gemm_conv_wgrad_workspace_bytes(int b, int cin, int cout, long P);
+int gemm_conv_backward_weight(int b, int cin, int cout, long P, const float *x, const float *dy, float *dw, float *partial,
+                              hipStream_t stream);
+
 }  // namespace amc
 
 using namespace amc;
@@ -252,6 +260,8 @@ AMC_API int amc3d_pointwise_conv_forward(int b, int cin, int cout, long P, const
 {
     if (b <= 0 || P <= 0 || cout <= 0) return 0;
     if (cin <= 0 || !x || !weight || !y) return bad_arg("amc3d_pointwise_conv_forward: bad argument");
+    if (!bias && gemm_conv_pays(cin, cout) && P < (1L << 31))
+        return gemm_conv_forward(b, cin, cout, P, x, weight, y, (hipStream_t)stream);
     pw_gemm(b, cout, cin, P, weight, cin, 1, bias, x, y, (hipStream_t)stream);
     return launch_status("amc3d_pointwise_conv_forward");
 }
@@ -259,6 +269,7 @@ AMC_API int amc3d_pointwise_conv_forward(int b, int cin, int cout, long P, const
 AMC_API size_t amc3d_pointwise_conv_workspace_bytes(int b, int cin, int cout, long P)
 {
     if (b <= 0 || P <= 0 || cin <= 0 || cout <= 0) return 0;
+    if (gemm_conv_pays(cin, cout) && P < (1L << 31)) return gemm_conv_wgrad_workspace_bytes(b, cin, cout, P);
     const PwSplit s = pw_split(b, cin, cout, P);
     return (size_t)s.groups * cout * cin * sizeof(float);
 }
@@ -271,10 +282,15 @@ AMC_API int amc3d_pointwise_conv_backward(int b, int cin, int cout, long P, cons
     if (b <= 0 || P <= 0) return 0;
     if (cin <= 0 || cout <= 0 || !weight || !dy) return bad_arg("amc3d_pointwise_conv_backward: bad argument");
     hipStream_t stream = (hipStream_t)stream_;
-    if (dx) pw_gemm(b, cin, cout, P, weight, 1, cin, nullptr, dy, dx, stream);
+    const bool deep = gemm_conv_pays(cin, cout) && P < (1L << 31);
+    if (dx) {
+        if (deep && cout > 128) { if (int st = gemm_conv_backward_data(b, cin, cout, P, dy, weight, dx, stream)) return st; }
+        else pw_gemm(b, cin, cout, P, weight, 1, cin, nullptr, dy, dx, stream);
+    }
     if (dweight) {
         if (!x || !workspace || workspace_bytes < amc3d_pointwise_conv_workspace_bytes(b, cin, cout, P))
             return bad_arg("amc3d_pointwise_conv_backward: null pointer or workspace too small");
+        if (deep) return gemm_conv_backward_weight(b, cin, cout, P, x, dy, dweight, (float *)workspace, stream);
         const PwSplit s = pw_split(b, cin, cout, P);
         float *partial = (float *)workspace;
 #define AMC_PWW(A, B) launch_pw_wgrad<A, B>(s, cout, cin, P, dy, x, partial, stream)

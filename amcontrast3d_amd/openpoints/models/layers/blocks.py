@@ -148,6 +148,8 @@ def _pw_pays(conv, x):
     the deep, narrow ones (>= 128 channels over <= 10^5 positions) are MFMA-bound GEMMs the library does better."""
     positions = x.numel() // x.shape[1]
     cin, cout = conv.in_channels, conv.out_channels
+    if min(cin, cout) >= 64:  # csrc/gemm.hip: double-buffered 128x128 MFMA tiles, on par with the library GEMMs and
+        return positions >= 65536  # without MIOpen's layout transposes around the weight gradient
     return positions >= 131072 and max(cin, cout) <= 128 or (max(cin, cout) <= 64 and positions >= 32768)
 
 
