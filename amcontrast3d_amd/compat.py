@@ -94,7 +94,7 @@ def knnquery_cuda(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2):
     work = torch.empty(wbytes, dtype=torch.uint8, device=xyz.device)
     with torch.cuda.device(xyz.device):
         _lib.check(lib.amc3d_knnquery(m, nsample, n, nb, _p(xyz), _p(new_xyz), _p(offset), _p(new_offset), _p(idx),
-                                      _p(dist2), _p(work), wbytes, _s(xyz)), "amc3d_knnquery")
+                                      _p(dist2), _p(work), wbytes, 0, _s(xyz)), "amc3d_knnquery")
 
 
 def _module(name, fns):

@@ -1176,7 +1176,7 @@ AMC_API size_t amc3d_knnquery_workspace_bytes(int n, int m, int nsample, int nba
 
 AMC_API int amc3d_knnquery(int m, int nsample, int n, int nbatch, const float *xyz, const float *new_xyz,
                            const int *offset, const int *new_offset, int *idx, float *dist2, void *workspace,
-                           size_t workspace_bytes, void *stream_)
+                           size_t workspace_bytes, int reuse_grid, void *stream_)
 {
     if (m <= 0) return 0;
     if (nsample <= 0 || nsample > KNN_MAXK) return bad_arg("amc3d_knnquery: nsample must be in 1..100");
@@ -1197,9 +1197,14 @@ AMC_API int amc3d_knnquery(int m, int nsample, int n, int nbatch, const float *x
     static const int kg_sub = getenv("AMC3D_KG_SUB") ? atoi(getenv("AMC3D_KG_SUB")) : 8;
     static const int kg_extra = getenv("AMC3D_KG_EXTRA") ? atoi(getenv("AMC3D_KG_EXTRA")) : 1;
     static const float kg_scale = getenv("AMC3D_KG_SCALE") ? (float)atof(getenv("AMC3D_KG_SCALE")) : 1.1f;
-    if (int st = kg_build(w, base, n, m, nbatch, xyz, new_xyz, offset, new_offset, (nsample + kg_sub - 1) / kg_sub + kg_extra,
-                          kg_sub, kg_scale, 0.f, stream))
+    if (reuse_grid) {
+        // the workspace still holds the grid of this very support set (xyz, offset) from an earlier call: its cell
+        // size was calibrated for that call's k, which only steers speed.  Only the replay counter is reset.
+        hipLaunchKernelGGL(kg_init_kernel, dim3(1), dim3(64), 0, stream, (int *)(base + w.bbox), (int *)(base + w.fb_count));
+    } else if (int st = kg_build(w, base, n, m, nbatch, xyz, new_xyz, offset, new_offset,
+                                 (nsample + kg_sub - 1) / kg_sub + kg_extra, kg_sub, kg_scale, 0.f, stream)) {
         return st;
+    }
     GridParams *gp = (GridParams *)(base + w.params);
     int *fb_count = (int *)(base + w.fb_count);
     int *cell_start = (int *)(base + w.cell_start);

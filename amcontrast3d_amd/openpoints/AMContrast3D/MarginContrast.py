@@ -124,7 +124,10 @@ class ContrastHead(nn.Module):
 
     def plan(self, target, stageACE_list, num_classes, ignore_index, ambiguity_args):
         """coordinate / label-only part of every stage (see plan_stage)"""
-        with torch.no_grad():
+        from amcontrast3d_amd import ops
+        # the full-resolution cloud is searched four times (its own neighbours, then the label votes of the three
+        # coarser stages): one cell grid serves all four
+        with torch.no_grad(), ops.knn_grid_reuse():
             return [plan_stage(ambiguity_args.stages, i, stageACE_list, target.flatten(), self.nstride, num_classes,
                                ignore_index, ambiguity_args, self.ftype) for i in range(ambiguity_args.stages_num)]
 

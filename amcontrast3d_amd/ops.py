@@ -235,6 +235,24 @@ def three_interpolation(unknown_xyz, known_xyz, know_feat):
     return three_interpolate(know_feat, idx, weight)
 
 
+_grid_cache = None  # {(support ptr, n, offset ptr, segments, stream): workspace} while knn_grid_reuse() is active
+
+
+class knn_grid_reuse:
+    """with knn_grid_reuse(): k-NN searches over the same support tensor (same storage, same offsets) reuse the
+    cell grid the first of them built -- the caller guarantees the support is not modified inside the block."""
+
+    def __enter__(self):
+        global _grid_cache
+        self.prev, _grid_cache = _grid_cache, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _grid_cache
+        _grid_cache = self.prev
+        return False
+
+
 class KNNQuery(Function):
     @staticmethod
     def forward(ctx, nsample, xyz, new_xyz, offset, new_offset):
@@ -250,11 +268,18 @@ class KNNQuery(Function):
         dist2 = torch.empty(m, nsample, dtype=torch.float32, device=xyz.device)
         lib = _lib.load()
         wbytes = int(lib.amc3d_knnquery_workspace_bytes(n, m, nsample, nb))
-        work = torch.empty(wbytes, dtype=torch.uint8, device=xyz.device)
+        offset, new_offset = offset.contiguous(), new_offset.contiguous()
+        # inside `with knn_grid_reuse():` searches over the same support set share one cell grid
+        key = (xyz.data_ptr(), n, offset.data_ptr(), nb, _stream(xyz).value)
+        cached = _grid_cache.get(key) if _grid_cache is not None else None
+        reuse = cached is not None and cached.numel() >= wbytes and nsample <= 64
+        work = cached if reuse else torch.empty(wbytes, dtype=torch.uint8, device=xyz.device)
+        if _grid_cache is not None and not reuse and nsample <= 64:
+            _grid_cache[key] = work
         with torch.cuda.device(xyz.device), timing.span("knnquery", (n + m) * 12 + m * nsample * 8):
-            _lib.check(lib.amc3d_knnquery(m, nsample, n, nb, _ptr(xyz), _ptr(new_xyz), _ptr(offset.contiguous()),
-                                          _ptr(new_offset.contiguous()), _ptr(idx), _ptr(dist2), _ptr(work), wbytes,
-                                          _stream(xyz)), "knnquery")
+            _lib.check(lib.amc3d_knnquery(m, nsample, n, nb, _ptr(xyz), _ptr(new_xyz), _ptr(offset),
+                                          _ptr(new_offset), _ptr(idx), _ptr(dist2), _ptr(work), work.numel(),
+                                          int(reuse), _stream(xyz)), "knnquery")
         ctx.mark_non_differentiable(idx)
         return idx, torch.sqrt(dist2)
 
@@ -400,6 +425,7 @@ class BatchNormAct(Function):
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
         ctx.relu = bool(relu)
         ctx.mark_non_differentiable(mean, var_u)
+        ctx.set_materialize_grads(False)  # no zero tensors for the statistics' (absent) gradients
         return y, mean, var_u
 
     @staticmethod
@@ -454,6 +480,7 @@ class BatchNormMax(Function):
         ctx.save_for_backward(x, gamma, beta, mean, invstd, arg)
         ctx.relu = bool(relu)
         ctx.mark_non_differentiable(mean, var_u)
+        ctx.set_materialize_grads(False)  # no zero tensors for the statistics' (absent) gradients
         return y, mean, var_u
 
     @staticmethod

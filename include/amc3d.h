@@ -122,11 +122,14 @@ int amc3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_o
  * -> idx (m,nsample), dist2 (m,nsample) squared distances, ascending.
  * nsample <= 100 (the reference's per-thread heap is float[100]).
  * Results equal the reference's max-heap + heap-sort including how equal
- * distances are ordered. */
+ * distances are ordered.
+ * reuse_grid != 0: the workspace was last used by amc3d_knnquery with the SAME support set (xyz, offset, n,
+ * nbatch) and at least as many queries; its cell grid is kept and only the queries run (the loss asks for
+ * four neighbour sets of the full-resolution cloud per step).  Results are identical either way. */
 size_t amc3d_knnquery_workspace_bytes(int n, int m, int nsample, int nbatch);
 int amc3d_knnquery(int m, int nsample, int n, int nbatch, const float *xyz, const float *new_xyz,
                    const int *offset, const int *new_offset, int *idx, float *dist2,
-                   void *workspace, size_t workspace_bytes, void *stream);
+                   void *workspace, size_t workspace_bytes, int reuse_grid, void *stream);
 
 /* ---- adaptive-margin contrastive loss -------------------------------------------
  * The reference has no native code here: it evaluates this part with torch ops and a Python
