@@ -50,6 +50,7 @@ SIGNATURES = {
     "amc3d_pointwise_conv_backward": (_i, [_i, _i, _i, _l, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_bn_workspace_bytes": (_sz, [_i]),
     "amc3d_bn_stats": (_i, [_i, _i, _l, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "amc3d_bn_forward": (_i, [_i, _i, _l, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_bn_update_running": (_i, [_i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_bn_act": (_i, [_i, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_bn_max": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

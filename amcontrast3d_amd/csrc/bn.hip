@@ -96,16 +96,71 @@ __device__ __forceinline__ float bn_val(float x, float mean, float invstd, float
     return __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(x, mean), invstd), gamma), beta);
 }
 
+// When `partial` is set, the consumer kernels derive mean / invstd from the statistics kernel's partial sums
+// themselves (<= 64 pairs per channel: one wave, one LDS broadcast) instead of waiting for a separate finalize
+// launch; the first workgroup of every channel also publishes them (backward needs them) and performs
+// nn.BatchNorm's running-stat update, so a training-mode BN layer is two launches, not four.
+struct BnFused {
+    const double *partial;
+    int nchunks;
+    double count;
+    float eps, momentum;  // momentum < 0: no running update here (cumulative mode keeps its own launch)
+    float *mean_out, *invstd_out, *var_out, *running_mean, *running_var;
+    long long *tracked;
+};
+
+__device__ __forceinline__ void bn_partial_sums(const double *__restrict__ partial, int c, int nchunks, double &s1, double &s2)
+{
+    s1 = 0.0; s2 = 0.0;  // executed by the first wave only
+    for (int k = threadIdx.x; k < nchunks; k += 64) {
+        s1 += partial[((size_t)c * nchunks + k) * 2 + 0];
+        s2 += partial[((size_t)c * nchunks + k) * 2 + 1];
+    }
+    for (int s = 32; s >= 1; s >>= 1) { s1 += __shfl_xor(s1, s, 64); s2 += __shfl_xor(s2, s, 64); }
+}
+
+// mean and invstd of channel c, either given or derived from the partial sums (`writer`: this workgroup publishes)
+__device__ __forceinline__ void bn_channel_stats(const BnFused &f, int c, bool writer, const float *__restrict__ mean,
+                                                 const float *__restrict__ invstd, float &m, float &is)
+{
+    if (!f.partial) { m = mean[c]; is = invstd[c]; return; }
+    __shared__ float s_stat[2];
+    if (threadIdx.x < 64) {
+        double s1, s2;
+        bn_partial_sums(f.partial, c, f.nchunks, s1, s2);
+        if (threadIdx.x == 0) {
+            const double mu = s1 / f.count;
+            double var = s2 / f.count - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const float mf = (float)mu, isf = (float)(1.0 / sqrt(var + (double)f.eps));
+            s_stat[0] = mf; s_stat[1] = isf;
+            if (writer) {
+                const float vu = (float)(f.count > 1.0 ? var * f.count / (f.count - 1.0) : var);
+                f.mean_out[c] = mf; f.invstd_out[c] = isf; f.var_out[c] = vu;
+                if (f.running_mean && f.momentum >= 0.f) {  // running.mul_(1 - m).add_(batch, alpha=m)
+                    f.running_mean[c] = f.running_mean[c] * (1.f - f.momentum) + f.momentum * mf;
+                    f.running_var[c] = f.running_var[c] * (1.f - f.momentum) + f.momentum * vu;
+                    if (c == 0 && f.tracked) *f.tracked += 1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    m = s_stat[0]; is = s_stat[1];
+}
+
 // y = [relu](bn(x)), elementwise over (B, C, L); 4 elements per thread when L % 4 == 0
 __global__ __launch_bounds__(BN_THREADS) void bn_act_kernel(int C, long L, int relu, const float *__restrict__ x,
                                                             const float *__restrict__ mean,
                                                             const float *__restrict__ invstd,
                                                             const float *__restrict__ gamma,
-                                                            const float *__restrict__ beta, float *__restrict__ y)
+                                                            const float *__restrict__ beta, float *__restrict__ y, BnFused f)
 {
     const int bc = blockIdx.y;  // b * C + c
     const int c = bc % C;
-    const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
+    float m, is;
+    bn_channel_stats(f, c, blockIdx.x == 0 && bc < C, mean, invstd, m, is);
+    const float g = gamma[c], bt = beta[c];
     const float *xr = x + (size_t)bc * L;
     float *yr = y + (size_t)bc * L;
     if ((L & 3) == 0) {
@@ -130,13 +185,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_kernel(int C, int M, int K,
                                                             const float *__restrict__ invstd,
                                                             const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, float *__restrict__ y,
-                                                            unsigned char *__restrict__ arg)
+                                                            unsigned char *__restrict__ arg, BnFused f)
 {
     const int bc = blockIdx.y;
     const int c = bc % C;
     const int mi = blockIdx.x * BN_THREADS + threadIdx.x;
+    float m, is;
+    bn_channel_stats(f, c, blockIdx.x == 0 && bc < C, mean, invstd, m, is);
     if (mi >= M) return;
-    const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
+    const float g = gamma[c], bt = beta[c];
     const float *xr = x + ((size_t)bc * M + mi) * K;
     float best = -__builtin_inff();
     int bk = 0;
@@ -171,11 +228,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_coop_kernel(int C, int M, i
                                                                  const float *__restrict__ invstd,
                                                                  const float *__restrict__ gamma,
                                                                  const float *__restrict__ beta, float *__restrict__ y,
-                                                                 unsigned char *__restrict__ arg)
+                                                                 unsigned char *__restrict__ arg, BnFused f)
 {
     const int bc = blockIdx.y;
     const int c = bc % C;
-    const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
+    float m, is;
+    bn_channel_stats(f, c, blockIdx.x == 0 && bc < C, mean, invstd, m, is);
+    const float g = gamma[c], bt = beta[c];
     const float4 *xr = reinterpret_cast<const float4 *>(x + (size_t)bc * M * (LPR * 4));
     const long nf4 = (long)M * LPR;
     for (long f = (long)blockIdx.x * BN_THREADS + threadIdx.x; f < ((nf4 + 63) & ~63L); f += (long)gridDim.x * BN_THREADS) {
@@ -251,35 +310,30 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_kernel(
     }
 }
 
-// dgamma = Sb, dbeta = Sa, and the two per-channel coefficients of the dense term
-__global__ void bn_bwd_finalize_kernel(int C, int nchunks, double count, const double *__restrict__ partial,
-                                       float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                       float *__restrict__ mean_dq, float *__restrict__ mean_dq_xhat)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double sa = 0.0, sb = 0.0;
-    for (int k = 0; k < nchunks; ++k) {
-        sa += partial[((size_t)c * nchunks + k) * 2 + 0];
-        sb += partial[((size_t)c * nchunks + k) * 2 + 1];
-    }
-    dbeta[c] = (float)sa;
-    dgamma[c] = (float)sb;
-    mean_dq[c] = (float)(sa / count);
-    mean_dq_xhat[c] = (float)(sb / count);
-}
-
 // dx = gamma * invstd * (dq - mean(dq) - xhat * mean(dq * xhat))   (training-mode BN backward)
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
     int mode, int C, long L, int K, int relu, int vec, const float *__restrict__ x, const float *__restrict__ dy,
     const unsigned char *__restrict__ arg, const float *__restrict__ mean, const float *__restrict__ invstd,
-    const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ mean_dq,
-    const float *__restrict__ mean_dq_xhat, float *__restrict__ dx)
+    const float *__restrict__ gamma, const float *__restrict__ beta, const double *__restrict__ partial, int nchunks,
+    double count, float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dx)
 {
     const int bc = blockIdx.y;
     const int c = bc % C;
     const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
-    const float ma = mean_dq[c], mb = mean_dq_xhat[c], gi = __fmul_rn(g, is);
+    // Sa = sum dq, Sb = sum dq * xhat from the statistics kernel's partials (no separate finalize launch);
+    // the first workgroup of the channel also publishes dbeta = Sa, dgamma = Sb
+    __shared__ float s_co[2];
+    if (threadIdx.x < 64) {
+        double sa, sb;
+        bn_partial_sums(partial, c, nchunks, sa, sb);
+        if (threadIdx.x == 0) {
+            s_co[0] = (float)(sa / count);
+            s_co[1] = (float)(sb / count);
+            if (blockIdx.x == 0 && bc < C) { dbeta[c] = (float)sa; dgamma[c] = (float)sb; }
+        }
+    }
+    __syncthreads();
+    const float ma = s_co[0], mb = s_co[1], gi = __fmul_rn(g, is);
     const float *xr = x + (size_t)bc * L;
     float *dr = dx + (size_t)bc * L;
     auto one = [&](float xv, float d) {
@@ -397,8 +451,27 @@ AMC_API int amc3d_bn_act(int B, int C, long L, int relu, const float *x, const f
     const long per_block = BN_THREADS * 4 * 4;
     const int gx = (int)min((L + per_block - 1) / per_block, (long)4096);
     hipLaunchKernelGGL(bn_act_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, (hipStream_t)stream, C, L, relu, x, mean,
-                       invstd, gamma, beta, y);
+                       invstd, gamma, beta, y, BnFused{});
     return launch_status("amc3d_bn_act");
+}
+
+static int launch_bn_max(int B, int C, int M, int K, int relu, const float *x, const float *mean, const float *invstd,
+                         const float *gamma, const float *beta, float *y, unsigned char *arg, const BnFused &f,
+                         hipStream_t stream)
+{
+    const int lpr = K / 4;
+    if (K % 4 == 0 && (lpr == 2 || lpr == 4 || lpr == 8 || lpr == 16) && aligned16(x)) {
+        const int gx = (int)min((long)div_up((long)M * lpr, BN_THREADS * 4), 65535L);
+#define AMC_BNMAX(N)                                                                                                 \
+    hipLaunchKernelGGL(bn_max_coop_kernel<N>, dim3(gx, B * C), dim3(BN_THREADS), 0, stream, C, M, relu, x, mean, invstd, \
+                       gamma, beta, y, arg, f)
+        if (lpr == 2) AMC_BNMAX(2); else if (lpr == 4) AMC_BNMAX(4); else if (lpr == 8) AMC_BNMAX(8); else AMC_BNMAX(16);
+#undef AMC_BNMAX
+        return launch_status("amc3d_bn_max");
+    }
+    hipLaunchKernelGGL(bn_max_kernel, dim3(div_up(M, BN_THREADS), B * C), dim3(BN_THREADS), 0, stream, C, M, K, relu, x, mean,
+                       invstd, gamma, beta, y, arg, f);
+    return launch_status("amc3d_bn_max");
 }
 
 // y (B, C, M) = max over the K neighbours of [relu](bn(x (B, C, M, K))); arg (B, C, M) bytes, K <= 255
@@ -408,19 +481,51 @@ AMC_API int amc3d_bn_max(int B, int C, int M, int K, int relu, const float *x, c
     if (B <= 0 || C <= 0 || M <= 0) return 0;
     if (K <= 0 || K > 255 || !x || !mean || !invstd || !gamma || !beta || !y || !arg)
         return bad_arg("amc3d_bn_max: bad argument (K must be in 1..255)");
-    const int lpr = K / 4;
-    if (K % 4 == 0 && (lpr == 2 || lpr == 4 || lpr == 8 || lpr == 16) && aligned16(x)) {
-        const int gx = (int)min((long)div_up((long)M * lpr, BN_THREADS * 4), 65535L);
-#define AMC_BNMAX(N)                                                                                                   \
-    hipLaunchKernelGGL(bn_max_coop_kernel<N>, dim3(gx, B * C), dim3(BN_THREADS), 0, (hipStream_t)stream, C, M, relu, x, \
-                       mean, invstd, gamma, beta, y, arg)
-        if (lpr == 2) AMC_BNMAX(2); else if (lpr == 4) AMC_BNMAX(4); else if (lpr == 8) AMC_BNMAX(8); else AMC_BNMAX(16);
-#undef AMC_BNMAX
-        return launch_status("amc3d_bn_max");
+    return launch_bn_max(B, C, M, K, relu, x, mean, invstd, gamma, beta, y, arg, BnFused{}, (hipStream_t)stream);
+}
+
+// Training-mode BatchNorm forward in two launches: statistics, then normalise [+ReLU] (K == 0: y (B,C,L)) or
+// normalise [+ReLU] + max over the K neighbours (K > 0: L = M*K, y (B,C,M), arg (B,C,M)).  Writes mean, invstd,
+// var_unbiased (C each) and, when running_mean is given, performs nn.BatchNorm's buffer update
+// (momentum < 0 = None: cumulative average).
+AMC_API int amc3d_bn_forward(int B, int C, long L, int K, int relu, float eps, float momentum, const float *x,
+                             const float *gamma, const float *beta, float *y, unsigned char *arg, float *mean,
+                             float *invstd, float *var_unbiased, float *running_mean, float *running_var,
+                             long long *num_batches_tracked, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    if (B <= 0 || C <= 0 || L <= 0) return 0;
+    if (!x || !gamma || !beta || !y || !mean || !invstd || !var_unbiased || !workspace ||
+        workspace_bytes < amc3d_bn_workspace_bytes(C) || K < 0 || K > 255 || (K > 0 && (!arg || L % K != 0)) ||
+        (running_mean && (!running_var || !num_batches_tracked)))
+        return bad_arg("amc3d_bn_forward: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const BnSplit sp = bn_split(B, C, L);
+    const int vec = (L % 4 == 0) && aligned16(x);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(sp.nchunks, C), dim3(BN_THREADS), 0, stream, B, C, L, sp, vec, x,
+                       (double *)workspace);
+    BnFused f{};
+    f.partial = (const double *)workspace;
+    f.nchunks = sp.nchunks;
+    f.count = (double)B * (double)L;
+    f.eps = eps;
+    f.momentum = momentum;
+    f.mean_out = mean; f.invstd_out = invstd; f.var_out = var_unbiased;
+    f.running_mean = running_mean; f.running_var = running_var; f.tracked = num_batches_tracked;
+    int st;
+    if (K == 0) {
+        const long per_block = BN_THREADS * 4 * 4;
+        const int gx = (int)min((L + per_block - 1) / per_block, (long)4096);
+        hipLaunchKernelGGL(bn_act_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, stream, C, L, relu, x, mean, invstd, gamma,
+                           beta, y, f);
+        st = launch_status("amc3d_bn_forward");
+    } else {
+        st = launch_bn_max(B, C, (int)(L / K), K, relu, x, mean, invstd, gamma, beta, y, arg, f, stream);
     }
-    hipLaunchKernelGGL(bn_max_kernel, dim3(div_up(M, BN_THREADS), B * C), dim3(BN_THREADS), 0, (hipStream_t)stream, C, M,
-                       K, relu, x, mean, invstd, gamma, beta, y, arg);
-    return launch_status("amc3d_bn_max");
+    if (st) return st;
+    if (running_mean && momentum < 0.f)  // cumulative average: needs the counter before and after -> its own launch
+        hipLaunchKernelGGL(bn_running_kernel, dim3(1), dim3(1024), 0, stream, C, momentum, mean, var_unbiased, running_mean,
+                           running_var, num_batches_tracked);
+    return launch_status("amc3d_bn_forward");
 }
 
 // Backward of y = [relu](bn(x)) (arg == NULL, K = 1, dy (B,C,L)) or of y = max_K [relu](bn(x)) (arg given,
@@ -441,16 +546,12 @@ AMC_API int amc3d_bn_backward(int B, int C, long L, int K, int relu, const float
     const int nchunks = sp.nchunks;
     const int vec = (L % 4 == 0) && (K % 4 == 0 || !mode) && aligned16(x) && aligned16(dy) && aligned16(dx) && L < (1L << 31);
     double *partial = (double *)workspace;
-    float *mean_dq = (float *)((char *)workspace + amc3d_bn_workspace_bytes(C));
-    float *mean_dqx = mean_dq + C;
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nchunks, C), dim3(BN_THREADS), 0, stream, mode, B, C, L, K, relu, sp, vec, x,
                        dy, arg, mean, invstd, gamma, beta, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(div_up(C, 64)), dim3(64), 0, stream, C, nchunks,
-                       (double)B * (double)L, (const double *)partial, dgamma, dbeta, mean_dq, mean_dqx);
     const long per_block = BN_THREADS * 16;
     const int gx = (int)min((L + per_block - 1) / per_block, (long)4096);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, stream, mode, C, L, K, relu, vec, x, dy, arg,
-                       mean, invstd, gamma, beta, mean_dq, mean_dqx, dx);
+                       mean, invstd, gamma, beta, (const double *)partial, nchunks, (double)B * (double)L, dgamma, dbeta, dx);
     return launch_status("amc3d_bn_backward");
 }
 

@@ -113,23 +113,6 @@ def _fusable_bn(bn, x):
             and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled())
 
 
-def _update_running(bn, mean, var_unbiased):
-    # nn.BatchNorm bookkeeping (torch/nn/modules/batchnorm.py): momentum None = cumulative average
-    if mean.is_cuda and bn.running_mean.dtype == torch.float32 and bn.num_batches_tracked.dtype == torch.int64:
-        from amcontrast3d_amd.ops import bn_update_running
-        bn_update_running(bn, mean, var_unbiased)
-        return
-    with torch.no_grad():
-        bn.num_batches_tracked += 1
-        mom = bn.momentum
-        if mom is None:
-            bn.running_mean += (mean - bn.running_mean) / bn.num_batches_tracked
-            bn.running_var += (var_unbiased - bn.running_var) / bn.num_batches_tracked
-        else:
-            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-            bn.running_var.mul_(1 - mom).add_(var_unbiased, alpha=mom)
-
-
 def conv1x1(conv, x):
     """conv(x); a plain 1x1 convolution on a contiguous fp32 GPU tensor runs on the MFMA kernels of
     csrc/pwconv.hip (same parameters, same autograd contract), anything else on the stored torch module."""
@@ -173,12 +156,12 @@ def run_convblocks(blocks, x, pool_max=False, pre=None):
             bn = sub[1]
             if _fusable_bn(bn, y):
                 relu = len(sub) == 3
+                # the kernels also do nn.BatchNorm's running-stat bookkeeping (same launch)
                 if last and pool_max and y.dim() == 4 and y.shape[-1] <= 255:
-                    x, mean, var_u = BatchNormMax.apply(y, bn.weight, bn.bias, bn.eps, relu)
+                    x, _, _ = BatchNormMax.apply(y, bn.weight, bn.bias, bn.eps, relu, bn)
                     pooled = True
                 else:
-                    x, mean, var_u = BatchNormAct.apply(y, bn.weight, bn.bias, bn.eps, relu)
-                _update_running(bn, mean, var_u)
+                    x, _, _ = BatchNormAct.apply(y, bn.weight, bn.bias, bn.eps, relu, bn)
             else:
                 x = bn(y)
                 if len(sub) == 3:

@@ -400,12 +400,23 @@ def _bn_ws(C, dev, extra=0):
     return torch.empty(n, dtype=torch.uint8, device=dev), n
 
 
+def _bn_running_args(bn):
+    """(momentum, running_mean ptr, running_var ptr, num_batches_tracked ptr) of an nn.BatchNorm module whose
+    buffers the fused forward updates in place, or (0, None, None, None)"""
+    if bn is None or not bn.track_running_stats or bn.running_mean is None:
+        return 0.0, None, None, None
+    assert bn.running_mean.dtype == torch.float32 and bn.num_batches_tracked.dtype == torch.int64
+    mom = -1.0 if bn.momentum is None else float(bn.momentum)
+    return mom, _ptr(bn.running_mean), _ptr(bn.running_var), _ptr(bn.num_batches_tracked)
+
+
 class BatchNormAct(Function):
-    """y = [relu](batch_norm(x)) with batch statistics; x (B, C, *) contiguous fp32.
+    """y = [relu](batch_norm(x)) with batch statistics; x (B, C, *) contiguous fp32.  `bn`: the nn.BatchNorm module
+    whose running buffers are updated in the same launch (None: no update).
     Returns (y, batch mean, unbiased batch variance)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu):
+    def forward(ctx, x, gamma, beta, eps, relu, bn=None):
         _need_gpu(x, gamma, beta)
         x = x.contiguous()
         B, C = x.shape[0], x.shape[1]
@@ -417,11 +428,11 @@ class BatchNormAct(Function):
         y = torch.empty_like(x)
         work, wb = _bn_ws(C, dev)
         lib = _lib.load()
+        mom, rm, rv, nbt = _bn_running_args(bn)
         with torch.cuda.device(dev), timing.span("bn_act_forward", x.numel() * 12):
-            _lib.check(lib.amc3d_bn_stats(B, C, L, float(eps), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(var_u), _ptr(work),
-                                          wb, _stream(x)), "bn_stats")
-            _lib.check(lib.amc3d_bn_act(B, C, L, int(bool(relu)), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma),
-                                        _ptr(beta), _ptr(y), _stream(x)), "bn_act")
+            _lib.check(lib.amc3d_bn_forward(B, C, L, 0, int(bool(relu)), float(eps), mom, _ptr(x), _ptr(gamma), _ptr(beta),
+                                            _ptr(y), None, _ptr(mean), _ptr(invstd), _ptr(var_u), rm, rv, nbt,
+                                            _ptr(work), wb, _stream(x)), "bn_forward")
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
         ctx.relu = bool(relu)
         ctx.mark_non_differentiable(mean, var_u)
@@ -442,7 +453,7 @@ class BatchNormAct(Function):
             _lib.check(_lib.load().amc3d_bn_backward(B, C, L, 1, int(ctx.relu), _ptr(x), _ptr(dy), None, _ptr(mean),
                                                      _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dx), _ptr(dgamma),
                                                      _ptr(dbeta), _ptr(work), wb, _stream(x)), "bn_backward")
-        return dx, dgamma, dbeta, None, None
+        return dx, dgamma, dbeta, None, None, None
 
 
 @torch.no_grad()
@@ -460,7 +471,7 @@ class BatchNormMax(Function):
     Returns (y, batch mean, unbiased batch variance); the (B,C,M,K) normalised tensor is never written."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu):
+    def forward(ctx, x, gamma, beta, eps, relu, bn=None):
         _need_gpu(x, gamma, beta)
         x = x.contiguous()
         B, C, M, K = x.shape
@@ -472,11 +483,11 @@ class BatchNormMax(Function):
         arg = torch.empty(B, C, M, dtype=torch.uint8, device=dev)
         work, wb = _bn_ws(C, dev)
         lib = _lib.load()
+        mom, rm, rv, nbt = _bn_running_args(bn)
         with torch.cuda.device(dev), timing.span("bn_max_forward", x.numel() * 8 + y.numel() * 5):
-            _lib.check(lib.amc3d_bn_stats(B, C, M * K, float(eps), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(var_u),
-                                          _ptr(work), wb, _stream(x)), "bn_stats")
-            _lib.check(lib.amc3d_bn_max(B, C, M, K, int(bool(relu)), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma),
-                                        _ptr(beta), _ptr(y), _ptr(arg), _stream(x)), "bn_max")
+            _lib.check(lib.amc3d_bn_forward(B, C, M * K, K, int(bool(relu)), float(eps), mom, _ptr(x), _ptr(gamma),
+                                            _ptr(beta), _ptr(y), _ptr(arg), _ptr(mean), _ptr(invstd), _ptr(var_u), rm, rv,
+                                            nbt, _ptr(work), wb, _stream(x)), "bn_forward")
         ctx.save_for_backward(x, gamma, beta, mean, invstd, arg)
         ctx.relu = bool(relu)
         ctx.mark_non_differentiable(mean, var_u)
@@ -497,7 +508,7 @@ class BatchNormMax(Function):
                                                      _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dx),
                                                      _ptr(dgamma), _ptr(dbeta), _ptr(work), wb, _stream(x)),
                        "bn_backward")
-        return dx, dgamma, dbeta, None, None
+        return dx, dgamma, dbeta, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------

@@ -227,6 +227,14 @@ size_t amc3d_bn_workspace_bytes(int C);  /* for amc3d_bn_stats; amc3d_bn_backwar
 /* mean (C), invstd = 1/sqrt(biased var + eps) (C), var_unbiased (C, for the running estimate) */
 int amc3d_bn_stats(int B, int C, long L, float eps, const float *x, float *mean, float *invstd,
                    float *var_unbiased, void *workspace, size_t workspace_bytes, void *stream);
+/* Training-mode BatchNorm forward in two launches (statistics; normalise [+ReLU] [+max over K neighbours]):
+ * K == 0: y (B,C,L);  K > 0: L = M*K, y (B,C,M) and arg (B,C,M) bytes.  Writes mean, invstd, var_unbiased (C)
+ * for the backward pass and, when running_mean != NULL, updates nn.BatchNorm's buffers
+ * (torch/nn/modules/batchnorm.py; momentum < 0 = momentum None, the cumulative average). */
+int amc3d_bn_forward(int B, int C, long L, int K, int relu, float eps, float momentum, const float *x,
+                     const float *gamma, const float *beta, float *y, unsigned char *arg, float *mean,
+                     float *invstd, float *var_unbiased, float *running_mean, float *running_var,
+                     long long *num_batches_tracked, void *workspace, size_t workspace_bytes, void *stream);
 /* nn.BatchNorm's training-mode bookkeeping in one launch: num_batches_tracked += 1 and the moving average of
  * mean / unbiased variance (torch/nn/modules/batchnorm.py); momentum < 0 stands for momentum=None (cumulative) */
 int amc3d_bn_update_running(int C, float momentum, const float *mean, const float *var_unbiased,

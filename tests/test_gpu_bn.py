@@ -75,18 +75,21 @@ def test_bn_max_matches_torch(shape, relu):
     assert float((pair(a) - pair(b)).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
 
 
-def test_run_convblocks_equals_module_stack_and_updates_running_stats():
+@pytest.mark.parametrize("momentum", [0.1, None, 0.37])
+def test_run_convblocks_equals_module_stack_and_updates_running_stats(momentum):
     import amcontrast3d_amd
     amcontrast3d_amd.activate()
     from openpoints.models.layers import create_convblock2d, run_convblocks
     torch.manual_seed(0)
-    blocks = nn.Sequential(create_convblock2d(7, 16, norm_args={'norm': 'bn'}, act_args={'act': 'relu'}),
-                           create_convblock2d(16, 24, norm_args={'norm': 'bn'}, act_args=None)).to(DEV).train()
+    norm = {'norm': 'bn', 'momentum': momentum}
+    blocks = nn.Sequential(create_convblock2d(7, 16, norm_args=norm, act_args={'act': 'relu'}),
+                           create_convblock2d(16, 24, norm_args=norm, act_args=None)).to(DEV).train()
     import copy
     ref = copy.deepcopy(blocks)
     x = torch.randn(2, 7, 300, 32, device=DEV)
-    got = run_convblocks(blocks, x, pool_max=True)
-    want = ref(x).max(-1)[0]
+    for _ in range(2):  # two steps: the cumulative average (momentum None) depends on the step count
+        got = run_convblocks(blocks, x, pool_max=True)
+        want = ref(x).max(-1)[0]
     assert float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
     for (k, a), (_, b) in zip(blocks.state_dict().items(), ref.state_dict().items()):
         assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6), k
