@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--variant", default="S")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--fps-lanes", type=int, default=2,
+                    help="first-level FPS chains in flight (each for a different future batch; one launch per step)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="compute each batch's geometry inline instead of one step ahead on a side stream")
     ap.add_argument("--sync-bn", action="store_true",
@@ -132,8 +134,11 @@ def main():
     # Software pipeline over consecutive batches.  The coordinate-only half of a step
     # (amcontrast3d_amd/geometry.py) does not depend on features or weights, so it runs ahead, on two side
     # streams, while the current batch runs its feature half on the main stream:
-    #     stream A1 first sampling level of batch t+3: FPS 24000 -> 6000 (one workgroup per cloud: 8 of the
-    #               256 CUs for ~12 ms, a chain of 6000 dependent iterations)
+    #     streams A1[0..L) first sampling level of batches t+3 .. t+2+L: FPS 24000 -> 6000 (one workgroup per cloud:
+    #               8 of the 256 CUs for ~10 ms, a chain of 6000 dependent iterations).  The chain is latency-bound
+    #               and leaves 97 % of the chip idle, so L = --fps-lanes of them (default 2) are in flight at once,
+    #               each for a different future batch and launched L steps before its result is consumed: one
+    #               launch and one completed sampling per step
     #     stream A2 sampling levels 2-4 of batch t+2   : FPS 6000 -> 1500 -> 375 -> 93 (~2.5 ms, same shape)
     #     stream B  neighbourhoods of batch t+1      : ball queries, relative positions, 3-NN, and the loss
     #               geometry (k-NN, class votes, positive masks, ambiguities)
@@ -147,7 +152,9 @@ def main():
     main_s = torch.cuda.Stream()  # all work of this process runs on non-default streams (capture recipe)
     main_s.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(main_s)
-    s_a, s_a2, s_b = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    lanes = max(1, args.fps_lanes)
+    s_a = [torch.cuda.Stream() for _ in range(lanes)]
+    s_a2, s_b = torch.cuda.Stream(), torch.cuda.Stream()
     head = criterion.contrast_head
     nlevels = len(list((model.module if hasattr(model, "module") else model).encoder.encoder))
 
@@ -161,8 +168,8 @@ def main():
         return geometry.precompute_rest(model, head, data, fps, 13, None, aargs)
 
     if overlap:
-        a1_out = geo_fps_first()               # written by stream A1 (batch t+3): first FPS level
-        a1_stable = geometry.clone(a1_out)     # batch t+2: read by stream A2
+        a1_out = [geo_fps_first() for _ in range(lanes)]  # written by streams A1[lane]: first FPS level
+        a1_stable = geometry.clone(a1_out[0])  # batch t+2: read by stream A2
         a2_out = geo_fps_tail(a1_stable)       # written by stream A2 (batch t+2): FPS levels 2..4
         a_stable = geometry.clone(a1_stable + a2_out)  # batch t+1: read by stream B
         b_full = geo_rest(a_stable)            # stream B (batch t+1): neighbourhoods, 3-NN, loss geometry
@@ -172,14 +179,14 @@ def main():
         data["_geometry"] = cur
         torch.cuda.synchronize()
 
-    def rotate():  # main stream, between steps: advance the pipeline buffers by one batch
+    def rotate(lane=0):  # main stream, between steps: advance the pipeline buffers by one batch
         geometry.copy_into(cur_fps, a_stable)
         geometry.copy_into(cur_rest, b_out)
         geometry.copy_into(a_stable, a1_stable + a2_out)
-        geometry.copy_into(a1_stable, a1_out)
+        geometry.copy_into(a1_stable, a1_out[lane])
 
-    def body_a():
-        geometry.copy_into(a1_out, geo_fps_first())
+    def body_a(lane=0):
+        geometry.copy_into(a1_out[lane], geo_fps_first())
 
     def body_a2():
         geometry.copy_into(a2_out, geo_fps_tail(a1_stable))
@@ -191,17 +198,21 @@ def main():
         torch.nn.utils.clip_grad_norm_(params, 10, norm_type=2)
         opt.step()
 
+    step_no = [0]
+
     def run_step(f_rotate, f_a, f_a2, f_b, f_feat, f_update):
         if overlap:
-            main_s.wait_stream(s_a)
+            lane = step_no[0] % lanes  # the FPS lane launched `lanes` steps ago delivers now and is relaunched
+            step_no[0] += 1
+            main_s.wait_stream(s_a[lane])
             main_s.wait_stream(s_a2)
             main_s.wait_stream(s_b)
-            f_rotate()
-            s_a.wait_stream(main_s)
+            f_rotate[lane]()
+            s_a[lane].wait_stream(main_s)
             s_a2.wait_stream(main_s)
             s_b.wait_stream(main_s)
-            with torch.cuda.stream(s_a):
-                f_a()
+            with torch.cuda.stream(s_a[lane]):
+                f_a[lane]()
             with torch.cuda.stream(s_a2):
                 f_a2()
             with torch.cuda.stream(s_b):
@@ -213,7 +224,8 @@ def main():
 
     def eager_step():
         opt.zero_grad(set_to_none=True)
-        run_step(rotate, body_a, body_a2, body_b, fwd_bwd, update)
+        run_step([lambda l=l: rotate(l) for l in range(lanes)], [lambda l=l: body_a(l) for l in range(lanes)], body_a2,
+                 body_b, fwd_bwd, update)
 
     step = eager_step
     if use_graph:
@@ -223,17 +235,19 @@ def main():
             eager_step()
         torch.cuda.synchronize()
         opt.zero_grad(set_to_none=True)
-        graphs = {k: torch.cuda.CUDAGraph() for k in ("rotate", "a", "a2", "b", "feat", "update")}
+        names = ["a2", "b", "feat", "update"] + [f"rotate{l}" for l in range(lanes)] + [f"fps{l}" for l in range(lanes)]
+        graphs = {k: torch.cuda.CUDAGraph() for k in names}
         cap = torch.cuda.Stream()
         with torch.cuda.graph(graphs["feat"], stream=cap):
             fwd_bwd()
         with torch.cuda.graph(graphs["update"], stream=cap):
             update()
         if overlap:
-            with torch.cuda.graph(graphs["rotate"], stream=cap):
-                rotate()
-            with torch.cuda.graph(graphs["a"], stream=cap):
-                body_a()
+            for l in range(lanes):
+                with torch.cuda.graph(graphs[f"rotate{l}"], stream=cap):
+                    rotate(l)
+                with torch.cuda.graph(graphs[f"fps{l}"], stream=cap):
+                    body_a(l)
             with torch.cuda.graph(graphs["a2"], stream=cap):
                 body_a2()
             with torch.cuda.graph(graphs["b"], stream=cap):
@@ -241,8 +255,8 @@ def main():
         torch.cuda.synchronize()
 
         def step():
-            run_step(graphs["rotate"].replay, graphs["a"].replay, graphs["a2"].replay, graphs["b"].replay, graphs["feat"].replay,
-                     graphs["update"].replay)
+            run_step([graphs[f"rotate{l}"].replay for l in range(lanes)], [graphs[f"fps{l}"].replay for l in range(lanes)],
+                     graphs["a2"].replay, graphs["b"].replay, graphs["feat"].replay, graphs["update"].replay)
 
     for _ in range(args.warmup):
         step()
@@ -271,9 +285,9 @@ def main():
             torch.cuda.synchronize()
             return round((time.perf_counter() - t) / reps * 1e3, 3)
         parts = {"features_ms": alone(graphs["feat"].replay, main_s), "update_ms": alone(graphs["update"].replay, main_s),
-                 "fps_level1_ms": alone(graphs["a"].replay, s_a), "fps_levels2to4_ms": alone(graphs["a2"].replay, s_a2),
+                 "fps_level1_ms": alone(graphs["fps0"].replay, s_a[0]), "fps_levels2to4_ms": alone(graphs["a2"].replay, s_a2),
                  "neighbourhood_geometry_ms": alone(graphs["b"].replay, s_b),
-                 "rotate_ms": alone(graphs["rotate"].replay, main_s)}
+                 "rotate_ms": alone(graphs["rotate0"].replay, main_s)}
 
     # per-operator HIP-event timing: the same step, launched eagerly so each C-ABI launch can be
     # bracketed by events on its stream (events cannot bracket nodes inside a graph replay)
@@ -352,8 +366,8 @@ def main():
                        "global_batch": args.batch * world, "points": args.points,
                        "parallelism": f"dp{world}" + ("+syncbn+ddp" if use_ddp else ""),
                        "launch": "hipGraph replay (fwd+loss+bwd | clip+AdamW)" if use_graph else "eager",
-                       "pipeline": "4 streams: FPS level 1 (t+3) | FPS levels 2-4 (t+2) | neighbourhood + loss geometry (t+1) | "
-                                   "features (t)"
+                       "pipeline": f"{3 + lanes} streams: FPS level 1 of {lanes} future batches in flight | FPS levels 2-4 "
+                                               f"(t+2) | neighbourhood + loss geometry (t+1) | features (t)"
                                    if overlap_was else "none"},
             "loss": round(final_loss, 6),
             "roofline": roofline,
