@@ -198,7 +198,27 @@ __global__ __launch_bounds__(1024) void masked_mean_kernel(int m, const float *_
     __shared__ int s_cnt[16];
     double sum = 0.0;
     int cnt = 0;
-    for (int i = threadIdx.x; i < m; i += 1024) {
+    // one workgroup (fixed order, no workspace): keep many 16-byte loads in flight per thread instead of a
+    // dependent scalar load per element
+    const int m4 = ((((uintptr_t)loss_pt | (uintptr_t)a) & 15) == 0) ? (m & ~3) : 0;
+    for (int i0 = threadIdx.x * 4; i0 < m4; i0 += 4096 * 4) {
+        float4 lv[4], av[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 4096;
+            const bool ok = i < m4;
+            lv[u] = ok ? *reinterpret_cast<const float4 *>(loss_pt + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            av[u] = ok ? *reinterpret_cast<const float4 *>(a + i) : make_float4(-1.f, -1.f, -1.f, -1.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float l4[4] = {lv[u].x, lv[u].y, lv[u].z, lv[u].w}, a4[4] = {av[u].x, av[u].y, av[u].z, av[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (0.f < a4[e] && a4[e] <= 1.f) { sum += (double)l4[e]; cnt += 1; }
+        }
+    }
+    for (int i = m4 + threadIdx.x; i < m; i += 1024) {
         const float ai = a[i];
         if (0.f < ai && ai <= 1.f) { sum += (double)loss_pt[i]; cnt += 1; }
     }
