@@ -112,7 +112,11 @@ struct FpsRecord {  // one per wave and iteration parity, 32 bytes
     float x, y, z, pad2;
 };
 
-template <int PPT, int NG, int MAXT = 512>
+// LEAN: the sweep keeps only each lane's maximum per group; the winning slot (and whether the maximum is attained
+// twice inside the winning lane) is found afterwards by comparing the winning group's slots with the maximum.
+// That frees the per-group slot registers and 5 of 15 instructions per swept slot, which is what lets the groups
+// shrink to 4 slots (256 points): twice as many, tighter boxes.
+template <int PPT, int NG, int MAXT = 512, bool LEAN = false>
 __global__ __launch_bounds__(MAXT) void fps_kernel(int n, int m, int log2rb, const float *__restrict__ dataset,
                                                    float *__restrict__ temp, int *__restrict__ idxs,
                                                    int *__restrict__ perm_ws)
@@ -279,66 +283,114 @@ __global__ __launch_bounds__(MAXT) void fps_kernel(int n, int m, int log2rb, con
                     const float d = dist2_ref(px[j], py[j], pz[j], x1, y1, z1);
                     const float dm = fminf(d, pt[j]);
                     pt[j] = dm;
-                    const bool gtm = dm > b, eqm = dm == b;
-                    tie = gtm ? false : (tie || eqm);
-                    sl = gtm ? j : sl;
+                    if (!LEAN) {
+                        const bool gtm = dm > b, eqm = dm == b;
+                        tie = gtm ? false : (tie || eqm);
+                        sl = gtm ? j : sl;
+                    }
                     b = fmaxf(b, dm);
                     if (GS >= 4) __builtin_amdgcn_sched_barrier(0);  // keep register pressure flat
                 }
                 gb[g] = b;
-                gsl[g] = sl;
-                tiebits = tie ? (tiebits | (1u << g)) : (tiebits & ~(1u << g));
+                if (!LEAN) {
+                    gsl[g] = sl;
+                    tiebits = tie ? (tiebits | (1u << g)) : (tiebits & ~(1u << g));
+                }
                 const float nthr = wave_max_f32(b);  // the group's new M; evaluated in every lane, kept by lane g
                 pthr = lane == g ? nthr : pthr;
             }
         }
         AMC_STAMP(0)
         // ---- 2. lane maximum over its groups ---------------------------------------------------------
-        float best = gb[0];
-        int slot = gsl[0];
-        bool ltie = (tiebits & 1u) != 0;
+        float vw, wx = 0.f, wy = 0.f, wz = 0.f;
+        bool amb_w;
+        int wl, jstar;
+        if (LEAN) {
+            float best = gb[0];
 #pragma unroll
-        for (int g = 1; g < NG; ++g) {
-            const bool gtm = gb[g] > best, eqm = gb[g] == best;
-            ltie = gtm ? ((tiebits >> g) & 1u) != 0 : (ltie || eqm);
-            slot = gtm ? gsl[g] : slot;
-            best = fmaxf(best, gb[g]);
-        }
-        // ---- 3. wave arg-max; the winner lane's coordinates come straight from its VGPRs ---------
-        const float vw = wave_max_f32(best);
-        const unsigned long long cand = __ballot(best == vw);
-        const bool amb_w = __popcll(cand) != 1 || __ballot(best == vw && ltie) != 0;
-        const int wl = (int)__builtin_ctzll(cand);
-        const int jstar = __builtin_amdgcn_readlane(slot, wl);
-        float wx = 0.f, wy = 0.f, wz = 0.f;
-        switch (jstar) {
-#define AMC_FPS_CASE(J)                                                                                        \
-    case J:                                                                                                    \
-        if (J < PPT) {                                                                                         \
-            wx = readlane_f32(px[J < PPT ? J : 0], wl);                                                        \
-            wy = readlane_f32(py[J < PPT ? J : 0], wl);                                                        \
-            wz = readlane_f32(pz[J < PPT ? J : 0], wl);                                                        \
+            for (int g = 1; g < NG; ++g) best = fmaxf(best, gb[g]);
+            int bg = 0, eqc = 0;  // first group attaining it, how many do
+#pragma unroll
+            for (int g = NG - 1; g >= 0; --g) {
+                const bool eq = gb[g] == best;
+                bg = eq ? g : bg;
+                eqc += eq ? 1 : 0;
+            }
+            // ---- 3. wave arg-max; slot and coordinates of the winner from the winning group's slots -------
+            vw = wave_max_f32(best);
+            const unsigned long long cand = __ballot(best == vw);
+            wl = (int)__builtin_ctzll(cand);
+            const int gstar = __builtin_amdgcn_readlane(bg, wl);
+            float cx = 0.f, cy = 0.f, cz = 0.f;
+            int sl = 0, cnt = 0;
+            switch (gstar) {
+#define AMC_FPS_GCASE(G)                                                                                       \
+    case G:                                                                                                    \
+        if (G < NG) {                                                                                          \
+            _Pragma("unroll") for (int jj = GS - 1; jj >= 0; --jj) {                                            \
+                const int j = (G < NG ? G : 0) * GS + jj;                                                       \
+                const bool eq = pt[j] == vw;                                                                    \
+                sl = eq ? j : sl; cx = eq ? px[j] : cx; cy = eq ? py[j] : cy; cz = eq ? pz[j] : cz;             \
+                cnt += eq ? 1 : 0;                                                                              \
+            }                                                                                                  \
         }                                                                                                      \
         break;
-            AMC_FPS_CASE(0) AMC_FPS_CASE(1) AMC_FPS_CASE(2) AMC_FPS_CASE(3) AMC_FPS_CASE(4) AMC_FPS_CASE(5)
-            AMC_FPS_CASE(6) AMC_FPS_CASE(7) AMC_FPS_CASE(8) AMC_FPS_CASE(9) AMC_FPS_CASE(10) AMC_FPS_CASE(11)
-            AMC_FPS_CASE(12) AMC_FPS_CASE(13) AMC_FPS_CASE(14) AMC_FPS_CASE(15) AMC_FPS_CASE(16) AMC_FPS_CASE(17)
-            AMC_FPS_CASE(18) AMC_FPS_CASE(19) AMC_FPS_CASE(20) AMC_FPS_CASE(21) AMC_FPS_CASE(22) AMC_FPS_CASE(23)
-            AMC_FPS_CASE(24) AMC_FPS_CASE(25) AMC_FPS_CASE(26) AMC_FPS_CASE(27) AMC_FPS_CASE(28) AMC_FPS_CASE(29)
-            AMC_FPS_CASE(30) AMC_FPS_CASE(31) AMC_FPS_CASE(32) AMC_FPS_CASE(33) AMC_FPS_CASE(34) AMC_FPS_CASE(35)
-            AMC_FPS_CASE(36) AMC_FPS_CASE(37) AMC_FPS_CASE(38) AMC_FPS_CASE(39) AMC_FPS_CASE(40) AMC_FPS_CASE(41)
-            AMC_FPS_CASE(42) AMC_FPS_CASE(43) AMC_FPS_CASE(44) AMC_FPS_CASE(45) AMC_FPS_CASE(46) AMC_FPS_CASE(47)
-            AMC_FPS_CASE(48) AMC_FPS_CASE(49) AMC_FPS_CASE(50) AMC_FPS_CASE(51) AMC_FPS_CASE(52) AMC_FPS_CASE(53)
-            AMC_FPS_CASE(54) AMC_FPS_CASE(55) AMC_FPS_CASE(56) AMC_FPS_CASE(57) AMC_FPS_CASE(58) AMC_FPS_CASE(59)
-            AMC_FPS_CASE(60) AMC_FPS_CASE(61) AMC_FPS_CASE(62) AMC_FPS_CASE(63) AMC_FPS_CASE(64) AMC_FPS_CASE(65)
-            AMC_FPS_CASE(66) AMC_FPS_CASE(67) AMC_FPS_CASE(68) AMC_FPS_CASE(69) AMC_FPS_CASE(70) AMC_FPS_CASE(71)
-            AMC_FPS_CASE(72) AMC_FPS_CASE(73) AMC_FPS_CASE(74) AMC_FPS_CASE(75) AMC_FPS_CASE(76) AMC_FPS_CASE(77)
-            AMC_FPS_CASE(78) AMC_FPS_CASE(79) AMC_FPS_CASE(80) AMC_FPS_CASE(81) AMC_FPS_CASE(82) AMC_FPS_CASE(83)
-            AMC_FPS_CASE(84) AMC_FPS_CASE(85) AMC_FPS_CASE(86) AMC_FPS_CASE(87) AMC_FPS_CASE(88) AMC_FPS_CASE(89)
-            AMC_FPS_CASE(90) AMC_FPS_CASE(91) AMC_FPS_CASE(92) AMC_FPS_CASE(93) AMC_FPS_CASE(94) AMC_FPS_CASE(95)
+                AMC_FPS_GCASE(0) AMC_FPS_GCASE(1) AMC_FPS_GCASE(2) AMC_FPS_GCASE(3) AMC_FPS_GCASE(4) AMC_FPS_GCASE(5)
+                AMC_FPS_GCASE(6) AMC_FPS_GCASE(7) AMC_FPS_GCASE(8) AMC_FPS_GCASE(9) AMC_FPS_GCASE(10) AMC_FPS_GCASE(11)
+                AMC_FPS_GCASE(12) AMC_FPS_GCASE(13) AMC_FPS_GCASE(14) AMC_FPS_GCASE(15)
+#undef AMC_FPS_GCASE
+                default: break;
+            }
+            jstar = __builtin_amdgcn_readlane(sl, wl);
+            wx = readlane_f32(cx, wl); wy = readlane_f32(cy, wl); wz = readlane_f32(cz, wl);
+            // ambiguous: several lanes hold the maximum, or the winning lane holds it in several groups or slots
+            amb_w = __popcll(cand) != 1 || __builtin_amdgcn_readlane(eqc, wl) != 1 || __builtin_amdgcn_readlane(cnt, wl) != 1;
+        } else {
+            float best = gb[0];
+            int slot = gsl[0];
+            bool ltie = (tiebits & 1u) != 0;
+    #pragma unroll
+            for (int g = 1; g < NG; ++g) {
+                const bool gtm = gb[g] > best, eqm = gb[g] == best;
+                ltie = gtm ? ((tiebits >> g) & 1u) != 0 : (ltie || eqm);
+                slot = gtm ? gsl[g] : slot;
+                best = fmaxf(best, gb[g]);
+            }
+            // ---- 3. wave arg-max; the winner lane's coordinates come straight from its VGPRs ---------
+            vw = wave_max_f32(best);
+            const unsigned long long cand = __ballot(best == vw);
+            amb_w = __popcll(cand) != 1 || __ballot(best == vw && ltie) != 0;
+            wl = (int)__builtin_ctzll(cand);
+            jstar = __builtin_amdgcn_readlane(slot, wl);
+            switch (jstar) {
+    #define AMC_FPS_CASE(J)                                                                                        \
+        case J:                                                                                                    \
+            if (J < PPT) {                                                                                         \
+                wx = readlane_f32(px[J < PPT ? J : 0], wl);                                                        \
+                wy = readlane_f32(py[J < PPT ? J : 0], wl);                                                        \
+                wz = readlane_f32(pz[J < PPT ? J : 0], wl);                                                        \
+            }                                                                                                      \
+            break;
+                AMC_FPS_CASE(0) AMC_FPS_CASE(1) AMC_FPS_CASE(2) AMC_FPS_CASE(3) AMC_FPS_CASE(4) AMC_FPS_CASE(5)
+                AMC_FPS_CASE(6) AMC_FPS_CASE(7) AMC_FPS_CASE(8) AMC_FPS_CASE(9) AMC_FPS_CASE(10) AMC_FPS_CASE(11)
+                AMC_FPS_CASE(12) AMC_FPS_CASE(13) AMC_FPS_CASE(14) AMC_FPS_CASE(15) AMC_FPS_CASE(16) AMC_FPS_CASE(17)
+                AMC_FPS_CASE(18) AMC_FPS_CASE(19) AMC_FPS_CASE(20) AMC_FPS_CASE(21) AMC_FPS_CASE(22) AMC_FPS_CASE(23)
+                AMC_FPS_CASE(24) AMC_FPS_CASE(25) AMC_FPS_CASE(26) AMC_FPS_CASE(27) AMC_FPS_CASE(28) AMC_FPS_CASE(29)
+                AMC_FPS_CASE(30) AMC_FPS_CASE(31) AMC_FPS_CASE(32) AMC_FPS_CASE(33) AMC_FPS_CASE(34) AMC_FPS_CASE(35)
+                AMC_FPS_CASE(36) AMC_FPS_CASE(37) AMC_FPS_CASE(38) AMC_FPS_CASE(39) AMC_FPS_CASE(40) AMC_FPS_CASE(41)
+                AMC_FPS_CASE(42) AMC_FPS_CASE(43) AMC_FPS_CASE(44) AMC_FPS_CASE(45) AMC_FPS_CASE(46) AMC_FPS_CASE(47)
+                AMC_FPS_CASE(48) AMC_FPS_CASE(49) AMC_FPS_CASE(50) AMC_FPS_CASE(51) AMC_FPS_CASE(52) AMC_FPS_CASE(53)
+                AMC_FPS_CASE(54) AMC_FPS_CASE(55) AMC_FPS_CASE(56) AMC_FPS_CASE(57) AMC_FPS_CASE(58) AMC_FPS_CASE(59)
+                AMC_FPS_CASE(60) AMC_FPS_CASE(61) AMC_FPS_CASE(62) AMC_FPS_CASE(63) AMC_FPS_CASE(64) AMC_FPS_CASE(65)
+                AMC_FPS_CASE(66) AMC_FPS_CASE(67) AMC_FPS_CASE(68) AMC_FPS_CASE(69) AMC_FPS_CASE(70) AMC_FPS_CASE(71)
+                AMC_FPS_CASE(72) AMC_FPS_CASE(73) AMC_FPS_CASE(74) AMC_FPS_CASE(75) AMC_FPS_CASE(76) AMC_FPS_CASE(77)
+                AMC_FPS_CASE(78) AMC_FPS_CASE(79) AMC_FPS_CASE(80) AMC_FPS_CASE(81) AMC_FPS_CASE(82) AMC_FPS_CASE(83)
+                AMC_FPS_CASE(84) AMC_FPS_CASE(85) AMC_FPS_CASE(86) AMC_FPS_CASE(87) AMC_FPS_CASE(88) AMC_FPS_CASE(89)
+                AMC_FPS_CASE(90) AMC_FPS_CASE(91) AMC_FPS_CASE(92) AMC_FPS_CASE(93) AMC_FPS_CASE(94) AMC_FPS_CASE(95)
            
-#undef AMC_FPS_CASE
-            default: break;
+    #undef AMC_FPS_CASE
+                default: break;
+            }
         }
         if (lane == 0) {
             FpsRecord r;
@@ -478,11 +530,11 @@ __global__ __launch_bounds__(1024) void fps_kernel_large(int n, int m, const flo
     }
 }
 
-template <int PPT, int NG, int MAXT = 512>
+template <int PPT, int NG, int MAXT = 512, bool LEAN = false>
 static int launch_fps(int b, int n, int m, int waves, int log2rb, const float *dataset, float *temp, int *idxs,
                       int *perm, hipStream_t stream)
 {
-    hipLaunchKernelGGL((fps_kernel<PPT, NG, MAXT>), dim3(b), dim3(waves * 64), 0, stream, n, m, log2rb, dataset, temp, idxs,
+    hipLaunchKernelGGL((fps_kernel<PPT, NG, MAXT, LEAN>), dim3(b), dim3(waves * 64), 0, stream, n, m, log2rb, dataset, temp, idxs,
                        perm);
     return launch_status("amc3d_furthest_point_sampling");
 }
@@ -521,12 +573,14 @@ AMC_API int amc3d_furthest_point_sampling(int b, int n, int m, const float *data
         return w;
     };
     static const int variant = getenv("AMC3D_FPS_VARIANT") ? atoi(getenv("AMC3D_FPS_VARIANT")) : 0;
-    if (n > 12288 && variant == 2) return launch_fps<48, 12>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
-    if (n > 12288 && variant == 3) return launch_fps<48, 8>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
-    if (n > 12288) return launch_fps<48, 6>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
-    if (n > 6144) return launch_fps<24, 3>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
-    if (n > 3072) return launch_fps<12, 3>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
-    if (n > 1536) return launch_fps<6, 3>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
+    if (n > 12288 && variant == 2) return launch_fps<48, 12, 512, true>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
+    if (n > 12288 && variant == 3) return launch_fps<48, 8, 512, true>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
+    if (n > 12288 && variant == 4) return launch_fps<48, 6, 512, true>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
+    if (n > 12288 && variant == 5) return launch_fps<48, 6>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
+    if (n > 12288) return launch_fps<48, 6, 512, true>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
+    if (n > 6144) return launch_fps<24, 3, 512, true>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
+    if (n > 3072) return launch_fps<12, 3, 512, true>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
+    if (n > 1536) return launch_fps<6, 3, 512, true>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
     if (n > 512) return launch_fps<3, 1>(b, n, m, waves_for(3), log2rb, dataset, temp, idxs, perm, stream);
     if (n > 64) return launch_fps<2, 1>(b, n, m, waves_for(2), log2rb, dataset, temp, idxs, perm, stream);
     return launch_fps<1, 1>(b, n, m, 1, log2rb, dataset, temp, idxs, perm, stream);
