@@ -112,6 +112,42 @@ struct FpsRecord {  // one per wave and iteration parity, 32 bytes
     float x, y, z, pad2;
 };
 
+// coordinates of slot j (wave-uniform) of lane wl, straight from the owner lane's VGPRs
+template <int PPT>
+__device__ __forceinline__ void fps_slot_coords(const float (&px)[PPT], const float (&py)[PPT], const float (&pz)[PPT], int j,
+                                                int wl, float &wx, float &wy, float &wz)
+{
+    switch (j) {
+#define AMC_FPS_CASE(J)                                                                                        \
+    case J:                                                                                                    \
+        if (J < PPT) {                                                                                         \
+            wx = readlane_f32(px[J < PPT ? J : 0], wl);                                                        \
+            wy = readlane_f32(py[J < PPT ? J : 0], wl);                                                        \
+            wz = readlane_f32(pz[J < PPT ? J : 0], wl);                                                        \
+        }                                                                                                      \
+        break;
+        AMC_FPS_CASE(0) AMC_FPS_CASE(1) AMC_FPS_CASE(2) AMC_FPS_CASE(3) AMC_FPS_CASE(4) AMC_FPS_CASE(5)
+        AMC_FPS_CASE(6) AMC_FPS_CASE(7) AMC_FPS_CASE(8) AMC_FPS_CASE(9) AMC_FPS_CASE(10) AMC_FPS_CASE(11)
+        AMC_FPS_CASE(12) AMC_FPS_CASE(13) AMC_FPS_CASE(14) AMC_FPS_CASE(15) AMC_FPS_CASE(16) AMC_FPS_CASE(17)
+        AMC_FPS_CASE(18) AMC_FPS_CASE(19) AMC_FPS_CASE(20) AMC_FPS_CASE(21) AMC_FPS_CASE(22) AMC_FPS_CASE(23)
+        AMC_FPS_CASE(24) AMC_FPS_CASE(25) AMC_FPS_CASE(26) AMC_FPS_CASE(27) AMC_FPS_CASE(28) AMC_FPS_CASE(29)
+        AMC_FPS_CASE(30) AMC_FPS_CASE(31) AMC_FPS_CASE(32) AMC_FPS_CASE(33) AMC_FPS_CASE(34) AMC_FPS_CASE(35)
+        AMC_FPS_CASE(36) AMC_FPS_CASE(37) AMC_FPS_CASE(38) AMC_FPS_CASE(39) AMC_FPS_CASE(40) AMC_FPS_CASE(41)
+        AMC_FPS_CASE(42) AMC_FPS_CASE(43) AMC_FPS_CASE(44) AMC_FPS_CASE(45) AMC_FPS_CASE(46) AMC_FPS_CASE(47)
+        AMC_FPS_CASE(48) AMC_FPS_CASE(49) AMC_FPS_CASE(50) AMC_FPS_CASE(51) AMC_FPS_CASE(52) AMC_FPS_CASE(53)
+        AMC_FPS_CASE(54) AMC_FPS_CASE(55) AMC_FPS_CASE(56) AMC_FPS_CASE(57) AMC_FPS_CASE(58) AMC_FPS_CASE(59)
+        AMC_FPS_CASE(60) AMC_FPS_CASE(61) AMC_FPS_CASE(62) AMC_FPS_CASE(63) AMC_FPS_CASE(64) AMC_FPS_CASE(65)
+        AMC_FPS_CASE(66) AMC_FPS_CASE(67) AMC_FPS_CASE(68) AMC_FPS_CASE(69) AMC_FPS_CASE(70) AMC_FPS_CASE(71)
+        AMC_FPS_CASE(72) AMC_FPS_CASE(73) AMC_FPS_CASE(74) AMC_FPS_CASE(75) AMC_FPS_CASE(76) AMC_FPS_CASE(77)
+        AMC_FPS_CASE(78) AMC_FPS_CASE(79) AMC_FPS_CASE(80) AMC_FPS_CASE(81) AMC_FPS_CASE(82) AMC_FPS_CASE(83)
+        AMC_FPS_CASE(84) AMC_FPS_CASE(85) AMC_FPS_CASE(86) AMC_FPS_CASE(87) AMC_FPS_CASE(88) AMC_FPS_CASE(89)
+        AMC_FPS_CASE(90) AMC_FPS_CASE(91) AMC_FPS_CASE(92) AMC_FPS_CASE(93) AMC_FPS_CASE(94) AMC_FPS_CASE(95)
+       
+#undef AMC_FPS_CASE
+        default: break;
+    }
+}
+
 // LEAN: the sweep keeps only each lane's maximum per group; the winning slot (and whether the maximum is attained
 // twice inside the winning lane) is found afterwards by comparing the winning group's slots with the maximum.
 // That frees the per-group slot registers and 5 of 15 instructions per swept slot, which is what lets the groups
@@ -321,7 +357,6 @@ __global__ __launch_bounds__(MAXT) void fps_kernel(int n, int m, int log2rb, con
             const unsigned long long cand = __ballot(best == vw);
             wl = (int)__builtin_ctzll(cand);
             const int gstar = __builtin_amdgcn_readlane(bg, wl);
-            float cx = 0.f, cy = 0.f, cz = 0.f;
             int sl = 0, cnt = 0;
             switch (gstar) {
 #define AMC_FPS_GCASE(G)                                                                                       \
@@ -330,7 +365,7 @@ __global__ __launch_bounds__(MAXT) void fps_kernel(int n, int m, int log2rb, con
             _Pragma("unroll") for (int jj = GS - 1; jj >= 0; --jj) {                                            \
                 const int j = (G < NG ? G : 0) * GS + jj;                                                       \
                 const bool eq = pt[j] == vw;                                                                    \
-                sl = eq ? j : sl; cx = eq ? px[j] : cx; cy = eq ? py[j] : cy; cz = eq ? pz[j] : cz;             \
+                sl = eq ? j : sl;                                                                               \
                 cnt += eq ? 1 : 0;                                                                              \
             }                                                                                                  \
         }                                                                                                      \
@@ -342,7 +377,7 @@ __global__ __launch_bounds__(MAXT) void fps_kernel(int n, int m, int log2rb, con
                 default: break;
             }
             jstar = __builtin_amdgcn_readlane(sl, wl);
-            wx = readlane_f32(cx, wl); wy = readlane_f32(cy, wl); wz = readlane_f32(cz, wl);
+            fps_slot_coords<PPT>(px, py, pz, jstar, wl, wx, wy, wz);
             // ambiguous: several lanes hold the maximum, or the winning lane holds it in several groups or slots
             amb_w = __popcll(cand) != 1 || __builtin_amdgcn_readlane(eqc, wl) != 1 || __builtin_amdgcn_readlane(cnt, wl) != 1;
         } else {
