@@ -112,6 +112,7 @@ def main():
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the product path)"
+    local = local % torch.cuda.device_count()  # (rehearsals put several ranks on one card; a real node has one each)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.load()
