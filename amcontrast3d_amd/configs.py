@@ -49,6 +49,36 @@ def model_cfg(variant='S', num_classes=13, in_channels=4, dropout=0.5, radius=0.
     })
 
 
+def model_cfg_mm(variant='XL', num_classes=13, in_channels=4, dropout=0.5, width=None, blocks=None, ignore_index=None,
+                 dataset='s3dis', **apm):
+    """AMContrast3D++ (cfgs/{s3dis,scannet}/AMContrast3D-MM.yaml:33-88): the AA model plus the ambiguity
+    prediction module and masked refinement.  `apm`: overrides of the APM_args block."""
+    cfg = model_cfg(variant, num_classes=num_classes, in_channels=in_channels, dropout=dropout, width=width, blocks=blocks)
+    w = cfg['encoder_args']['width']
+    cfg['NAME'] = 'BaseSeg_M_AMContrast3D'
+    cfg['encoder_args']['NAME'] = 'PointNextEncoder_M_AMContrast3D'
+    cfg['decoder_args']['NAME'] = 'PointNextDecoder_M_AMContrast3D'
+    cfg['cls_args']['ignore_index'] = ignore_index
+    cfg['AEF_args'] = ambiguity_args_mm(dataset)
+    apm_args = {'NAME': 'APM_pf_ConCate', 'feature_dim': [w, 2 * w, 4 * w, 8 * w], 'linear_mapping': False,
+                'cross_attention': False, 'feat_concate': False, 'channel': [32, 16, 8, 4, 2], 'dropout': [0, 0, 0, 0, 0],
+                'nsample_k': 12, 'threshold': 0.9, 'threshold_max': 1.0, 'gamma': 1, 'fusion': 'MIN', 'att_dim': 3}
+    apm_args.update(apm)
+    cfg['APM_args'] = apm_args
+    return copy.deepcopy(cfg)
+
+
+def ambiguity_args_mm(dataset='s3dis'):
+    """ambiguity_args of the MM configs: the AA values plus the regression weight and the refinement's source"""
+    args = ambiguity_args(dataset)
+    args.update({'w3': 0.01, 'source': 'APM', 'source_mode': 'Train'})
+    return args
+
+
+def criterion_cfg_mm():
+    return {'NAME': 'CrossEntropyAcePre'}
+
+
 def ambiguity_args(dataset='s3dis'):
     args = {
         'action': False, 'vis': False, 'nsample': 24, 'ccbeta': 0.04, 'cctype': 'Method2',

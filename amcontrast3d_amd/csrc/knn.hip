@@ -1157,7 +1157,9 @@ int three_nn_grid(int b, int n, int m, const float *unknown, const float *known,
     char *base = (char *)workspace;
     int *off_s = (int *)(base + 768), *off_q = (int *)(base + 6400);
     hipLaunchKernelGGL(kg_uniform_offsets_kernel, dim3(1), dim3(64), 0, stream, b, m, n, off_s, off_q);
-    if (int st = kg_build(w, base, b * m, b * n, b, known, unknown, off_s, off_q, 2, 2, 1.0f, 0.f, stream)) return st;
+    static const float nn3_scale = getenv("AMC3D_NN3_SCALE") ? (float)atof(getenv("AMC3D_NN3_SCALE")) : 1.0f;
+    static const int nn3_k = getenv("AMC3D_NN3_K") ? atoi(getenv("AMC3D_NN3_K")) : 2;
+    if (int st = kg_build(w, base, b * m, b * n, b, known, unknown, off_s, off_q, nn3_k, 2, nn3_scale, 0.f, stream)) return st;
     hipLaunchKernelGGL(nn3_grid_kernel, dim3(min(div_up((long)b * n, 4), 256 * 32)), dim3(256), 0, stream, b * n, n, m,
                        unknown, (const GridParams *)(base + w.params), (const int *)(base + w.cell_start),
                        (const float4 *)(base + w.sorted), dist2, idx);

@@ -15,6 +15,19 @@ LOSS.register_module(name='CrossEntropyLoss', module=CrossEntropyLoss)
 LOSS.register_module(name='BCEWithLogitsLoss', module=BCEWithLogitsLoss)
 
 
+def _cross_entropy(crit, logit, target):
+    """(CE value, flattened target): nn.CrossEntropyLoss on the (B*N, ncls) view of the logits, through the fused
+    kernel when the module is the plain default"""
+    if (type(crit) is CrossEntropyLoss and crit.weight is None and crit.label_smoothing == 0.0
+            and crit.reduction == 'mean' and logit.is_cuda and logit.dtype == torch.float32 and logit.dim() == 3
+            and not torch.is_autocast_enabled()):
+        # same value without the (B*N, ncls) transposed copy: one fused pass over the (B,ncls,N) logits
+        from amcontrast3d_amd.ops import cross_entropy_mean
+        return cross_entropy_mean(logit, target, crit.ignore_index), target.flatten()
+    target = target.flatten()
+    return crit(logit.transpose(1, 2).reshape(-1, logit.shape[1]), target), target
+
+
 @LOSS.register_module()
 class CrossEntropyAce(torch.nn.Module):
     """w1 * CE(logits, target) + w2 * sum_stage contrast(stage).  Like the reference, the
@@ -26,20 +39,35 @@ class CrossEntropyAce(torch.nn.Module):
         self.contrast_head = ContrastHead()
 
     def forward(self, logit, target, stageACE_list, num_classes, ignore_index, ambiguity_args):
-        crit = self.creterion
-        if (type(crit) is CrossEntropyLoss and crit.weight is None and crit.label_smoothing == 0.0
-                and crit.reduction == 'mean' and logit.is_cuda and logit.dtype == torch.float32 and logit.dim() == 3
-                and not torch.is_autocast_enabled()):
-            # same value without the (B*N, ncls) transposed copy: one fused pass over the (B,ncls,N) logits
-            from amcontrast3d_amd.ops import cross_entropy_mean
-            ce = cross_entropy_mean(logit, target, crit.ignore_index)
-            target = target.flatten()
-        else:
-            logit = logit.transpose(1, 2).reshape(-1, logit.shape[1])  # (B,ncls,N) -> (B*N,ncls)
-            target = target.flatten()
-            ce = crit(logit, target)
+        ce, target = _cross_entropy(self.creterion, logit, target)
         contrast, _, _ = self.contrast_head(logit, target, stageACE_list, num_classes, ignore_index, ambiguity_args)
         return ambiguity_args.w1 * ce + ambiguity_args.w2 * contrast
+
+
+@LOSS.register_module()
+class CrossEntropyAcePre(torch.nn.Module):
+    """AMContrast3D++ objective (loss/build.py:281-319): w1 * CE + w2 * contrast for the segmentation, and
+    w3 * L1(predicted ambiguity, AEF ambiguity) for the APM, returned separately:
+    (segmentation loss, w1*CE, w2*contrast, w3*regression)."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.creterion = CrossEntropyLoss()
+        self.contrast_head = ContrastHead()
+        self.MAE = torch.nn.L1Loss()
+        self.MSE = torch.nn.MSELoss()
+        self.HUBER = torch.nn.HuberLoss(reduction='mean', delta=0.1)
+
+    def forward(self, logit, target, stageACE_list, num_classes, ignore_index, ambiguity_args):
+        ce, target = _cross_entropy(self.creterion, logit, target)
+        contrast, target_ai, _ = self.contrast_head(logit, target, stageACE_list, num_classes, ignore_index,
+                                                    ambiguity_args)
+        logits_ai = torch.cat(stageACE_list['ambiguity']).flatten()
+        regression = self.MAE(logits_ai, target_ai)
+        ce = ambiguity_args.w1 * ce
+        contrast = ambiguity_args.w2 * contrast
+        regression = ambiguity_args.w3 * regression
+        return ce + contrast, ce, contrast, regression
 
 
 def build_criterion_from_cfg(cfg, **kwargs):

@@ -1,0 +1,72 @@
+"""AMContrast3D++ backbone: the AMContrast3D encoder / decoder plus masked refinement of the decoder features.
+
+Drop-in for openpoints/models/backbone/pointnext_MM.py:
+    PointNextEncoder_M_AMContrast3D  :321-482  same layers, same forward as the AMContrast3D encoder
+                                               (pointnext_AA.py:313-471); only the registry name differs
+    PointNextDecoder_M_AMContrast3D  :485-573  FeaturePropogation stack + per-level RefinementMethod
+State-dict keys equal the reference's (``encoder.*`` / ``decoder.*`` as in the AA classes; the decoder's
+``ambiguity_head`` holds no parameters).
+"""
+from typing import List
+
+import numpy as np
+import torch
+
+from ..build import MODELS
+from .pointnext_AA import PointNextDecoder_AMContrast3D, PointNextEncoder_AMContrast3D
+from openpoints.AMContrast3D.MarginContrast import AmbiguityHead
+from openpoints.AMContrast3D.MaskedRefine import RefinementMethod
+
+
+@MODELS.register_module()
+class PointNextEncoder_M_AMContrast3D(PointNextEncoder_AMContrast3D):
+    pass
+
+
+@MODELS.register_module()
+class PointNextDecoder_M_AMContrast3D(PointNextDecoder_AMContrast3D):
+    def __init__(self, encoder_channel_list: List[int], decoder_layers: int = 2, decoder_stages: int = 4, **kwargs):
+        super().__init__(encoder_channel_list, decoder_layers, decoder_stages, **kwargs)
+        self.ambiguity_head = AmbiguityHead()
+
+    def forward_then_AMContrast3D(self, p, f, stage_list, mapping, attention, concate, nsample_k, threshold,
+                                  threshold_max, gamma, fusion, num_classes, ignore_index, ambiguity_args):
+        # ---- which ambiguity drives the refinement: the APM's prediction, or the AEF's estimate from the labels
+        if ambiguity_args.source == 'APM' and ambiguity_args.source_mode in ('Train', 'Test'):
+            a_list = stage_list['ambiguity']
+        elif ambiguity_args.source == 'AEF' and ambiguity_args.source_mode == 'Train':
+            if 'y' not in stage_list['inputs'].keys():
+                raise ValueError('Please change [ambiguity_args.source] to be [APM] for [Test].')
+            a_list = self.ambiguity_head(stage_list['inputs']['y'].flatten(), stage_list, num_classes, ignore_index,
+                                         ambiguity_args)
+            stage_list['ambiguity_GT'] = a_list
+        else:
+            raise ValueError('Please change [ambiguity_args.source] to be [APM] for [Test].')
+
+        geometry = stage_list.get('geometry')
+        if geometry is None:
+            geometry = stage_list['geometry'] = {}
+        if 'decoder' not in geometry:
+            geometry['decoder'] = self.plan_geometry(p)
+        refine_rate = []
+        B = f[0].shape[0]
+        for i in range(-1, -len(self.decoder) - 1, -1):
+            f[i - 1] = self.decoder[i][1:](
+                [p[i], self.decoder[i][0]([p[i - 1], f[i - 1]], [p[i], f[i]], geom=geometry['decoder'][i])])[1]
+            # the contrastive embedding is taken BEFORE the refinement (pointnext_MM.py:541-544)
+            stage_list['up'][i]['f_out'] = torch.flatten(f[i - 1].transpose(1, 2), start_dim=0, end_dim=1)
+            a = a_list[i].unsqueeze(0).view(B, 1, -1)
+            refine = RefinementMethod(stage_list, p[i - 1], f[i - 1], a, i, B, nsample_k, fusion, threshold_max,
+                                      threshold, gamma)
+            if mapping:
+                f[i - 1] = refine.MapAttention() if attention else refine.MapSum()
+            else:
+                f[i - 1], rate = refine.DualMasks()
+                refine_rate.append(rate)
+        avg_rate = np.mean(refine_rate)  # nan (with numpy's warning) when mapping is on, as in the reference
+        return f[-len(self.decoder) - 1].squeeze(-1), stage_list, avg_rate
+
+    def forward(self, p, f, stage_list, mapping, attention, concate, nsample_k, threshold, threshold_max, gamma, fusion,
+                num_classes, ignore_index, ambiguity_args):
+        return self.forward_then_AMContrast3D(p, f, stage_list, mapping, attention, concate, nsample_k, threshold,
+                                              threshold_max, gamma, fusion, num_classes, ignore_index, ambiguity_args)

@@ -112,6 +112,49 @@ def run_model_case(name, variant, B, N, num_classes=13, in_channels=4, dataset="
           f"({os.path.getsize(os.path.join(OUT, name + '.npz')) / 1e6:.2f} MB)")
 
 
+def run_mm_case(name, variant, B, N, num_classes=13, in_channels=4, dataset="s3dis", store_weights=True, grad_keys=(),
+                **model_kw):
+    """AMContrast3D++ (BaseSeg_M_AMContrast3D + CrossEntropyAcePre): one forward + loss + backward of the reference,
+    loss = segmentation + regression as examples/segmentation/main_MM.py:404-410 combines them."""
+    torch.manual_seed(0)
+    mcfg = cfg_of(configs.model_cfg_mm(variant, num_classes=num_classes, in_channels=in_channels, dropout=0, dataset=dataset,
+                                       **model_kw))
+    model = build_model_from_cfg(mcfg)
+    model.train()
+    criterion = build_criterion_from_cfg(cfg_of(configs.criterion_cfg_mm()))
+    aargs = cfg_of(configs.ambiguity_args_mm(dataset))
+    nb = synthetic.make_batch(B, N, first_id=300, num_classes=num_classes)
+    data = tensor_batch(nb)
+    target = data["y"]
+    out = {"pos": nb["pos"], "x": nb["x"], "y": nb["y"]}
+    sums = param_checksums(model)
+    if store_weights:
+        for k, v in model.state_dict().items():
+            out["w/" + k] = v.numpy().copy()
+    logits, stage, refine = model(data)
+    seg, ce, contrast, reg = criterion(logits, target, stage, num_classes, None, aargs)
+    loss = seg + reg
+    loss.backward()
+    out["logits"] = logits.detach().numpy()
+    out["loss"] = np.float64(loss.item())
+    out["loss_ce"], out["loss_contrast"], out["loss_reg"] = (np.float64(v.item()) for v in (ce, contrast, reg))
+    out["refine_rate"] = np.float64(refine)
+    for i in range(4):
+        out[f"apm/{i}"] = stage["ambiguity"][i].detach().numpy()
+        out[f"f_out/{i}"] = stage["up"][i]["f_out"].detach().numpy()
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    out["grad_abs_sum"] = np.float64(sum(float(g.double().abs().sum()) for g in grads.values()))
+    for k in grad_keys:
+        out["g/" + k] = grads[k].numpy().copy()
+    meta = {"variant": variant, "B": B, "N": N, "num_classes": num_classes, "in_channels": in_channels, "dataset": dataset,
+            "model_kw": model_kw, "param_checksums": sums, "grad_norms": {k: float(g.double().norm()) for k, g in grads.items()},
+            "state_keys": list(model.state_dict().keys()), "torch": torch.__version__}
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: loss={loss.item():.6f} ce={ce.item():.6f} contrast={contrast.item():.6f} reg={reg.item():.6f} "
+          f"refine={refine:.3f}% ({os.path.getsize(os.path.join(OUT, name + '.npz')) / 1e6:.2f} MB)")
+
+
 def run_ops_case():
     """The reference's Python wrappers on small clouds, including tie-heavy ones."""
     rng = np.random.default_rng(7)
@@ -194,8 +237,19 @@ def run_state_keys():
     print("state_keys:", {k: (v if isinstance(v, int) else len(v)) for k, v in keys.items()})
 
 
+def run_mm_cases():
+    # AMContrast3D++ with a narrow S-shaped backbone and stored weights: APM towers, masked refinement (DualMasks,
+    # threshold lowered so that a good share of the points is refined at seed-0 init), three-term loss
+    run_mm_case("model_mm_w8_b2_n2048", "S", 2, 2048, width=8, threshold=0.5,
+                grad_keys=["APM.layer_0.0.weight", "APM.layer_3.20.weight", "encoder.encoder.1.0.convs.0.0.weight",
+                           "decoder.decoder.0.0.convs.0.0.weight", "head.head.1.0.weight"])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "mm":
+        run_mm_cases()
+        sys.exit(0)
     run_state_keys()
     run_ops_case()
     G = ["encoder.encoder.0.0.convs.0.0.weight", "encoder.encoder.1.0.convs.0.0.weight",
@@ -210,3 +264,4 @@ if __name__ == "__main__":
     # ScanNet-shaped: 20 classes + ignore_index -100, 7 input channels, global max feature in the head
     run_model_case("model_S_scannet_b2_n2048", "S", 2, 2048, num_classes=20, in_channels=7, dataset="scannet",
                    ignore_index=-100, ignore_frac=0.05, voxel_size=0.02, global_feat="max", grad_keys=G[:1])
+    run_mm_cases()

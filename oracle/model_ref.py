@@ -87,6 +87,46 @@ def _block_params(enc, attr, scaling):
     return out
 
 
+# ------------------------------------------------------------------------------------------
+# AMContrast3D++ pieces: ambiguity prediction module and masked refinement
+# ------------------------------------------------------------------------------------------
+def apm_tower(sd, s, p, f, training=True):
+    """APM_pf_ConCate.forward for resolution s (AMContrast3D/APM/concatenation.py:26-57, 166-180): [Linear, Dropout(0),
+    BatchNorm1d, Sigmoid] x 5, Linear -> 1, BatchNorm1d, Sigmoid on rows [xyz ; feature]; p (B,n,3), f (B,D,n)."""
+    x = torch.cat((p.reshape(-1, 3), f.permute(0, 2, 1).reshape(-1, f.shape[1])), dim=1)
+    pre = f"APM.layer_{s}"
+    for lin, bn in ((0, 2), (4, 6), (8, 10), (12, 14), (16, 18), (20, 21)):
+        x = F.linear(x, sd[f"{pre}.{lin}.weight"], sd[f"{pre}.{lin}.bias"])
+        x = torch.sigmoid(_bn(x, sd, f"{pre}.{bn}", training))
+    return x  # (B*n, 1)
+
+
+def dual_masks(p, f, a, K_nn, threshold, threshold_max, gamma, fusion="MIN"):
+    """RefinementMethod.DualMasks (AMContrast3D/MaskedRefine.py:60-98): p (B,n,3), f (B,D,n), a (B,1,n).
+    The (B,D,n) tensor is reinterpreted as (B*n, D) rows (:64) and back (:106), the k-NN spans the whole batch."""
+    B, D, n = f.shape
+    xyz = p.reshape(-1, 3).contiguous()
+    o = torch.tensor([xyz.shape[0]], dtype=torch.int32)
+    nidx, _ = K.knnquery(K_nn, xyz, xyz, o, o)
+    nidx = nidx[..., 1:].contiguous()
+    m, k = nidx.shape
+    flat = nidx.view(-1).long()
+    f_rows = f.contiguous().view(-1, D)
+    a_rows = a.contiguous().view(-1, 1)
+    nf = f_rows[flat].view(m, k, D)
+    na = a_rows[flat].view(m, k, 1)
+    if fusion == "MIN":  # one-hot of the arg-min ambiguity times the features, summed over the neighbours (:103-113)
+        onehot = torch.zeros(m, k).scatter_(1, torch.min(na, 1).indices, 1.0)
+        good = (nf * onehot.unsqueeze(-1)).sum(1)
+    else:                # 'MIN_ALL0' (:114-119)
+        good = (nf * ~na.gt(0)).mean(1)
+    cross = good.view(B, D, -1)
+    mask = a.le(threshold_max) * a.ge(threshold)
+    f_new = f * ~mask + cross * mask
+    rate = float(mask.long().count_nonzero()) / a.numel() * 100
+    return gamma * f_new + (1 - gamma) * f, rate
+
+
 def model_forward(sd, cfg, data, training=True):
     """BaseSeg_AMContrast3D.forward (base_seg.py:122-126) -> logits (B,ncls,N), stage list.
 
@@ -140,6 +180,11 @@ def model_forward(sd, cfg, data, training=True):
             down.append({"p_out": po.reshape(-1, 3), "f_out": fo.transpose(1, 2).reshape(-1, fo.shape[1]),
                          "offset": torch.tensor([po.shape[0] * po.shape[1]], dtype=torch.int32)})
     stage = {"inputs": data, "down": down, "up": down}
+    apm = cfg.get("APM_args")  # AMContrast3D++ (base_seg.py:57-94): predicted ambiguities of p[1..4]
+    if apm is not None:
+        assert not apm["linear_mapping"], "oracle: the shipped MM configs use linear_mapping False"
+        stage["ambiguity"] = [apm_tower(sd, s, p[s + 1], f[s + 1], training) for s in range(4)]
+    rates = []
 
     # decoder (pointnext_AA.py:508-522; FeaturePropogation.forward :210-226)
     ndec = 4
@@ -153,6 +198,11 @@ def model_forward(sd, cfg, data, training=True):
             k += 1
         f[i - 1] = x
         stage["up"][i]["f_out"] = x.transpose(1, 2).reshape(-1, x.shape[1])
+        if apm is not None:  # pointnext_MM.py:546-558: refine AFTER the contrastive embedding was taken
+            a = stage["ambiguity"][i].unsqueeze(0).view(x.shape[0], 1, -1)
+            f[i - 1], rate = dual_masks(p[i - 1], x, a, apm["nsample_k"], apm["threshold"], apm["threshold_max"],
+                                        apm["gamma"], apm["fusion"])
+            rates.append(rate)
 
     # SegHead (base_seg.py:256-267); dropout is expected to be disabled (p = 0) in parity runs
     x = f[-ndec - 1]
@@ -166,6 +216,8 @@ def model_forward(sd, cfg, data, training=True):
     for n, hi in enumerate(keys):
         lastk = n == len(keys) - 1
         x = _convblock(x, sd, f"head.head.{hi}", norm=not lastk, act=not lastk, training=training)
+    if apm is not None:
+        stage["refine_rate"] = sum(rates) / len(rates)
     return x, stage
 
 
@@ -256,4 +308,24 @@ def train_step(sd, cfg, data, target, num_classes, ignore_index, args):
     loss.backward()
     grads = {k: v.grad for k, v in leaf.items() if isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None}
     return {"loss": loss.detach(), "ce": ce.detach(), "contrast": [x.detach() for x in parts], "ambiguity": amb,
+            "logits": logits.detach(), "grads": grads, "stage": stage}
+
+
+def criterion_mm(logits, target, stage, num_classes, ignore_index, args):
+    """CrossEntropyAcePre.forward (loss/build.py:294-319) -> (segmentation loss, w1*ce, w2*contrast, w3*regression)."""
+    seg, ce, parts, amb = criterion(logits, target, stage, num_classes, ignore_index, args)
+    reg = F.l1_loss(torch.cat(stage["ambiguity"]).flatten(), torch.cat(amb))
+    return seg, args["w1"] * ce, args["w2"] * sum(parts), args["w3"] * reg
+
+
+def train_step_mm(sd, cfg, data, target, num_classes, ignore_index, args):
+    """main_MM.py:404-417: loss = segmentation + regression, one backward."""
+    leaf = {k: (v.detach().clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
+            for k, v in sd.items()}
+    logits, stage = model_forward(leaf, cfg, data, training=True)
+    seg, ce, contrast, reg = criterion_mm(logits, target, stage, num_classes, ignore_index, args)
+    loss = seg + reg
+    loss.backward()
+    grads = {k: v.grad for k, v in leaf.items() if isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None}
+    return {"loss": loss.detach(), "ce": ce.detach(), "contrast": contrast.detach(), "reg": reg.detach(),
             "logits": logits.detach(), "grads": grads, "stage": stage}

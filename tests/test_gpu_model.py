@@ -160,3 +160,44 @@ def test_precomputed_geometry_is_the_same_computation():
         geometry.copy_into(plan, plan2)
         logits2, _ = model(d2)
         assert torch.equal(logits0, logits2)
+
+
+def test_mm_product_matches_reference_run():
+    """AMContrast3D++ (BaseSeg_M_AMContrast3D + CrossEntropyAcePre): APM towers, masked refinement (DualMasks over
+    the GPU k-NN), three-term loss and gradients against the reference's own run (tests/golden/model_mm_*.npz)."""
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from openpoints.loss import build_criterion_from_cfg
+    from openpoints.models import build_model_from_cfg
+    dev = torch.device("cuda:0")
+    g = load_golden("model_mm_w8_b2_n2048")
+    m = g["meta"]
+    cfg = configs.model_cfg_mm(m["variant"], num_classes=m["num_classes"], in_channels=m["in_channels"], dropout=0,
+                               dataset=m["dataset"], **m["model_kw"])
+    model = build_model_from_cfg(easy(cfg))
+    assert list(model.state_dict().keys()) == m["state_keys"]  # the authors' checkpoints load key by key
+    model.load_state_dict({k[2:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("w/")}, strict=True)
+    model = model.to(dev).train()
+    criterion = build_criterion_from_cfg(easy(configs.criterion_cfg_mm())).to(dev)
+    aargs = easy(configs.ambiguity_args_mm(m["dataset"]))
+    data = {"pos": torch.from_numpy(g["pos"]).to(dev), "x": torch.from_numpy(g["x"]).to(dev),
+            "y": torch.from_numpy(g["y"]).to(dev)}
+    logits, stage, refine = model(data)
+    seg, ce, contrast, reg = criterion(logits, data["y"], stage, m["num_classes"], None, aargs)
+    (seg + reg).backward()  # examples/segmentation/main_MM.py:409-410
+
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["logits"], rtol=1e-4, atol=1e-4)
+    for got, ref in ((seg + reg, "loss"), (ce, "loss_ce"), (contrast, "loss_contrast"), (reg, "loss_reg")):
+        assert abs(float(got) - float(g[ref])) <= 1e-4 * max(1.0, abs(float(g[ref]))), ref
+    assert abs(refine - float(g["refine_rate"])) <= 1e-2  # percent of refined points; a threshold comparison per point
+    for i in range(4):
+        np.testing.assert_allclose(stage["ambiguity"][i].detach().cpu().numpy(), g[f"apm/{i}"], rtol=1e-4, atol=1e-5)
+        assert_close_range(stage["up"][i]["f_out"].detach().cpu().numpy(), g[f"f_out/{i}"], f"f_out/{i}")
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    for k, v in g.items():
+        if k.startswith("g/"):
+            ref = torch.from_numpy(v).to(dev)
+            assert float((grads[k[2:]] - ref).norm()) <= GRAD_RTOL * float(ref.norm()) + 1e-7, k
+    gmax = max(m["grad_norms"].values())
+    for k, n in m["grad_norms"].items():
+        assert abs(float(grads[k].double().norm()) - n) <= GRAD_RTOL * n + 1e-5 * gmax, k

@@ -170,3 +170,28 @@ def test_synthetic_scenes_are_reproducible_and_shaped():
     d = synthetic.make_scene(5, 4000, duplicates=True)
     import numpy as np
     assert len(np.unique(d["pos"], axis=0)) < 4000  # padded by repetition like data_util.py:161-167
+
+
+def test_mm_registry_and_state_keys():
+    """AMContrast3D++ classes are registered under the reference's names and the model's state-dict keys are the
+    reference's (recorded in the golden fixture's meta by oracle/gen_golden.py)."""
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from amcontrast3d_amd import configs
+    from conftest import load_golden
+    from openpoints.loss import LOSS
+    from openpoints.models import MODELS, build_model_from_cfg
+    from openpoints.utils import EasyConfig
+    for name in ("BaseSeg_M_AMContrast3D", "PointNextEncoder_M_AMContrast3D", "PointNextDecoder_M_AMContrast3D",
+                 "APM_pf_ConCate"):
+        assert MODELS.get(name) is not None, name
+    assert LOSS.get("CrossEntropyAcePre") is not None
+    m = load_golden("model_mm_w8_b2_n2048")["meta"]
+    c = EasyConfig()
+    c.update(configs.model_cfg_mm(m["variant"], dropout=0, **m["model_kw"]))
+    model = build_model_from_cfg(c)
+    assert list(model.state_dict().keys()) == m["state_keys"]
+    xl = EasyConfig()
+    xl.update(configs.model_cfg_mm("XL"))  # cfgs/s3dis/AMContrast3D-MM.yaml shape
+    apm = build_model_from_cfg(xl.APM_args)
+    assert [apm.layer_0[0].in_features, apm.layer_3[0].in_features] == [3 + 64, 3 + 512]

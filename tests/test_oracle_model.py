@@ -67,3 +67,34 @@ def test_oracle_matches_reference_run(name):
     gmax = max(m["grad_norms"].values())
     for k, n in m["grad_norms"].items():
         assert abs(float(r["grads"][k].double().norm()) - n) <= GRAD_RTOL * n + 1e-5 * gmax, k
+
+
+# ---- AMContrast3D++: APM + masked refinement + three-term loss ------------------------
+def mm_case_setup(name="model_mm_w8_b2_n2048"):
+    g = load_golden(name)
+    m = g["meta"]
+    cfg = configs.model_cfg_mm(m["variant"], num_classes=m["num_classes"], in_channels=m["in_channels"], dropout=0,
+                               dataset=m["dataset"], **m["model_kw"])
+    sd = {k[2:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("w/")}
+    data = {"pos": torch.from_numpy(g["pos"]), "x": torch.from_numpy(g["x"])}
+    return g, m, cfg, sd, data, torch.from_numpy(g["y"])
+
+
+def test_oracle_mm_matches_reference_run():
+    g, m, cfg, sd, data, target = mm_case_setup()
+    torch.set_num_threads(8)
+    r = model_ref.train_step_mm(sd, cfg, data, target, m["num_classes"], None, configs.ambiguity_args_mm(m["dataset"]))
+    np.testing.assert_allclose(r["logits"].numpy(), g["logits"], rtol=1e-4, atol=1e-4)
+    for key, ref in (("loss", "loss"), ("ce", "loss_ce"), ("contrast", "loss_contrast"), ("reg", "loss_reg")):
+        assert abs(float(r[key]) - float(g[ref])) <= 1e-4 * max(1.0, abs(float(g[ref]))), key
+    assert abs(r["stage"]["refine_rate"] - float(g["refine_rate"])) <= 1e-3
+    for i in range(4):
+        np.testing.assert_allclose(r["stage"]["ambiguity"][i].detach().numpy(), g[f"apm/{i}"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(r["stage"]["up"][i]["f_out"].detach().numpy(), g[f"f_out/{i}"], rtol=1e-4, atol=1e-4)
+    for k, v in g.items():
+        if k.startswith("g/"):
+            ref = torch.from_numpy(v)
+            assert float((r["grads"][k[2:]] - ref).norm()) <= GRAD_RTOL * float(ref.norm()) + 1e-7, k
+    gmax = max(m["grad_norms"].values())
+    for k, n in m["grad_norms"].items():
+        assert abs(float(r["grads"][k].double().norm()) - n) <= GRAD_RTOL * n + 1e-5 * gmax, k
