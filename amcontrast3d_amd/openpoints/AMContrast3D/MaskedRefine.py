@@ -43,7 +43,8 @@ class RefinementMethod:
     # ---- the default: self mask x cross mask --------------------------------------------------------------
     def DualMasks(self):
         xyz = self.position.view(-1, 3)
-        o = torch.tensor([xyz.shape[0]], dtype=torch.int32, device=xyz.device)
+        from openpoints.models.backbone.pointnext_AA import _segment_offset
+        o = _segment_offset(xyz.shape[0], xyz.device)  # IntTensor([b*n]).cuda() of the reference, cached (capture-safe)
         neighbor_idx, _ = pointops.knnquery(self.sample_k, xyz, xyz, o, o)  # (b*n, K), one segment
         D = self.feature.shape[1]
         f_rows = self.feature.view(-1, D)      # memory reinterpretation, see the module docstring
@@ -52,10 +53,17 @@ class RefinementMethod:
         neighbor_idx = neighbor_idx[..., 1:].contiguous()
         m = neighbor_idx.shape[0]
         flat = neighbor_idx.view(-1).long()
-        neighbor_feature = f_rows[flat, :].view(m, self.sample_k, D)
-        neighbor_ambiguity = a_rows[flat, :].view(m, self.sample_k, 1)
-
-        cross = self.cross_mask(neighbor_ambiguity, neighbor_feature, D)
+        neighbor_ambiguity = a_rows.index_select(0, flat).view(m, self.sample_k, 1)
+        if self.fusion == 'MIN':
+            # The reference gathers all K-1 neighbour rows (m, K-1, D), multiplies them by a one-hot of the arg-min
+            # ambiguity and sums over the neighbours (:103-113): that IS the arg-min neighbour's row (plus exact
+            # zeros).  Gathering only that row moves 1/(K-1) of the bytes, forward and backward (index_add).
+            good_idx = torch.min(neighbor_ambiguity, 1).indices                            # (m, 1), first on ties
+            best = neighbor_idx.long().gather(1, good_idx).view(-1)
+            cross = f_rows.index_select(0, best).view(self.feature.shape[0], D, -1)
+        else:
+            neighbor_feature = f_rows.index_select(0, flat).view(m, self.sample_k, D)
+            cross = self.cross_mask(neighbor_ambiguity, neighbor_feature, D)
         self_mask, rate = self.self_mask()
         f_new = self.feature * ~self_mask + cross * self_mask
         self.feature = self.gamma * f_new + (1 - self.gamma) * self.feature  # constant updating rate
@@ -76,5 +84,8 @@ class RefinementMethod:
 
     def self_mask(self):
         mask = self.ambiguity.le(self.threshold_max) * self.ambiguity.ge(self.threshold)
-        update_count = torch.count_nonzero(mask.long()).item()  # host sync, as in the reference (:113)
-        return mask, (update_count / self.ambiguity.numel()) * 100
+        count = torch.count_nonzero(mask.long())
+        if mask.is_cuda and torch.cuda.is_current_stream_capturing():
+            # under hipGraph capture the percentage stays a 0-dim tensor (the reference's .item() is a host sync)
+            return mask, count.to(torch.float32) / self.ambiguity.numel() * 100
+        return mask, (count.item() / self.ambiguity.numel()) * 100

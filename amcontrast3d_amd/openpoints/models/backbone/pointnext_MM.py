@@ -63,7 +63,10 @@ class PointNextDecoder_M_AMContrast3D(PointNextDecoder_AMContrast3D):
             else:
                 f[i - 1], rate = refine.DualMasks()
                 refine_rate.append(rate)
-        avg_rate = np.mean(refine_rate)  # nan (with numpy's warning) when mapping is on, as in the reference
+        if refine_rate and torch.is_tensor(refine_rate[0]):
+            avg_rate = torch.stack(refine_rate).mean()  # captured step: stays on the device
+        else:
+            avg_rate = np.mean(refine_rate)  # nan (with numpy's warning) when mapping is on, as in the reference
         return f[-len(self.decoder) - 1].squeeze(-1), stage_list, avg_rate
 
     def forward(self, p, f, stage_list, mapping, attention, concate, nsample_k, threshold, threshold_max, gamma, fusion,

@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="clouds per GPU")
     ap.add_argument("--points", type=int, default=24000)
     ap.add_argument("--variant", default="S")
+    ap.add_argument("--mm", action="store_true",
+                    help="AMContrast3D++ (BaseSeg_M_AMContrast3D + CrossEntropyAcePre) instead of AMContrast3D")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--fps-lanes", type=int, default=2,
@@ -58,7 +60,7 @@ def parse():
     return ap.parse_args()
 
 
-def build(variant, dev, world, ddp):
+def build(variant, dev, world, ddp, mm=False):
     import amcontrast3d_amd
     amcontrast3d_amd.activate()
     from amcontrast3d_amd import configs, dist as adist
@@ -66,14 +68,14 @@ def build(variant, dev, world, ddp):
     from openpoints.models import build_model_from_cfg
     from openpoints.utils import EasyConfig
     torch.manual_seed(0)
-    cfg = configs.model_cfg(variant, dropout=0.5)
+    cfg = configs.model_cfg_mm(variant, dropout=0.5) if mm else configs.model_cfg(variant, dropout=0.5)
     c = EasyConfig(); c.update(cfg)
     model = build_model_from_cfg(c).to(dev).train()
     if ddp:
         model = adist.wrap_data_parallel(model, dev, world)
-    cc = EasyConfig(); cc.update(configs.criterion_cfg())
+    cc = EasyConfig(); cc.update(configs.criterion_cfg_mm() if mm else configs.criterion_cfg())
     criterion = build_criterion_from_cfg(cc).to(dev)
-    aargs = EasyConfig(); aargs.update(configs.ambiguity_args("s3dis"))
+    aargs = EasyConfig(); aargs.update(configs.ambiguity_args_mm("s3dis") if mm else configs.ambiguity_args("s3dis"))
     # cfgs/s3dis/default.yaml:64-72: AdamW lr 0.01 wd 1e-4, clip 10
     decay, no_decay = [], []
     for p in model.parameters():
@@ -119,7 +121,7 @@ def main():
 
     use_ddp = world > 1 and args.sync_bn
     use_graph = not args.no_graph and not use_ddp
-    cfg, model, criterion, aargs, opt = build(args.variant, dev, world, use_ddp)
+    cfg, model, criterion, aargs, opt = build(args.variant, dev, world, use_ddp, args.mm)
     ids = adist.scene_ids(rank, world, args.batch)
     nb = synthetic.make_batch(args.batch, args.points, first_id=ids[0])
     data = {k: torch.from_numpy(v).to(dev) for k, v in nb.items()}
@@ -128,8 +130,13 @@ def main():
     out = {}
 
     def fwd_bwd():
-        logits, stage = model(data)
-        out["loss"] = criterion(logits, data["y"], stage, 13, None, aargs)
+        if args.mm:  # examples/segmentation/main_MM.py:404-410: segmentation + regression objective
+            logits, stage, _ = model(data)
+            seg, _, _, reg = criterion(logits, data["y"], stage, 13, None, aargs)
+            out["loss"] = seg + reg
+        else:
+            logits, stage = model(data)
+            out["loss"] = criterion(logits, data["y"], stage, 13, None, aargs)
         out["loss"].backward()
 
     # Software pipeline over consecutive batches.  The coordinate-only half of a step
@@ -361,7 +368,7 @@ def main():
             "value": round(value, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"PointNeXt-{args.variant} + AMContrast3D-AA, S3DIS-shaped {args.points}-pt "
+            "config": {"workload": f"PointNeXt-{args.variant} + AMContrast3D-{'MM (++)' if args.mm else 'AA'}, S3DIS-shaped {args.points}-pt "
                                    f"voxelised (0.04 m) clouds, batch {args.batch}/GPU, fwd + CE/contrast loss + bwd + "
                                    f"clip + AdamW",
                        "global_batch": args.batch * world, "points": args.points,
