@@ -102,8 +102,33 @@ def precompute_rest(model, contrast_head, data, fps, num_classes, ignore_index, 
             blocks.append(cache[key])
         enc.append(blocks)
     plan = {"encoder": enc, "decoder": m.decoder.plan_geometry(p)}
-    plan["loss"] = precompute_loss(contrast_head, plan, data["y"], num_classes, ignore_index, ambiguity_args)
+    from . import ops
+    with ops.knn_grid_reuse():  # the refinement's k-NN searches the same clouds as the loss: shared cell grids
+        plan["loss"] = precompute_loss(contrast_head, plan, data["y"], num_classes, ignore_index, ambiguity_args)
+        refine = precompute_refine(m, plan)
+        if refine is not None:
+            plan["refine"] = refine
     return plan
+
+
+@torch.no_grad()
+def precompute_refine(model, plan):
+    """AMContrast3D++ only: the neighbour lists of the decoder's masked refinement (MaskedRefine.py:60-70, k-NN of
+    every decoder level's cloud over the whole batch, self match dropped) -- coordinates only, so part of the plan.
+    -> {level i in -1..-4: idx (B*n, K-1) int32} or None for models without refinement."""
+    from . import ops
+    from openpoints.models.backbone.pointnext_AA import _segment_offset
+    k = getattr(model, "nsample_k", None)
+    if k is None or getattr(model, "linear_mapping", False):
+        return None
+    out = {}
+    stages = stage_points(plan)  # flattened clouds of p[1..4]; decoder level i refines p[i-1] = stage index 4+i
+    for i in range(-1, -len(stages) - 1, -1):
+        xyz = stages[4 + i]["p_out"]
+        o = _segment_offset(xyz.shape[0], xyz.device)
+        idx, _ = ops.knnquery(k, xyz, xyz, o, o)
+        out[i] = idx[..., 1:].contiguous()
+    return out
 
 
 def split(plan):
@@ -112,6 +137,8 @@ def split(plan):
     rest = {"encoder": [[{k: v for k, v in b[0].items() if k not in ("fps_idx", "new_p")}] + list(b[1:])
                         for b in plan["encoder"]],
             "decoder": plan["decoder"], "loss": plan["loss"]}
+    if "refine" in plan:
+        rest["refine"] = plan["refine"]
     return fps, rest
 
 

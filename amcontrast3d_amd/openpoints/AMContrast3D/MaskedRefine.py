@@ -42,15 +42,20 @@ class RefinementMethod:
 
     # ---- the default: self mask x cross mask --------------------------------------------------------------
     def DualMasks(self):
-        xyz = self.position.view(-1, 3)
-        from openpoints.models.backbone.pointnext_AA import _segment_offset
-        o = _segment_offset(xyz.shape[0], xyz.device)  # IntTensor([b*n]).cuda() of the reference, cached (capture-safe)
-        neighbor_idx, _ = pointops.knnquery(self.sample_k, xyz, xyz, o, o)  # (b*n, K), one segment
+        geometry = self.stage_list.get('geometry') if hasattr(self.stage_list, 'get') else None
+        planned = geometry.get('refine') if geometry is not None else None
+        if planned is not None and self.i in planned and planned[self.i].shape[1] == self.sample_k - 1:
+            neighbor_idx = planned[self.i]      # coordinate-only: prepared with the rest of the geometry plan
+        else:
+            xyz = self.position.view(-1, 3)
+            from openpoints.models.backbone.pointnext_AA import _segment_offset
+            o = _segment_offset(xyz.shape[0], xyz.device)  # IntTensor([b*n]).cuda() of the reference, cached
+            neighbor_idx, _ = pointops.knnquery(self.sample_k, xyz, xyz, o, o)  # (b*n, K), one segment
+            neighbor_idx = neighbor_idx[..., 1:].contiguous()
         D = self.feature.shape[1]
         f_rows = self.feature.view(-1, D)      # memory reinterpretation, see the module docstring
         a_rows = self.ambiguity.view(-1, 1)
         self.sample_k -= 1                      # drop the self match
-        neighbor_idx = neighbor_idx[..., 1:].contiguous()
         m = neighbor_idx.shape[0]
         flat = neighbor_idx.view(-1).long()
         neighbor_ambiguity = a_rows.index_select(0, flat).view(m, self.sample_k, 1)

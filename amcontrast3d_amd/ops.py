@@ -244,7 +244,9 @@ class knn_grid_reuse:
 
     def __enter__(self):
         global _grid_cache
-        self.prev, _grid_cache = _grid_cache, {}
+        self.prev = _grid_cache
+        if _grid_cache is None:  # re-entrant: an enclosing block's grids stay visible
+            _grid_cache = {}
         return self
 
     def __exit__(self, *exc):

@@ -201,3 +201,30 @@ def test_mm_product_matches_reference_run():
     gmax = max(m["grad_norms"].values())
     for k, n in m["grad_norms"].items():
         assert abs(float(grads[k].double().norm()) - n) <= GRAD_RTOL * n + 1e-5 * gmax, k
+
+
+def test_mm_precomputed_geometry_is_the_same_computation():
+    """The refinement's neighbour lists are coordinate-only and travel with the geometry plan: bit-identical logits."""
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from amcontrast3d_amd import geometry, synthetic
+    from openpoints.loss import build_criterion_from_cfg
+    from openpoints.models import build_model_from_cfg
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = build_model_from_cfg(easy(configs.model_cfg_mm("S", dropout=0, width=8, threshold=0.5))).to(dev).train()
+    criterion = build_criterion_from_cfg(easy(configs.criterion_cfg_mm())).to(dev)
+    aa = easy(configs.ambiguity_args_mm("s3dis"))
+    nb = synthetic.make_batch(2, 2048, first_id=55)
+    data = {k: torch.from_numpy(v).to(dev) for k, v in nb.items()}
+    logits0, stage0, r0 = model(dict(data))
+    seg0 = criterion(logits0, data["y"], stage0, 13, None, aa)[0]
+    plan = geometry.precompute(model, criterion.contrast_head, data, 13, None, aa) if False else None
+    fps = geometry.precompute_fps(model, data)
+    plan = geometry.precompute_rest(model, criterion.contrast_head, data, fps, 13, None, aa)
+    assert set(plan["refine"]) == {-1, -2, -3, -4} and plan["refine"][-4].shape == (2 * 2048, 11)
+    d2 = dict(data)
+    d2["_geometry"] = plan
+    logits1, stage1, r1 = model(d2)
+    seg1 = criterion(logits1, data["y"], stage1, 13, None, aa)[0]
+    assert torch.equal(logits0, logits1) and float(seg0) == float(seg1) and abs(r0 - r1) < 1e-9
