@@ -67,9 +67,10 @@ def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
 
 
 def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
-    work = torch.empty(b * n, dtype=torch.int32, device=points.device)
+    wb = int(_lib.load().amc3d_fps_workspace_bytes(b, n))
+    work = torch.empty(max(wb, 4), dtype=torch.uint8, device=points.device)
     _call("amc3d_furthest_point_sampling", points, b, n, m, _p(points), _p(temp) if temp is not None else None, _p(idx),
-          _p(work), work.numel() * 4)
+          _p(work), wb)
     return 1
 
 

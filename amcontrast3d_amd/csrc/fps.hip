@@ -112,6 +112,77 @@ struct FpsRecord {  // one per wave and iteration parity, 32 bytes
     float x, y, z, pad2;
 };
 
+// Morton-cell counting sort of one cloud by the whole workgroup: perm[sorted position] = point index (cells of a
+// 16^3 grid over the cloud's bounding box, in Morton order; the order inside a cell is whatever the atomics give --
+// no result depends on it).  Ends with a workgroup barrier: perm is visible to the workgroup afterwards.
+__device__ __forceinline__ void fps_morton_sort(const float *__restrict__ pts, int n, int *__restrict__ perm, int *s_cells,
+                                                float (*s_red)[6], int *s_wsum)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (int k = tid; k < n; k += nthreads) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = pts[(size_t)k * 3 + c];
+            lo[c] = fminf(lo[c], v);
+            hi[c] = fmaxf(hi[c], v);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        lo[c] = -wave_max_f32(-lo[c]);
+        hi[c] = wave_max_f32(hi[c]);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { s_red[wave][c] = lo[c]; s_red[wave][3 + c] = hi[c]; }
+    }
+    for (int i = tid; i < 4096; i += nthreads) s_cells[i] = 0;
+    __syncthreads();
+    float mn[3], sc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float l = s_red[0][c], h = s_red[0][3 + c];
+        for (int w = 1; w < nwaves; ++w) { l = fminf(l, s_red[w][c]); h = fmaxf(h, s_red[w][3 + c]); }
+        mn[c] = l;
+        sc[c] = h > l ? 16.f / (h - l) : 0.f;
+    }
+    auto cell_of = [&](int k) {
+        unsigned cc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int v = (int)((pts[(size_t)k * 3 + c] - mn[c]) * sc[c]);
+            cc[c] = (unsigned)min(max(v, 0), 15);
+        }
+        return (int)morton3_4bit(cc[0], cc[1], cc[2]);
+    };
+    for (int k = tid; k < n; k += nthreads) atomicAdd(&s_cells[cell_of(k)], 1);
+    __syncthreads();
+    // exclusive scan of the 4096 counters: each thread owns a contiguous chunk
+    const int per = 4096 / nthreads;  // nthreads in {64,...,1024} divides 4096
+    int sum = 0;
+    for (int i = 0; i < per; ++i) sum += s_cells[tid * per + i];
+    int inc = sum;
+    for (int s = 1; s < 64; s <<= 1) {
+        const int o = __shfl_up(inc, s, 64);
+        if (lane >= s) inc += o;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += s_wsum[w];
+    int run = base + inc - sum;
+    for (int i = 0; i < per; ++i) {
+        const int c = s_cells[tid * per + i];
+        s_cells[tid * per + i] = run;
+        run += c;
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += nthreads) perm[atomicAdd(&s_cells[cell_of(k)], 1)] = k;
+    __syncthreads();  // perm (global, written by this workgroup) is visible to it from here on
+}
+
 // coordinates of slot j (wave-uniform) of lane wl, straight from the owner lane's VGPRs
 template <int PPT>
 __device__ __forceinline__ void fps_slot_coords(const float (&px)[PPT], const float (&py)[PPT], const float (&pz)[PPT], int j,
@@ -172,69 +243,7 @@ __global__ __launch_bounds__(MAXT) void fps_kernel(int n, int m, int log2rb, con
     int *out = idxs + (size_t)blockIdx.x * m;
 
     // ================= prologue 1: Morton-cell counting sort of the cloud (perm[sorted] = k) =========
-    {
-        float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
-        for (int k = tid; k < n; k += nthreads) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float v = pts[(size_t)k * 3 + c];
-                lo[c] = fminf(lo[c], v);
-                hi[c] = fmaxf(hi[c], v);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            lo[c] = -wave_max_f32(-lo[c]);
-            hi[c] = wave_max_f32(hi[c]);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { s_red[wave][c] = lo[c]; s_red[wave][3 + c] = hi[c]; }
-        }
-        for (int i = tid; i < 4096; i += nthreads) s_cells[i] = 0;
-        __syncthreads();
-        float mn[3], sc[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float l = s_red[0][c], h = s_red[0][3 + c];
-            for (int w = 1; w < nwaves; ++w) { l = fminf(l, s_red[w][c]); h = fmaxf(h, s_red[w][3 + c]); }
-            mn[c] = l;
-            sc[c] = h > l ? 16.f / (h - l) : 0.f;
-        }
-        auto cell_of = [&](int k) {
-            unsigned cc[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int v = (int)((pts[(size_t)k * 3 + c] - mn[c]) * sc[c]);
-                cc[c] = (unsigned)min(max(v, 0), 15);
-            }
-            return (int)morton3_4bit(cc[0], cc[1], cc[2]);
-        };
-        for (int k = tid; k < n; k += nthreads) atomicAdd(&s_cells[cell_of(k)], 1);
-        __syncthreads();
-        // exclusive scan of the 4096 counters: each thread owns a contiguous chunk
-        const int per = 4096 / nthreads;  // nthreads in {64,...,1024} divides 4096
-        int sum = 0;
-        for (int i = 0; i < per; ++i) sum += s_cells[tid * per + i];
-        int inc = sum;
-        for (int s = 1; s < 64; s <<= 1) {
-            const int o = __shfl_up(inc, s, 64);
-            if (lane >= s) inc += o;
-        }
-        if (lane == 63) s_wsum[wave] = inc;
-        __syncthreads();
-        int base = 0;
-        for (int w = 0; w < wave; ++w) base += s_wsum[w];
-        int run = base + inc - sum;
-        for (int i = 0; i < per; ++i) {
-            const int c = s_cells[tid * per + i];
-            s_cells[tid * per + i] = run;
-            run += c;
-        }
-        __syncthreads();
-        for (int k = tid; k < n; k += nthreads) perm[atomicAdd(&s_cells[cell_of(k)], 1)] = k;
-        __syncthreads();  // perm (global, written by this workgroup) is visible to it from here on
-    }
+    fps_morton_sort(pts, n, perm, s_cells, s_red, s_wsum);
 
     // ================= prologue 2: load the cloud in sorted order, group spheres ====================
     // group G = g * nwaves + wave holds sorted positions [G*GS*64, (G+1)*GS*64): neighbouring groups
@@ -505,6 +514,173 @@ __global__ __launch_bounds__(MAXT) void fps_kernel(int n, int m, int log2rb, con
 #endif
 }
 
+// Clouds too large for the register file (24576 < n <= FPS_L2_MAX, e.g. the 64000 / 120000-point ScanNet batches
+// of the AMContrast3D++ configs).  Same algorithm as fps_kernel -- Morton-sorted cloud, 512-point groups with
+// bounding boxes, exact pruning, a tie slow path in the reference's key order -- but the sorted cloud (float4
+// x, y, z, running minimum) lives in the caller's workspace, i.e. in L2 (16 bytes per point), and only the groups
+// a new sample can affect are loaded, updated and stored.  Every group's state -- box, M = its largest running
+// minimum, where that maximum sits and its coordinates -- is held by one lane of the wave that owns the group
+// (groups are dealt round-robin to the 16 waves; up to 32 per wave), so the per-iteration arg-max is a lane-
+// parallel reduction over group states, with no memory access on the critical path unless a group is swept.
+constexpr int FPS_L2_GROUP = 512;
+constexpr int FPS_L2_MAX = 16 * 32 * FPS_L2_GROUP;  // 262144 points per cloud
+
+__global__ __launch_bounds__(1024) void fps_kernel_l2(int n, int m, int log2rb, const float *__restrict__ dataset,
+                                                       float *__restrict__ temp, int *__restrict__ idxs,
+                                                       int *__restrict__ perm_ws, float4 *__restrict__ sorted_ws)
+{
+    __shared__ int s_cells[4096];
+    __shared__ float s_red[16][6];
+    __shared__ int s_wsum[16];
+    __shared__ FpsRecord s_rec[2][16];
+    __shared__ unsigned s_key[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *pts = dataset + (size_t)blockIdx.x * n * 3;
+    int *perm = perm_ws + (size_t)blockIdx.x * n;
+    float4 *sp = sorted_ws + (size_t)blockIdx.x * n;
+    int *out = idxs + (size_t)blockIdx.x * m;
+
+    fps_morton_sort(pts, n, perm, s_cells, s_red, s_wsum);
+    for (int s0 = tid; s0 < n; s0 += 1024) {
+        const int k = perm[s0];
+        sp[s0] = make_float4(pts[(size_t)k * 3], pts[(size_t)k * 3 + 1], pts[(size_t)k * 3 + 2],
+                             temp ? temp[(size_t)blockIdx.x * n + k] : 1e10f);
+    }
+    __syncthreads();  // sp (global, written by this workgroup) is visible to it from here on
+
+    // ---- group states: lane g of wave w owns group G = w + 16 g ------------------------------------------------
+    const int ngroups = (n + FPS_L2_GROUP - 1) / FPS_L2_GROUP;
+    const int ngw = (ngroups - wave + 15) / 16;  // groups of this wave (<= 32)
+    float blx = 0.f, bly = 0.f, blz = 0.f, bhx = 0.f, bhy = 0.f, bhz = 0.f, gm = -2.f;  // box, M (-2: no group)
+    float gx = 0.f, gy = 0.f, gz = 0.f;  // coordinates of the group's arg-max
+    int gpos = 0, gtie = 0;              // its sorted position; M attained more than once inside the group
+
+    // (re)compute group g's state after `upd` (the sample's coordinates, or NaN-free far point for the initial pass)
+    auto sweep_group = [&](int g, float x1, float y1, float z1, bool first) {
+        const int base = (wave + 16 * g) * FPS_L2_GROUP;
+        float4 v[8];
+        float b = -1.f;
+        float lx = 3.4e38f, ly = 3.4e38f, lz = 3.4e38f, hx = -3.4e38f, hy = -3.4e38f, hz = -3.4e38f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s0 = base + j * 64 + lane;
+            const bool ok = s0 < n;
+            v[j] = ok ? sp[s0] : make_float4(0.f, 0.f, 0.f, -2.f);
+            if (!first && ok) {
+                const float d = dist2_ref(v[j].x, v[j].y, v[j].z, x1, y1, z1);
+                const float dm = fminf(d, v[j].w);
+                if (dm != v[j].w) sp[s0].w = dm;  // 4-byte store of the changed minima only
+                v[j].w = dm;
+            }
+            b = fmaxf(b, v[j].w);
+            if (first) {
+                lx = fminf(lx, ok ? v[j].x : 3.4e38f); hx = fmaxf(hx, ok ? v[j].x : -3.4e38f);
+                ly = fminf(ly, ok ? v[j].y : 3.4e38f); hy = fmaxf(hy, ok ? v[j].y : -3.4e38f);
+                lz = fminf(lz, ok ? v[j].z : 3.4e38f); hz = fmaxf(hz, ok ? v[j].z : -3.4e38f);
+            }
+        }
+        const float vw = wave_max_f32(b);
+        int cnt = 0, sl = 0;
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+#pragma unroll
+        for (int j = 7; j >= 0; --j) {
+            const bool eq = v[j].w == vw;
+            cnt += eq ? 1 : 0;
+            sl = eq ? j : sl;
+            cx = eq ? v[j].x : cx; cy = eq ? v[j].y : cy; cz = eq ? v[j].z : cz;
+        }
+        const unsigned long long cand = __ballot(cnt > 0);
+        const int wl = (int)__builtin_ctzll(cand);
+        const int tie = (__popcll(cand) != 1 || __builtin_amdgcn_readlane(cnt, wl) != 1) ? 1 : 0;
+        const int spos = base + __builtin_amdgcn_readlane(sl, wl) * 64 + wl;
+        const float wx = readlane_f32(cx, wl), wy = readlane_f32(cy, wl), wz = readlane_f32(cz, wl);
+        if (first) {
+            lx = -wave_max_f32(-lx); ly = -wave_max_f32(-ly); lz = -wave_max_f32(-lz);
+            hx = wave_max_f32(hx); hy = wave_max_f32(hy); hz = wave_max_f32(hz);
+        }
+        if (lane == g) {
+            gm = vw; gtie = tie; gpos = spos; gx = wx; gy = wy; gz = wz;
+            if (first) { blx = lx; bly = ly; blz = lz; bhx = hx; bhy = hy; bhz = hz; }
+        }
+    };
+    for (int g = 0; g < ngw; ++g) sweep_group(g, 0.f, 0.f, 0.f, true);
+
+    float x1 = pts[0], y1 = pts[1], z1 = pts[2];  // old = 0
+    if (tid == 0) out[0] = 0;
+    for (int it = 1; it < m; ++it) {
+        const int buf = it & 1;
+        // ---- 1. groups the new sample can affect (box test, one lane per group) ------------------------------
+        const float ex = fmaxf(fmaxf(blx - x1, x1 - bhx), 0.f), ey = fmaxf(fmaxf(bly - y1, y1 - bhy), 0.f),
+                    ez = fmaxf(fmaxf(blz - z1, z1 - bhz), 0.f);
+        const float d2box = (ex * ex + ey * ey) + ez * ez;
+        unsigned sweep = (unsigned)__ballot(lane < ngw && !(d2box * 0.99999f > gm));
+        while (sweep) {
+            const int g = (int)__builtin_ctz(sweep);
+            sweep &= sweep - 1;
+            sweep_group(g, x1, y1, z1, false);
+        }
+        // ---- 2. wave arg-max over its groups' states -----------------------------------------------------------
+        const float val = lane < ngw ? gm : -3.f;
+        const float vw = wave_max_f32(val);
+        const unsigned long long cand = __ballot(val == vw);
+        const int wl = (int)__builtin_ctzll(cand);
+        const bool amb_w = __popcll(cand) != 1 || __builtin_amdgcn_readlane(gtie, wl) != 0;
+        if (lane == 0) {
+            FpsRecord r;
+            r.v = vw; r.amb = amb_w ? 1 : 0; r.spos = __builtin_amdgcn_readlane(gpos, wl); r.pad = 0;
+            r.x = readlane_f32(gx, wl); r.y = readlane_f32(gy, wl); r.z = readlane_f32(gz, wl); r.pad2 = 0.f;
+            s_rec[buf][wave] = r;
+        }
+        lds_barrier();
+        // ---- 3. workgroup arg-max over the 16 wave records ------------------------------------------------------
+        float rv = -3.f, rx = 0.f, ry = 0.f, rz = 0.f;
+        int ra = 0, rs = 0;
+        if (lane < 16) {
+            const FpsRecord r = s_rec[buf][lane];
+            rv = r.v; ra = r.amb; rs = r.spos; rx = r.x; ry = r.y; rz = r.z;
+        }
+        const float vb = readlane_f32(row_max_f32(rv), 0);
+        const unsigned long long candw = __ballot(lane < 16 && rv == vb);
+        const bool amb_b = __popcll(candw) != 1 || __ballot(lane < 16 && rv == vb && ra != 0) != 0;
+        if (!amb_b) {
+            const int ww = (int)__builtin_ctzll(candw);
+            x1 = readlane_f32(rx, ww);
+            y1 = readlane_f32(ry, ww);
+            z1 = readlane_f32(rz, ww);
+            if (tid == 0) out[it] = -1 - __builtin_amdgcn_readlane(rs, ww);
+        } else {
+            // ---- slow path: the maximum is attained by several points -> the reference's key order ------------
+            // (the running minima this wave just stored are visible to its own loads; groups belong to one wave)
+            unsigned mykey = 0xffffffffu;
+            for (int g = 0; g < ngw; ++g) {
+                if (__builtin_amdgcn_readlane(__float_as_int(gm), g) != __float_as_int(vb)) continue;  // wave-uniform
+                const int base = (wave + 16 * g) * FPS_L2_GROUP;
+                for (int j = 0; j < 8; ++j) {
+                    const int s0 = base + j * 64 + lane;
+                    if (s0 < n && sp[s0].w == vb) mykey = min(mykey, fps_key(perm[s0], log2rb));
+                }
+            }
+            for (int s0 = 32; s0 >= 1; s0 >>= 1) mykey = min(mykey, (unsigned)__shfl_xor((int)mykey, s0, 64));
+            if (lane == 0) s_key[buf][wave] = mykey;
+            lds_barrier();
+            unsigned kk = 0xffffffffu;
+            for (int w = 0; w < 16; ++w) kk = min(kk, s_key[buf][w]);
+            const int old = fps_unkey(kk, log2rb);
+            x1 = uniform_f32(pts[(size_t)old * 3 + 0]);
+            y1 = uniform_f32(pts[(size_t)old * 3 + 1]);
+            z1 = uniform_f32(pts[(size_t)old * 3 + 2]);
+            if (tid == 0) out[it] = old;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < m; i += 1024) {
+        const int v = out[i];
+        if (v < 0) out[i] = perm[-1 - v];
+    }
+    if (temp)
+        for (int s0 = tid; s0 < n; s0 += 1024) temp[(size_t)blockIdx.x * n + perm[s0]] = sp[s0].w;
+}
+
 // Large clouds (more than 24 points per thread): the reference's structure, running minimum in global
 // memory, thread t owns k = t, t+1024, ...  Not on the benchmark path (n <= 24576 there); kept so the
 // entry point has no size limit.
@@ -580,7 +756,10 @@ using namespace amc;
 
 AMC_API size_t amc3d_fps_workspace_bytes(int b, int n)
 {
-    return (size_t)(b > 0 ? b : 0) * (size_t)(n > 0 ? n : 0) * sizeof(int);
+    // permutation (int per point) for the register-resident kernels; clouds above 24576 points also keep their
+    // sorted float4 copy there
+    const size_t pts = (size_t)(b > 0 ? b : 0) * (size_t)(n > 0 ? n : 0);
+    return ((pts * sizeof(int) + 15) & ~(size_t)15) + (n > 24576 ? pts * sizeof(float4) : 0);
 }
 
 AMC_API int amc3d_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp, int *idxs,
@@ -592,9 +771,18 @@ AMC_API int amc3d_furthest_point_sampling(int b, int n, int m, const float *data
     // cuda_utils.h:10-14: largest power of two <= n, capped at 1024 (defines the tie order)
     int log2rb = 0;
     while ((2 << log2rb) <= n && log2rb < 10) ++log2rb;
-    if (n > 24576) {
-        if (!temp) return bad_arg("amc3d_furthest_point_sampling: n > 24576 needs the temp buffer");
+    if (n > FPS_L2_MAX) {
+        if (!temp) return bad_arg("amc3d_furthest_point_sampling: n > 262144 needs the temp buffer");
         hipLaunchKernelGGL(fps_kernel_large, dim3(b), dim3(1024), 0, stream, n, m, dataset, temp, idxs);
+        return launch_status("amc3d_furthest_point_sampling");
+    }
+    if (n > 24576) {
+        if (!workspace || workspace_bytes < amc3d_fps_workspace_bytes(b, n))
+            return bad_arg("amc3d_furthest_point_sampling: workspace too small (amc3d_fps_workspace_bytes)");
+        int *perm_l2 = (int *)workspace;
+        float4 *sorted_l2 = (float4 *)((char *)workspace + (((size_t)b * n * sizeof(int) + 15) & ~(size_t)15));
+        hipLaunchKernelGGL(fps_kernel_l2, dim3(b), dim3(1024), 0, stream, n, m, log2rb, dataset, temp, idxs, perm_l2,
+                           sorted_l2);
         return launch_status("amc3d_furthest_point_sampling");
     }
     if (!workspace || workspace_bytes < amc3d_fps_workspace_bytes(b, n))

@@ -141,16 +141,18 @@ class FurthestPointSampling(Function):
         _need_gpu(xyz)
         B, N, _ = xyz.size()
         output = torch.empty(B, npoint, dtype=torch.int32, device=xyz.device)
-        # the reference's (B,N) scratch of running minima (filled with 1e10) stays on chip
-        # for N <= 24576; larger clouds get the buffer
+        # the reference's (B,N) scratch of running minima (filled with 1e10) lives in registers (N <= 24576) or in
+        # the workspace (N <= 262144); only larger clouds need the buffer itself
         temp = None
-        if N > 24576:
+        if N > 262144:
             temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
+        lib = _lib.load()
+        wb = int(lib.amc3d_fps_workspace_bytes(B, N))
         with torch.cuda.device(xyz.device), timing.span("furthest_point_sampling", B * N * 12 + B * int(npoint) * 4):
-            work = torch.empty(B * N, dtype=torch.int32, device=xyz.device)
+            work = torch.empty(max(wb, 4), dtype=torch.uint8, device=xyz.device)
             _lib.check(_lib.load().amc3d_furthest_point_sampling(B, N, int(npoint), _ptr(xyz),
                                                                  _ptr(temp) if temp is not None else None,
-                                                                 _ptr(output), _ptr(work), work.numel() * 4,
+                                                                 _ptr(output), _ptr(work), wb,
                                                                  _stream(xyz)), "furthest_point_sampling")
         ctx.mark_non_differentiable(output)
         return output

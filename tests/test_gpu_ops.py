@@ -111,7 +111,10 @@ def test_fps_golden(dev, ops_fix, tag):
     # every points-per-thread bracket of the register kernel, tie-heavy clouds included (slow path)
     (2, 24000, 1500, "dup"), (1, 13000, 500, "room"), (1, 12288, 300, "lattice"), (1, 7000, 700, "dup"),
     (2, 3100, 400, "uniform"), (1, 1600, 1600, "lattice"), (3, 600, 150, "dup"), (1, 65, 65, "uniform"),
-    (1, 64, 64, "lattice"), (2, 1537, 200, "room"), (1, 24576, 200, "uniform")])
+    (1, 64, 64, "lattice"), (2, 1537, 200, "room"), (1, 24576, 200, "uniform"),
+    # above 24576 points per cloud: the L2-resident pruned kernel (ScanNet-sized batches of the MM configs)
+    (2, 64000, 1000, "room"), (1, 30000, 800, "dup"), (1, 50000, 400, "lattice"), (1, 120000, 300, "room"),
+    (1, 24577, 24577, "uniform")])
 def test_fps_vs_oracle(dev, B, N, M, kind):
     from amcontrast3d_amd import ops
     from oracle import pointops_ref as K
