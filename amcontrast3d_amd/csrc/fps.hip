@@ -29,8 +29,6 @@
 // RB = opt_n_threads(n).  The sorted layout here has nothing to do with k, so whenever the maximum is
 // attained by more than one point (detected per lane, per wave and per workgroup) the iteration takes
 // a slow path that evaluates exactly that key order over all tied points.
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace amc {
@@ -795,11 +793,6 @@ AMC_API int amc3d_furthest_point_sampling(int b, int n, int m, const float *data
         while (w < 8 && w * 64 * ppt < n) w <<= 1;
         return w;
     };
-    static const int variant = getenv("AMC3D_FPS_VARIANT") ? atoi(getenv("AMC3D_FPS_VARIANT")) : 0;
-    if (n > 12288 && variant == 2) return launch_fps<48, 12, 512, true>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
-    if (n > 12288 && variant == 3) return launch_fps<48, 8, 512, true>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
-    if (n > 12288 && variant == 4) return launch_fps<48, 6, 512, true>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
-    if (n > 12288 && variant == 5) return launch_fps<48, 6>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
     if (n > 12288) return launch_fps<48, 6, 512, true>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
     if (n > 6144) return launch_fps<24, 3, 512, true>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);
     if (n > 3072) return launch_fps<12, 3, 512, true>(b, n, m, 8, log2rb, dataset, temp, idxs, perm, stream);

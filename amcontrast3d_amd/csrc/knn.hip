@@ -142,9 +142,11 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_exact_kernel(
 // reference's heap.  Distances are always the reference's expression (dist2_ref).
 //
 // Cell size.  h is calibrated on the data, per call: 64 sample queries get an estimate of their k-th
-// neighbour distance from a brute-force scan of every 8th support point (one workgroup each), and
-// h = 1.1 * the 80th percentile, so that most queries finish after the 3x3x3 block whatever the
-// density or dimensionality of the cloud (surfaces, volumes, 8 overlapping clouds in one segment...).
+// neighbour distance from a brute-force scan of every 4th support point (one workgroup each), and
+// h = 0.7 * the 80th percentile, so that the 3x3x3 block holds a few k candidates whatever the density or
+// dimensionality of the cloud (surfaces, volumes, 8 overlapping clouds in one segment...); queries whose k-th
+// neighbour lies beyond the block go on to the next shell.  (Sub-sampling step and scale: swept on the loss's
+// seven searches with scratch/knn_sweep.sh, see amc3d_knnquery.)
 // h steers speed only; any h gives the same results.
 // =============================================================================================
 constexpr int KG_SAMPLES = 64;
@@ -1157,9 +1159,9 @@ int three_nn_grid(int b, int n, int m, const float *unknown, const float *known,
     char *base = (char *)workspace;
     int *off_s = (int *)(base + 768), *off_q = (int *)(base + 6400);
     hipLaunchKernelGGL(kg_uniform_offsets_kernel, dim3(1), dim3(64), 0, stream, b, m, n, off_s, off_q);
-    static const float nn3_scale = getenv("AMC3D_NN3_SCALE") ? (float)atof(getenv("AMC3D_NN3_SCALE")) : 1.0f;
-    static const int nn3_k = getenv("AMC3D_NN3_K") ? atoi(getenv("AMC3D_NN3_K")) : 2;
-    if (int st = kg_build(w, base, b * m, b * n, b, known, unknown, off_s, off_q, nn3_k, 2, nn3_scale, 0.f, stream)) return st;
+    // cell edge = p80 of the 2nd-neighbour distance among every 2nd known point (~ the 4th neighbour): swept in
+    // scratch/nn3_bench.py, 1.0 x that is the fastest
+    if (int st = kg_build(w, base, b * m, b * n, b, known, unknown, off_s, off_q, 2, 2, 1.0f, 0.f, stream)) return st;
     hipLaunchKernelGGL(nn3_grid_kernel, dim3(min(div_up((long)b * n, 4), 256 * 32)), dim3(256), 0, stream, b * n, n, m,
                        unknown, (const GridParams *)(base + w.params), (const int *)(base + w.cell_start),
                        (const float4 *)(base + w.sorted), dist2, idx);
@@ -1196,9 +1198,11 @@ AMC_API int amc3d_knnquery(int m, int nsample, int n, int nbatch, const float *x
     const KnnWorkspace w = knn_layout(n, m);
     if (!workspace || workspace_bytes < w.total) return bad_arg("amc3d_knnquery: workspace too small");
     char *base = (char *)workspace;
-    static const int kg_sub = getenv("AMC3D_KG_SUB") ? atoi(getenv("AMC3D_KG_SUB")) : 8;
-    static const int kg_extra = getenv("AMC3D_KG_EXTRA") ? atoi(getenv("AMC3D_KG_EXTRA")) : 1;
-    static const float kg_scale = getenv("AMC3D_KG_SCALE") ? (float)atof(getenv("AMC3D_KG_SCALE")) : 1.1f;
+    // cell edge = scale x p80 of the ceil(k/sub)-th neighbour distance among every sub-th support point; swept on
+    // the loss's seven searches (scratch/knn_sweep.sh): speed only, any value gives the same results
+    static const int kg_sub = getenv("AMC3D_KG_SUB") ? atoi(getenv("AMC3D_KG_SUB")) : 4;
+    static const int kg_extra = getenv("AMC3D_KG_EXTRA") ? atoi(getenv("AMC3D_KG_EXTRA")) : 0;
+    static const float kg_scale = getenv("AMC3D_KG_SCALE") ? (float)atof(getenv("AMC3D_KG_SCALE")) : 0.7f;
     if (reuse_grid) {
         // the workspace still holds the grid of this very support set (xyz, offset) from an earlier call: its cell
         // size was calibrated for that call's k, which only steers speed.  Only the replay counter is reset.
