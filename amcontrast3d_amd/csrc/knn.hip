@@ -1178,6 +1178,13 @@ AMC_API size_t amc3d_knnquery_workspace_bytes(int n, int m, int nsample, int nba
     return knn_layout(n > 0 ? n : 1, m > 0 ? m : 1).total;
 }
 
+// 1 when amc3d_knnquery builds (or, with reuse_grid, expects) the cell grid for this problem size, 0 when it
+// answers with the all-pairs heap kernel and leaves the workspace untouched
+AMC_API int amc3d_knnquery_uses_grid(int m, int nsample, int n, int nbatch)
+{
+    return (nsample <= KG_MAXK && (long)n * m >= (1L << 22) && n >= 4 * KG_SAMPLES && nbatch <= 64) ? 1 : 0;
+}
+
 AMC_API int amc3d_knnquery(int m, int nsample, int n, int nbatch, const float *xyz, const float *new_xyz,
                            const int *offset, const int *new_offset, int *idx, float *dist2, void *workspace,
                            size_t workspace_bytes, int reuse_grid, void *stream_)
@@ -1189,7 +1196,7 @@ AMC_API int amc3d_knnquery(int m, int nsample, int n, int nbatch, const float *x
     hipStream_t stream = (hipStream_t)stream_;
     const int exact_blocks = min(div_up(m, KNN_WAVES), 256 * 8);
     // small problems and k > 64: the heap replay alone (it is exact for every input)
-    const bool grid = nsample <= KG_MAXK && (long)n * m >= (1L << 22) && n >= 4 * KG_SAMPLES && nbatch <= 64;
+    const bool grid = amc3d_knnquery_uses_grid(m, nsample, n, nbatch) != 0;
     if (!grid) {
         hipLaunchKernelGGL(knn_exact_kernel, dim3(exact_blocks), dim3(KNN_WAVES * 64), 0, stream, m, nsample, nbatch,
                            xyz, new_xyz, offset, new_offset, idx, dist2, (const int *)nullptr, (const int *)nullptr);

@@ -276,9 +276,10 @@ class KNNQuery(Function):
         # inside `with knn_grid_reuse():` searches over the same support set share one cell grid
         key = (xyz.data_ptr(), n, offset.data_ptr(), nb, _stream(xyz).value)
         cached = _grid_cache.get(key) if _grid_cache is not None else None
-        reuse = cached is not None and cached.numel() >= wbytes and nsample <= 64
+        gridded = bool(lib.amc3d_knnquery_uses_grid(m, nsample, n, nb))  # else: all-pairs kernel, no grid in `work`
+        reuse = gridded and cached is not None and cached.numel() >= wbytes
         work = cached if reuse else torch.empty(wbytes, dtype=torch.uint8, device=xyz.device)
-        if _grid_cache is not None and not reuse and nsample <= 64:
+        if _grid_cache is not None and gridded and not reuse:
             _grid_cache[key] = work
         with torch.cuda.device(xyz.device), timing.span("knnquery", (n + m) * 12 + m * nsample * 8):
             _lib.check(lib.amc3d_knnquery(m, nsample, n, nb, _ptr(xyz), _ptr(new_xyz), _ptr(offset),

@@ -127,6 +127,9 @@ int amc3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_o
  * nbatch) and at least as many queries; its cell grid is kept and only the queries run (the loss asks for
  * four neighbour sets of the full-resolution cloud per step).  Results are identical either way. */
 size_t amc3d_knnquery_workspace_bytes(int n, int m, int nsample, int nbatch);
+/* 1: this problem size goes through the cell grid (so a later call may pass reuse_grid, and this call may reuse an
+ * earlier grid); 0: the all-pairs heap kernel answers and the workspace is left untouched */
+int amc3d_knnquery_uses_grid(int m, int nsample, int n, int nbatch);
 int amc3d_knnquery(int m, int nsample, int n, int nbatch, const float *xyz, const float *new_xyz,
                    const int *offset, const int *new_offset, int *idx, float *dist2,
                    void *workspace, size_t workspace_bytes, int reuse_grid, void *stream);

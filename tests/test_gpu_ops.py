@@ -310,3 +310,25 @@ def test_cpu_tensors_are_rejected_loudly(dev):
         p = torch.rand(10, 3, device=dev)
         o = torch.tensor([10], dtype=torch.int32, device=dev)
         ops.knnquery(101, p, p, o, o)
+
+
+def test_knn_grid_reuse_gives_the_same_lists(dev):
+    """Searches over one support cloud inside `knn_grid_reuse()` share the first call's cell grid (calibrated for
+    that call's k): results must equal independent calls, also when the first call was too small to build a grid."""
+    from amcontrast3d_amd import ops
+    xyz = torch.from_numpy(clouds(21, 1, 30000, "room")[0]).to(dev)
+    o = torch.tensor([xyz.shape[0]], dtype=torch.int32, device=dev)
+    queries = [(24, xyz, o), (4, xyz[::4].contiguous(), None), (64, xyz[::64].contiguous(), None),
+               (16, xyz[:50].contiguous(), None)]  # the last one: 50 x 30000 pairs -> all-pairs kernel
+    def run(k, q, qo):
+        qo = qo if qo is not None else torch.tensor([q.shape[0]], dtype=torch.int32, device=dev)
+        idx, dist = ops.knnquery(k, xyz, q, o, qo)
+        return idx.clone(), dist.clone()
+    alone = [run(*a) for a in queries]
+    for order in (queries, queries[::-1]):  # reversed: the small all-pairs call comes first and must not be "reused"
+        with ops.knn_grid_reuse():
+            shared = [run(*a) for a in order]
+        if order is not queries:
+            shared = shared[::-1]
+        for (i0, d0), (i1, d1) in zip(alone, shared):
+            assert torch.equal(i0, i1) and torch.equal(d0, d1)
