@@ -146,6 +146,9 @@ def run_convblocks(blocks, x, pool_max=False, pre=None):
     from amcontrast3d_amd.ops import BatchNormAct, BatchNormMax
     mods = list(blocks)
     pooled = False
+    fused = _sa_tail(mods, pool_max, pre)
+    if fused is not None:
+        return fused
     for bi, blk in enumerate(mods):
         last = bi == len(mods) - 1
         sub = list(blk) if isinstance(blk, nn.Sequential) else None
@@ -177,6 +180,30 @@ def run_convblocks(blocks, x, pool_max=False, pre=None):
     if pool_max and not pooled:
         x = torch.max(x, dim=-1, keepdim=False)[0]
     return x
+
+
+def _sa_tail(mods, pool_max, pre):
+    """[conv0 (already applied: `pre`), BN, ReLU] -> [1x1 conv, BN (, ReLU)] -> max over 32 neighbours as one recomputing
+    kernel family (csrc/sa_tail.hip), or None when the stack is not of that form."""
+    import os
+    if pre is None or not pool_max or len(mods) != 2 or os.environ.get("AMC3D_NO_SA_TAIL"):
+        return None
+    s0 = list(mods[0]) if isinstance(mods[0], nn.Sequential) else None
+    s1 = list(mods[1]) if isinstance(mods[1], nn.Sequential) else None
+    if (s0 is None or s1 is None or len(s0) != 3 or type(s0[2]) is not nn.ReLU or len(s1) not in (2, 3)
+            or (len(s1) == 3 and type(s1[2]) is not nn.ReLU) or not isinstance(s1[0], nn.Conv2d)):
+        return None
+    bn1, conv2, bn2 = s0[1], s1[0], s1[1]
+    if (pre.dim() != 4 or not _fusable_bn(bn1, pre) or not _fusable_bn(bn2, pre) or conv2.bias is not None
+            or conv2.kernel_size != (1, 1) or conv2.stride != (1, 1) or conv2.groups != 1
+            or any(v != 0 for v in conv2.padding) or conv2.in_channels != pre.shape[1]):
+        return None
+    from amcontrast3d_amd import ops
+    if not (ops.sa_tail_supported(pre.shape[1], conv2.out_channels, pre.shape[-1])
+            and ops.sa_tail_pays(pre.shape[1], conv2.out_channels)):
+        return None
+    return ops.SATail.apply(pre, bn1.weight, bn1.bias, bn1.eps, conv2.weight, bn2.weight, bn2.bias, bn2.eps,
+                            len(s1) == 3, bn1, bn2)
 
 
 def fused_first_conv(blocks, f, geom, feature_type):

@@ -672,3 +672,82 @@ class CrossEntropyMean(Function):
 
 def cross_entropy_mean(logits, target, ignore_index=-100):
     return CrossEntropyMean.apply(logits, target, ignore_index)
+
+
+class SATail(Function):
+    """pooled (B,C2,M) = max_k [relu2](bn2(conv2(relu(bn1(y1)))))  -- the tail of a two-layer SetAbstraction block
+    (pointnext_AA.py:104-127, 164-166) from the first conv's raw output y1 (B,C1,M,32), with batch statistics for both
+    BatchNorms, without materialising any (B,C,M,32) tensor after y1 (csrc/sa_tail.hip re-creates them per tile).
+    `bn1`, `bn2`: the nn.BatchNorm2d modules whose running buffers are updated (or None)."""
+
+    @staticmethod
+    def forward(ctx, y1, g1, b1, eps1, w2, g2, b2, eps2, relu2, bn1=None, bn2=None):
+        _need_gpu(y1, g1, b1, w2, g2, b2)
+        y1 = y1.contiguous()
+        B, C1, M, K = y1.shape
+        C2 = w2.shape[0]
+        dev = y1.device
+        lib = _lib.load()
+        assert w2.numel() == C2 * C1 and lib.amc3d_sa_tail_supported(C1, C2, K)
+        w2f = w2.reshape(C2, C1).contiguous()
+        mean1 = torch.empty(C1, dtype=torch.float32, device=dev)
+        invstd1, var1 = torch.empty_like(mean1), torch.empty_like(mean1)
+        mean2 = torch.empty(C2, dtype=torch.float32, device=dev)
+        invstd2, var2 = torch.empty_like(mean2), torch.empty_like(mean2)
+        pooled = torch.empty(B, C2, M, dtype=torch.float32, device=dev)
+        arg = torch.empty(B, C2, M, dtype=torch.uint8, device=dev)
+        work1, wb1 = _bn_ws(C1, dev)
+        wb = int(lib.amc3d_sa_tail_workspace_bytes(B, C1, C2, M))
+        work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
+        mom2, rm2, rv2, nbt2 = _bn_running_args(bn2)
+        flops = 2.0 * B * M * K * C1 * C2 * 2  # the 1x1 conv is evaluated twice (statistics pass, max pass)
+        with torch.cuda.device(dev), timing.span("sa_tail_forward", y1.numel() * 4 * 3 + pooled.numel() * 5, flops):
+            _lib.check(lib.amc3d_bn_stats(B, C1, M * K, float(eps1), _ptr(y1), _ptr(mean1), _ptr(invstd1), _ptr(var1),
+                                          _ptr(work1), wb1, _stream(y1)), "bn_stats")
+            _lib.check(lib.amc3d_sa_tail_forward(B, C1, C2, M, K, _ptr(y1), _ptr(mean1), _ptr(invstd1), _ptr(g1), _ptr(b1),
+                                                 _ptr(w2f), _ptr(g2), _ptr(b2), float(eps2), mom2, int(bool(relu2)),
+                                                 _ptr(pooled), _ptr(arg), _ptr(mean2), _ptr(invstd2), _ptr(var2), rm2, rv2,
+                                                 nbt2, _ptr(work), wb, _stream(y1)), "sa_tail_forward")
+        if bn1 is not None and bn1.track_running_stats and bn1.running_mean is not None:
+            bn_update_running(bn1, mean1, var1)
+        if bn2 is not None and bn2.track_running_stats and bn2.running_mean is not None and bn2.momentum is None:
+            bn_update_running(bn2, mean2, var2)  # cumulative average: its own launch
+        ctx.save_for_backward(y1, g1, b1, w2f, g2, b2, mean1, invstd1, mean2, invstd2, arg)
+        ctx.relu2, ctx.wshape = bool(relu2), tuple(w2.shape)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        y1, g1, b1, w2f, g2, b2, mean1, invstd1, mean2, invstd2, arg = ctx.saved_tensors
+        B, C1, M, K = y1.shape
+        C2 = w2f.shape[0]
+        dev = y1.device
+        dpooled = dpooled.contiguous()
+        lib = _lib.load()
+        dx1 = torch.empty_like(y1)
+        dw2 = torch.empty(C2, C1, dtype=torch.float32, device=dev)
+        dg2, db2 = torch.empty_like(g2), torch.empty_like(b2)
+        wb = int(lib.amc3d_sa_tail_workspace_bytes(B, C1, C2, M))
+        work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
+        dy1 = torch.empty_like(y1)
+        dg1, db1 = torch.empty_like(g1), torch.empty_like(b1)
+        work1, wb1 = _bn_ws(C1, dev, extra=C1 * 8)
+        flops = 2.0 * B * M * K * C1 * C2 * 4  # recompute twice + dx1 + dW2
+        with torch.cuda.device(dev), timing.span("sa_tail_backward", y1.numel() * 4 * 6 + dpooled.numel() * 10, flops):
+            _lib.check(lib.amc3d_sa_tail_backward(B, C1, C2, M, K, _ptr(y1), _ptr(mean1), _ptr(invstd1), _ptr(g1), _ptr(b1),
+                                                  _ptr(w2f), _ptr(mean2), _ptr(invstd2), _ptr(g2), _ptr(b2), int(ctx.relu2),
+                                                  _ptr(dpooled), _ptr(arg), _ptr(dx1), _ptr(dw2), _ptr(dg2), _ptr(db2),
+                                                  _ptr(work), wb, _stream(y1)), "sa_tail_backward")
+            # BN1 + ReLU backward on the raw y1 (csrc/bn.hip)
+            _lib.check(lib.amc3d_bn_backward(B, C1, M * K, 1, 1, _ptr(y1), _ptr(dx1), None, _ptr(mean1), _ptr(invstd1),
+                                             _ptr(g1), _ptr(b1), _ptr(dy1), _ptr(dg1), _ptr(db1), _ptr(work1), wb1,
+                                             _stream(y1)), "bn_backward")
+        return dy1, dg1, db1, None, dw2.view(ctx.wshape), dg2, db2, None, None, None, None
+
+
+def sa_tail_supported(c1, c2, k):
+    return bool(_lib.load().amc3d_sa_tail_supported(int(c1), int(c2), int(k)))
+
+
+def sa_tail_pays(c1, c2):
+    return bool(_lib.load().amc3d_sa_tail_pays(int(c1), int(c2)))
