@@ -17,6 +17,8 @@ _ll = ctypes.c_longlong
 SIGNATURES = {
     "amc3d_version": (ctypes.c_char_p, []),
     "amc3d_last_error": (ctypes.c_char_p, []),
+    "amc3d_stream_create_dedicated": (_i, [ctypes.POINTER(ctypes.c_void_p)]),
+    "amc3d_stream_destroy": (_i, [_vp]),
     "amc3d_grid_search_workspace_bytes": (_sz, [_i, _i, _i]),
     "amc3d_ball_query": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_group_points": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -61,6 +63,10 @@ SIGNATURES = {
     "amc3d_bn_act": (_i, [_i, _i, _l, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_bn_max": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_bn_backward": (_i, [_i, _i, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "amc3d_bn_sums": (_i, [_i, _i, _l, _vp, _vp, _vp, _sz, _vp]),
+    "amc3d_bn_forward_synced": (_i, [_i, _i, _l, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_bn_backward_sums": (_i, [_i, _i, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "amc3d_bn_backward_synced": (_i, [_i, _i, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 

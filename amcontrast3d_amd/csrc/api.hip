@@ -30,3 +30,35 @@ int fill_i32(int *p, int value, size_t count, hipStream_t stream)
 
 AMC_API const char *amc3d_version(void) { return "amc3d-hip gfx950 1"; }
 AMC_API const char *amc3d_last_error(void) { return amc::g_err; }
+
+// A HIP stream with a hardware queue of its own.  Ordinary streams of a process share at most four hardware queues
+// (round-robin, per priority): a long latency-bound kernel such as furthest point sampling (milliseconds on 8
+// workgroups) then stalls whatever stream happens to share its queue -- the training stream, a graph's internal
+// branch, RCCL -- and which one that is changes with every stream anybody creates.  Streams created with a CU mask get
+// a dedicated queue; the mask here enables every CU, so nothing else about the stream is special.
+AMC_API int amc3d_stream_create_dedicated(void **stream)
+{
+    if (!stream) return amc::bad_arg("amc3d_stream_create_dedicated: null pointer");
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess || cus <= 0) { amc::set_error("amc3d_stream_create_dedicated: %s", hipGetErrorString(e)); return (int)(e ? e : hipErrorUnknown); }
+    uint32_t mask[32];
+    const int words = (cus + 31) / 32;
+    if (words > 32) return amc::bad_arg("amc3d_stream_create_dedicated: more than 1024 CUs");
+    for (int i = 0; i < words; ++i) mask[i] = 0xffffffffu;
+    if (cus % 32) mask[words - 1] = (1u << (cus % 32)) - 1u;
+    hipStream_t s = nullptr;
+    e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
+    if (e != hipSuccess) { amc::set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e)); return (int)e; }
+    *stream = (void *)s;
+    return 0;
+}
+
+AMC_API int amc3d_stream_destroy(void *stream)
+{
+    if (!stream) return 0;
+    const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) { amc::set_error("hipStreamDestroy: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}

@@ -104,6 +104,7 @@ struct BnFused {
     const double *partial;
     int nchunks;
     double count;
+    const double *count_dev;  // set: the element count is read from device memory (cross-rank statistics)
     float eps, momentum;  // momentum < 0: no running update here (cumulative mode keeps its own launch)
     float *mean_out, *invstd_out, *var_out, *running_mean, *running_var;
     long long *tracked;
@@ -129,13 +130,14 @@ __device__ __forceinline__ void bn_channel_stats(const BnFused &f, int c, bool w
         double s1, s2;
         bn_partial_sums(f.partial, c, f.nchunks, s1, s2);
         if (threadIdx.x == 0) {
-            const double mu = s1 / f.count;
-            double var = s2 / f.count - mu * mu;
+            const double cnt = f.count_dev ? *f.count_dev : f.count;
+            const double mu = s1 / cnt;
+            double var = s2 / cnt - mu * mu;
             if (var < 0.0) var = 0.0;
             const float mf = (float)mu, isf = (float)(1.0 / sqrt(var + (double)f.eps));
             s_stat[0] = mf; s_stat[1] = isf;
             if (writer) {
-                const float vu = (float)(f.count > 1.0 ? var * f.count / (f.count - 1.0) : var);
+                const float vu = (float)(cnt > 1.0 ? var * cnt / (cnt - 1.0) : var);
                 f.mean_out[c] = mf; f.invstd_out[c] = isf; f.var_out[c] = vu;
                 if (f.running_mean && f.momentum >= 0.f) {  // running.mul_(1 - m).add_(batch, alpha=m)
                     f.running_mean[c] = f.running_mean[c] * (1.f - f.momentum) + f.momentum * mf;
@@ -315,7 +317,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
     int mode, int C, long L, int K, int relu, int vec, const float *__restrict__ x, const float *__restrict__ dy,
     const unsigned char *__restrict__ arg, const float *__restrict__ mean, const float *__restrict__ invstd,
     const float *__restrict__ gamma, const float *__restrict__ beta, const double *__restrict__ partial, int nchunks,
-    double count, float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dx)
+    double count, const double *__restrict__ count_dev, float *__restrict__ dgamma, float *__restrict__ dbeta,
+    float *__restrict__ dx)
 {
     const int bc = blockIdx.y;
     const int c = bc % C;
@@ -327,9 +330,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
         double sa, sb;
         bn_partial_sums(partial, c, nchunks, sa, sb);
         if (threadIdx.x == 0) {
-            s_co[0] = (float)(sa / count);
-            s_co[1] = (float)(sb / count);
-            if (blockIdx.x == 0 && bc < C) { dbeta[c] = (float)sa; dgamma[c] = (float)sb; }
+            const double cnt = count_dev ? *count_dev : count;
+            s_co[0] = (float)(sa / cnt);
+            s_co[1] = (float)(sb / cnt);
+            if (blockIdx.x == 0 && bc < C && dbeta) { dbeta[c] = (float)sa; dgamma[c] = (float)sb; }
         }
     }
     __syncthreads();
@@ -396,6 +400,21 @@ __global__ __launch_bounds__(1024) void bn_running_kernel(int C, float momentum,
     }
     __syncthreads();  // every thread has read the old counter
     if (threadIdx.x == 0) *tracked = nt;
+}
+
+// sums[c] = {first, second} partial sum of channel c added up over the chunks (one wave per channel): the rank-local
+// statistics a cross-rank BatchNorm exchanges.  With out_b/out_a set also stores them as floats (dbeta, dgamma).
+__global__ __launch_bounds__(64) void bn_reduce_partials_kernel(int nchunks, const double *__restrict__ partial,
+                                                                double *__restrict__ sums, float *__restrict__ out_a,
+                                                                float *__restrict__ out_b)
+{
+    const int c = blockIdx.x;
+    double s1, s2;
+    bn_partial_sums(partial, c, nchunks, s1, s2);
+    if (threadIdx.x == 0) {
+        sums[2 * c] = s1; sums[2 * c + 1] = s2;
+        if (out_a) { out_a[c] = (float)s1; out_b[c] = (float)s2; }
+    }
 }
 
 constexpr int BN_MAX_CHUNKS = 64;
@@ -551,7 +570,8 @@ AMC_API int amc3d_bn_backward(int B, int C, long L, int K, int relu, const float
     const long per_block = BN_THREADS * 16;
     const int gx = (int)min((L + per_block - 1) / per_block, (long)4096);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, stream, mode, C, L, K, relu, vec, x, dy, arg,
-                       mean, invstd, gamma, beta, (const double *)partial, nchunks, (double)B * (double)L, dgamma, dbeta, dx);
+                       mean, invstd, gamma, beta, (const double *)partial, nchunks, (double)B * (double)L,
+                       (const double *)nullptr, dgamma, dbeta, dx);
     return launch_status("amc3d_bn_backward");
 }
 
@@ -565,4 +585,107 @@ AMC_API int amc3d_bn_update_running(int C, float momentum, const float *mean, co
     hipLaunchKernelGGL(bn_running_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, C, momentum, mean, var_unbiased,
                        running_mean, running_var, num_batches_tracked);
     return launch_status("amc3d_bn_update_running");
+}
+
+// ---- BatchNorm with statistics over all ranks (torch.nn.SyncBatchNorm, which the reference converts every BN
+// layer to whenever world_size > 1: examples/segmentation/main_AA.py:146-148, 820).  The kernels are the ones above;
+// the per-channel sums leave the device function between the two launches so that the caller can all-reduce them:
+//     forward    amc3d_bn_sums -> all-reduce(sums[2C] ++ count) -> amc3d_bn_forward_synced
+//     backward   amc3d_bn_backward_sums -> all-reduce(dsums[2C]) -> amc3d_bn_backward_synced
+// Counts are read from device memory (sums_count[2C]), so ranks may hold different numbers of positions and the
+// sequence is capturable in a hipGraph.
+
+// sums (2C doubles): {sum x, sum x^2} of channel c over this rank's (B, L)
+AMC_API int amc3d_bn_sums(int B, int C, long L, const float *x, double *sums, void *workspace, size_t workspace_bytes,
+                          void *stream_)
+{
+    if (B <= 0 || C <= 0 || L <= 0) return 0;
+    if (!x || !sums || !workspace || workspace_bytes < amc3d_bn_workspace_bytes(C))
+        return bad_arg("amc3d_bn_sums: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const BnSplit sp = bn_split(B, C, L);
+    const int vec = (L % 4 == 0) && aligned16(x);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(sp.nchunks, C), dim3(BN_THREADS), 0, stream, B, C, L, sp, vec, x,
+                       (double *)workspace);
+    hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(C), dim3(64), 0, stream, sp.nchunks, (const double *)workspace, sums,
+                       (float *)nullptr, (float *)nullptr);
+    return launch_status("amc3d_bn_sums");
+}
+
+// second half of amc3d_bn_forward from global statistics: sums_count = 2C sums followed by the global element count
+AMC_API int amc3d_bn_forward_synced(int B, int C, long L, int K, int relu, float eps, float momentum, const float *x,
+                                    const double *sums_count, const float *gamma, const float *beta, float *y,
+                                    unsigned char *arg, float *mean, float *invstd, float *var_unbiased,
+                                    float *running_mean, float *running_var, long long *num_batches_tracked,
+                                    void *stream_)
+{
+    if (B <= 0 || C <= 0 || L <= 0) return 0;
+    if (!x || !sums_count || !gamma || !beta || !y || !mean || !invstd || !var_unbiased || K < 0 || K > 255 ||
+        (K > 0 && (!arg || L % K != 0)) || (running_mean && (!running_var || !num_batches_tracked)))
+        return bad_arg("amc3d_bn_forward_synced: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    BnFused f{};
+    f.partial = sums_count;
+    f.nchunks = 1;
+    f.count_dev = sums_count + 2 * (size_t)C;
+    f.eps = eps;
+    f.momentum = momentum;
+    f.mean_out = mean; f.invstd_out = invstd; f.var_out = var_unbiased;
+    f.running_mean = running_mean; f.running_var = running_var; f.tracked = num_batches_tracked;
+    int st;
+    if (K == 0) {
+        const long per_block = BN_THREADS * 4 * 4;
+        const int gx = (int)min((L + per_block - 1) / per_block, (long)4096);
+        hipLaunchKernelGGL(bn_act_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, stream, C, L, relu, x, mean, invstd, gamma,
+                           beta, y, f);
+        st = launch_status("amc3d_bn_forward_synced");
+    } else {
+        st = launch_bn_max(B, C, (int)(L / K), K, relu, x, mean, invstd, gamma, beta, y, arg, f, stream);
+    }
+    if (st) return st;
+    if (running_mean && momentum < 0.f)
+        hipLaunchKernelGGL(bn_running_kernel, dim3(1), dim3(1024), 0, stream, C, momentum, mean, var_unbiased, running_mean,
+                           running_var, num_batches_tracked);
+    return launch_status("amc3d_bn_forward_synced");
+}
+
+// dsums (2C doubles): {sum dq, sum dq * xhat} over this rank; dbeta / dgamma (C floats) = the same, rank-local
+// (torch's SyncBatchNorm leaves the parameter gradients local; the gradient all-reduce averages them)
+AMC_API int amc3d_bn_backward_sums(int B, int C, long L, int K, int relu, const float *x, const float *dy,
+                                   const unsigned char *arg, const float *mean, const float *invstd, const float *gamma,
+                                   const float *beta, double *dsums, float *dgamma, float *dbeta, void *workspace,
+                                   size_t workspace_bytes, void *stream_)
+{
+    if (B <= 0 || C <= 0 || L <= 0) return 0;
+    if (!x || !dy || !mean || !invstd || !gamma || !beta || !dsums || !dgamma || !dbeta || !workspace ||
+        workspace_bytes < amc3d_bn_workspace_bytes(C) || K <= 0 || (arg && L % K != 0))
+        return bad_arg("amc3d_bn_backward_sums: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int mode = arg ? 1 : 0;
+    const BnSplit sp = bn_split(B, C, mode ? L / K : L);
+    const int vec = (L % 4 == 0) && (K % 4 == 0 || !mode) && aligned16(x) && aligned16(dy) && L < (1L << 31);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(sp.nchunks, C), dim3(BN_THREADS), 0, stream, mode, B, C, L, K, relu, sp, vec,
+                       x, dy, arg, mean, invstd, gamma, beta, (double *)workspace);
+    hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(C), dim3(64), 0, stream, sp.nchunks, (const double *)workspace, dsums,
+                       dbeta, dgamma);
+    return launch_status("amc3d_bn_backward_sums");
+}
+
+// dx from the global {sum dq, sum dq * xhat} (dsums, 2C) and the global element count (*count, device memory)
+AMC_API int amc3d_bn_backward_synced(int B, int C, long L, int K, int relu, const float *x, const float *dy,
+                                     const unsigned char *arg, const float *mean, const float *invstd,
+                                     const float *gamma, const float *beta, const double *dsums, const double *count,
+                                     float *dx, void *stream_)
+{
+    if (B <= 0 || C <= 0 || L <= 0) return 0;
+    if (!x || !dy || !mean || !invstd || !gamma || !beta || !dsums || !count || !dx || K <= 0 || (arg && L % K != 0))
+        return bad_arg("amc3d_bn_backward_synced: bad argument");
+    const int mode = arg ? 1 : 0;
+    const int vec = (L % 4 == 0) && (K % 4 == 0 || !mode) && aligned16(x) && aligned16(dy) && aligned16(dx) && L < (1L << 31);
+    const long per_block = BN_THREADS * 16;
+    const int gx = (int)min((L + per_block - 1) / per_block, (long)4096);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, (hipStream_t)stream_, mode, C, L, K, relu,
+                       vec, x, dy, arg, mean, invstd, gamma, beta, dsums, 1, 0.0, count, (float *)nullptr, (float *)nullptr,
+                       dx);
+    return launch_status("amc3d_bn_backward_synced");
 }

@@ -55,7 +55,7 @@ __device__ __forceinline__ float sat_bn(float x, float mean, float invstd, float
     return __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(x, mean), invstd), gamma), beta);
 }
 
-template <int NCT, int MODE>
+template <int NCT, int MODE, int NIT>  // NIT: 32-channel tiles of C1 (used by the weight gradient of mode 3)
 __global__ __launch_bounds__(256) void sat_kernel(SatArgs a)
 {
     extern __shared__ float sat_smem[];
@@ -90,7 +90,6 @@ __global__ __launch_bounds__(256) void sat_kernel(SatArgs a)
     double acc_a[NCT], acc_b[NCT];  // modes 0 / 2: running sums of this lane's channels
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) { acc_a[ct] = 0.0; acc_b[ct] = 0.0; }
-    constexpr int NIT = 2;           // C1 tiles of 32 (C1 <= 64)
     sat_f32x16 accw[MODE == 3 ? NCT : 1][MODE == 3 ? NIT : 1];
     if (MODE == 3) {
 #pragma unroll
@@ -343,10 +342,14 @@ static void sat_launch(const SatArgs &a, int groups, hipStream_t stream)
 {
     const size_t lds = sat_lds(a.C1, a.C2, MODE);
     const int nct = (a.C2 + 31) / 32;
-#define AMC_SAT(N)                                                                                                          \
-    (void)hipFuncSetAttribute((const void *)sat_kernel<N, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
-    hipLaunchKernelGGL((sat_kernel<N, MODE>), dim3(groups, a.B), dim3(256), lds, stream, a)
-    if (nct == 1) { AMC_SAT(1); } else if (nct == 2) { AMC_SAT(2); } else if (nct == 3) { AMC_SAT(3); } else { AMC_SAT(4); }
+#define AMC_SAT(N, I)                                                                                                         \
+    (void)hipFuncSetAttribute((const void *)sat_kernel<N, MODE, I>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+    hipLaunchKernelGGL((sat_kernel<N, MODE, I>), dim3(groups, a.B), dim3(256), lds, stream, a)
+    if (MODE == 3 && a.C1 > 32) {
+        if (nct == 1) { AMC_SAT(1, 2); } else if (nct == 2) { AMC_SAT(2, 2); } else if (nct == 3) { AMC_SAT(3, 2); } else { AMC_SAT(4, 2); }
+    } else {
+        if (nct == 1) { AMC_SAT(1, 1); } else if (nct == 2) { AMC_SAT(2, 1); } else if (nct == 3) { AMC_SAT(3, 1); } else { AMC_SAT(4, 1); }
+    }
 #undef AMC_SAT
 }
 

@@ -113,6 +113,21 @@ def _fusable_bn(bn, x):
             and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled())
 
 
+def _synced_bn_group(bn, x):
+    """process group of a training-mode nn.SyncBatchNorm whose statistics really span several ranks (then the fused
+    kernels exchange their per-channel sums: ops.SyncBatchNormFused), else None"""
+    import torch.distributed as dist
+    if not (type(bn) is nn.SyncBatchNorm and bn.training and bn.affine and bn.track_running_stats and x.is_cuda
+            and x.dtype == torch.float32 and not torch.is_autocast_enabled() and dist.is_available()
+            and dist.is_initialized()):
+        return None
+    group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    return group if dist.get_world_size(group) > 1 or _FORCE_SYNCED_BN else None
+
+
+_FORCE_SYNCED_BN = False  # tests: take the cross-rank path in a one-rank group too
+
+
 def conv1x1(conv, x):
     """conv(x); a plain 1x1 convolution on a contiguous fp32 GPU tensor runs on the MFMA kernels of
     csrc/pwconv.hip (same parameters, same autograd contract), anything else on the stored torch module."""
@@ -143,7 +158,7 @@ def run_convblocks(blocks, x, pool_max=False, pre=None):
     fused gfx950 kernels (amcontrast3d_amd/csrc/bn.hip); everything else runs the stored modules as they are.
     Parameters, buffers and their bookkeeping stay those of the nn modules.
     `pre`: the already computed output of the first block's convolution (the fused gather+conv kernel)."""
-    from amcontrast3d_amd.ops import BatchNormAct, BatchNormMax
+    from amcontrast3d_amd.ops import BatchNormAct, BatchNormMax, SyncBatchNormFused
     mods = list(blocks)
     pooled = False
     fused = _sa_tail(mods, pool_max, pre)
@@ -157,7 +172,12 @@ def run_convblocks(blocks, x, pool_max=False, pre=None):
                 and (len(sub) == 2 or type(sub[2]) is nn.ReLU)):
             y = pre if (bi == 0 and pre is not None) else conv1x1(sub[0], x)
             bn = sub[1]
-            if _fusable_bn(bn, y):
+            group = _synced_bn_group(bn, y)
+            if group is not None:
+                pool = last and pool_max and y.dim() == 4 and y.shape[-1] <= 255
+                x, _, _ = SyncBatchNormFused.apply(y, bn.weight, bn.bias, bn.eps, len(sub) == 3, pool, bn, group)
+                pooled = pooled or pool
+            elif _fusable_bn(bn, y):
                 relu = len(sub) == 3
                 # the kernels also do nn.BatchNorm's running-stat bookkeeping (same launch)
                 if last and pool_max and y.dim() == 4 and y.shape[-1] <= 255:

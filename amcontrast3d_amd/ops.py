@@ -24,6 +24,21 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_dedicated = []  # (handle, ExternalStream): kept alive for the life of the process
+
+
+def dedicated_stream(device=None):
+    """A torch stream with a hardware queue of its own (amc3d_stream_create_dedicated): for the FPS launches of a
+    pipelined loop, which otherwise stall whichever stream shares their queue for milliseconds."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().amc3d_stream_create_dedicated(ctypes.byref(handle)), "stream_create_dedicated")
+    s = torch.cuda.ExternalStream(handle.value, device=dev)
+    _dedicated.append((handle, s))
+    return s
+
+
 def _stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
@@ -514,6 +529,80 @@ class BatchNormMax(Function):
                                                      _ptr(dgamma), _ptr(dbeta), _ptr(work), wb, _stream(x)),
                        "bn_backward")
         return dx, dgamma, dbeta, None, None, None
+
+
+class SyncBatchNormFused(Function):
+    """BatchNormAct (pool=False) / BatchNormMax (pool=True) with statistics over every rank of `group`:
+    torch.nn.SyncBatchNorm's arithmetic (torch/nn/modules/_functions.py; the reference converts all BN layers to it
+    when world_size > 1, examples/segmentation/main_AA.py:146-148) on the fused kernels.  Per layer one all-reduce of
+    2C+1 doubles forward ({sum x, sum x^2} per channel and the element count) and one of 2C doubles backward
+    ({sum dq, sum dq*xhat}); parameter gradients stay rank-local, as torch's do.  Counts stay on the device, so ranks
+    may hold different numbers of points and the whole sequence can be captured in a graph."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu, pool, bn, group):
+        import torch.distributed as dist
+        _need_gpu(x, gamma, beta)
+        x = x.contiguous()
+        B, C = x.shape[0], x.shape[1]
+        L = x.numel() // (B * C)
+        K = x.shape[-1] if pool else 0
+        dev = x.device
+        lib = _lib.load()
+        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+        sums[2 * C:].fill_(float(B * L))
+        work, wb = _bn_ws(C, dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.amc3d_bn_sums(B, C, L, _ptr(x), _ptr(sums), _ptr(work), wb, _stream(x)), "bn_sums")
+        dist.all_reduce(sums, group=group)
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty_like(mean)
+        var_u = torch.empty_like(mean)
+        if pool:
+            y = torch.empty(x.shape[:-1], dtype=torch.float32, device=dev)
+            arg = torch.empty(x.shape[:-1], dtype=torch.uint8, device=dev)
+        else:
+            y, arg = torch.empty_like(x), None
+        mom, rm, rv, nbt = _bn_running_args(bn)
+        with torch.cuda.device(dev):
+            _lib.check(lib.amc3d_bn_forward_synced(B, C, L, K, int(bool(relu)), float(eps), mom, _ptr(x), _ptr(sums),
+                                                   _ptr(gamma), _ptr(beta), _ptr(y), None if arg is None else _ptr(arg),
+                                                   _ptr(mean), _ptr(invstd), _ptr(var_u), rm, rv, nbt, _stream(x)),
+                       "bn_forward_synced")
+        saved = [x, gamma, beta, mean, invstd, sums] + ([arg] if pool else [])
+        ctx.save_for_backward(*saved)
+        ctx.relu, ctx.pool, ctx.group = bool(relu), bool(pool), group
+        ctx.mark_non_differentiable(mean, var_u)
+        ctx.set_materialize_grads(False)
+        return y, mean, var_u
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        import torch.distributed as dist
+        x, gamma, beta, mean, invstd, sums = ctx.saved_tensors[:6]
+        arg = ctx.saved_tensors[6] if ctx.pool else None
+        B, C = x.shape[0], x.shape[1]
+        L = x.numel() // (B * C)
+        K = x.shape[-1] if ctx.pool else 1
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        dsums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        work, wb = _bn_ws(C, x.device)
+        lib = _lib.load()
+        aptr = None if arg is None else _ptr(arg)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.amc3d_bn_backward_sums(B, C, L, K, int(ctx.relu), _ptr(x), _ptr(dy), aptr, _ptr(mean),
+                                                  _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dsums), _ptr(dgamma),
+                                                  _ptr(dbeta), _ptr(work), wb, _stream(x)), "bn_backward_sums")
+        dist.all_reduce(dsums, group=ctx.group)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.amc3d_bn_backward_synced(B, C, L, K, int(ctx.relu), _ptr(x), _ptr(dy), aptr, _ptr(mean),
+                                                    _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dsums),
+                                                    ctypes.c_void_p(sums.data_ptr() + 16 * C), _ptr(dx), _stream(x)),
+                       "bn_backward_synced")
+        return dx, dgamma, dbeta, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------

@@ -53,14 +53,18 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true",
                     help="compute each batch's geometry inline instead of one step ahead on a side stream")
     ap.add_argument("--sync-bn", action="store_true",
-                    help="N > 1: the reference's SyncBatchNorm + DistributedDataParallel (eager) instead of "
-                         "graph-captured per-rank steps + bucketed RCCL gradient all-reduce")
+                    help="N > 1: BatchNorm statistics over all ranks (the reference converts every BN layer to "
+                         "SyncBatchNorm when world_size > 1) on the fused kernels, one small RCCL all-reduce per layer "
+                         "and direction inside the captured step")
+    ap.add_argument("--ddp", action="store_true",
+                    help="N > 1: torch's SyncBatchNorm + DistributedDataParallel wrappers (eager), the literal "
+                         "main_AA.py:146-152 recipe, as a cross-check of the two paths above")
     ap.add_argument("--cpu-baseline-batch", type=int, default=2,
                     help="clouds in the CPU sample (bounded: the full batch of 8 takes minutes on the host)")
     return ap.parse_args()
 
 
-def build(variant, dev, world, ddp, mm=False):
+def build(variant, dev, world, ddp, mm=False, sync_bn=False):
     import amcontrast3d_amd
     amcontrast3d_amd.activate()
     from amcontrast3d_amd import configs, dist as adist
@@ -73,6 +77,8 @@ def build(variant, dev, world, ddp, mm=False):
     model = build_model_from_cfg(c).to(dev).train()
     if ddp:
         model = adist.wrap_data_parallel(model, dev, world)
+    elif sync_bn:  # main_AA.py:146-148; blocks.run_convblocks routes these layers to ops.SyncBatchNormFused
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     cc = EasyConfig(); cc.update(configs.criterion_cfg_mm() if mm else configs.criterion_cfg())
     criterion = build_criterion_from_cfg(cc).to(dev)
     aargs = EasyConfig(); aargs.update(configs.ambiguity_args_mm("s3dis") if mm else configs.ambiguity_args("s3dis"))
@@ -119,9 +125,20 @@ def main():
     dev = torch.device("cuda", local)
     _lib.load()
 
-    use_ddp = world > 1 and args.sync_bn
+    use_ddp = world > 1 and args.ddp
+    sync_bn = world > 1 and args.sync_bn and not use_ddp
+    if args.sync_bn and world == 1 and os.environ.get("AMC3D_FORCE_SYNC_BN"):
+        # rehearsal on a one-GPU box: a one-rank RCCL group, so that the captured step contains the all-reduces
+        import torch.distributed as tdist
+        import amcontrast3d_amd
+        amcontrast3d_amd.activate()
+        from openpoints.models.layers import blocks
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        tdist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        blocks._FORCE_SYNCED_BN = sync_bn = True
     use_graph = not args.no_graph and not use_ddp
-    cfg, model, criterion, aargs, opt = build(args.variant, dev, world, use_ddp, args.mm)
+    cfg, model, criterion, aargs, opt = build(args.variant, dev, world, use_ddp, args.mm, sync_bn)
     ids = adist.scene_ids(rank, world, args.batch)
     nb = synthetic.make_batch(args.batch, args.points, first_id=ids[0])
     data = {k: torch.from_numpy(v).to(dev) for k, v in nb.items()}
@@ -157,12 +174,29 @@ def main():
     # heavy per-node overhead (scratch/graph_conc.py: 1.6 ms vs 4.8 ms for three 0.95 ms chains).
     from amcontrast3d_amd import geometry
     overlap = not args.no_overlap and not use_ddp
-    main_s = torch.cuda.Stream()  # all work of this process runs on non-default streams (capture recipe)
+    prio = [int(v) for v in os.environ.get("AMC3D_STREAM_PRIO", "0,0,0,0").split(",")]  # main, fps lanes, a2, b
+    main_s = torch.cuda.Stream(priority=prio[0])  # all work of this process runs on non-default streams (capture recipe)
     main_s.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(main_s)
     lanes = max(1, args.fps_lanes)
-    s_a = [torch.cuda.Stream() for _ in range(lanes)]
-    s_a2, s_b = torch.cuda.Stream(), torch.cuda.Stream()
+    # Hardware queues.  Ordinary HIP streams of a process share GPU_MAX_HW_QUEUES (default 4) queues round-robin, and
+    # whatever shares a queue with a running FPS kernel (8 ms on 8 workgroups) waits for it; which stream that is
+    # changes with every stream anybody creates (graph-internal branches, RCCL).  So the two long-latency chains get
+    # queues of their own (csrc/api.hip: amc3d_stream_create_dedicated), shared only by work that is serial anyway:
+    #   Q_fps : the first-level FPS of both lanes (one launch per step, 8 ms each)
+    #   Q_geo : FPS levels 2-4, then the neighbourhood / loss geometry of the same batch
+    from amcontrast3d_amd import ops as _ops
+    qplan = os.environ.get("AMC3D_QUEUES", "fps,geo")  # others, for scratch/queue_sweep.sh: "pooled", "fps,a2,b", ...
+    if qplan == "pooled":
+        s_a = [torch.cuda.Stream(priority=prio[1]) for _ in range(lanes)]
+        s_a2, s_b = torch.cuda.Stream(priority=prio[2]), torch.cuda.Stream(priority=prio[3])
+    else:
+        q = {k: _ops.dedicated_stream(dev) for k in qplan.split(",")}
+        s_a = [q.get(f"fps{l}", q.get("fps")) or torch.cuda.Stream() for l in range(lanes)]
+        s_a2 = q.get("a2", q.get("geo")) or torch.cuda.Stream()
+        s_b = q.get("b", q.get("geo")) or torch.cuda.Stream()
+    ev_lane = [torch.cuda.Event() for _ in range(lanes)]
+    ev_a2, ev_b, ev_main = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
     head = criterion.contrast_head
     nlevels = len(list((model.module if hasattr(model, "module") else model).encoder.encoder))
 
@@ -212,19 +246,24 @@ def main():
         if overlap:
             lane = step_no[0] % lanes  # the FPS lane launched `lanes` steps ago delivers now and is relaunched
             step_no[0] += 1
-            main_s.wait_stream(s_a[lane])
-            main_s.wait_stream(s_a2)
-            main_s.wait_stream(s_b)
+            # events, not stream waits: several parts may share a queue (the other lane's FPS is still running)
+            main_s.wait_event(ev_lane[lane])
+            main_s.wait_event(ev_a2)
+            main_s.wait_event(ev_b)
             f_rotate[lane]()
-            s_a[lane].wait_stream(main_s)
-            s_a2.wait_stream(main_s)
-            s_b.wait_stream(main_s)
+            ev_main.record(main_s)
             with torch.cuda.stream(s_a[lane]):
+                s_a[lane].wait_event(ev_main)
                 f_a[lane]()
+                ev_lane[lane].record(s_a[lane])
             with torch.cuda.stream(s_a2):
+                s_a2.wait_event(ev_main)
                 f_a2()
+                ev_a2.record(s_a2)
             with torch.cuda.stream(s_b):
+                s_b.wait_event(ev_main)
                 f_b()
+                ev_b.record(s_b)
         f_feat()
         if world > 1 and not use_ddp:
             adist.allreduce_gradients(params)
@@ -245,20 +284,23 @@ def main():
         opt.zero_grad(set_to_none=True)
         names = ["a2", "b", "feat", "update"] + [f"rotate{l}" for l in range(lanes)] + [f"fps{l}" for l in range(lanes)]
         graphs = {k: torch.cuda.CUDAGraph() for k in names}
-        cap = torch.cuda.Stream()
-        with torch.cuda.graph(graphs["feat"], stream=cap):
+        cap = main_s if not os.environ.get("AMC3D_CAPTURE_SIDE") else torch.cuda.Stream()
+        # with a process group alive, RCCL's watchdog thread polls events while we capture: only this thread's calls
+        # may be policed by the capture (the default "global" mode turns that poll into a fatal error)
+        cap_mode = os.environ.get("AMC3D_CAPTURE_MODE") or ("thread_local" if world > 1 or sync_bn else "global")
+        with torch.cuda.graph(graphs["feat"], stream=cap, capture_error_mode=cap_mode):
             fwd_bwd()
-        with torch.cuda.graph(graphs["update"], stream=cap):
+        with torch.cuda.graph(graphs["update"], stream=cap, capture_error_mode=cap_mode):
             update()
         if overlap:
             for l in range(lanes):
-                with torch.cuda.graph(graphs[f"rotate{l}"], stream=cap):
+                with torch.cuda.graph(graphs[f"rotate{l}"], stream=cap, capture_error_mode=cap_mode):
                     rotate(l)
-                with torch.cuda.graph(graphs[f"fps{l}"], stream=cap):
+                with torch.cuda.graph(graphs[f"fps{l}"], stream=s_a[l], capture_error_mode=cap_mode):
                     body_a(l)
-            with torch.cuda.graph(graphs["a2"], stream=cap):
+            with torch.cuda.graph(graphs["a2"], stream=s_a2, capture_error_mode=cap_mode):
                 body_a2()
-            with torch.cuda.graph(graphs["b"], stream=cap):
+            with torch.cuda.graph(graphs["b"], stream=s_b, capture_error_mode=cap_mode):
                 body_b()
         torch.cuda.synchronize()
 
@@ -280,6 +322,30 @@ def main():
     dt = time.perf_counter() - t0
     dt = adist.max_over_ranks(dt, dev)
     final_loss = float(out["loss"].detach())
+
+    if use_graph and overlap and rank == 0 and os.environ.get("AMC3D_TIMELINE"):
+        # GPU start/end of every pipeline part relative to the step's first launch (HIP events around each replay)
+        def timed(fn, stream, tag, log):
+            def run():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream); fn(); e1.record(stream)
+                log.append((tag, e0, e1))
+            return run
+        for it in range(6):
+            log = []
+            ref = torch.cuda.Event(enable_timing=True)
+            ref.record(main_s)
+            h0 = time.perf_counter()
+            run_step([timed(graphs[f"rotate{l}"].replay, main_s, "rotate", log) for l in range(lanes)],
+                     [timed(graphs[f"fps{l}"].replay, s_a[l], f"fps{l}", log) for l in range(lanes)],
+                     timed(graphs["a2"].replay, s_a2, "a2", log), timed(graphs["b"].replay, s_b, "b", log),
+                     timed(graphs["feat"].replay, main_s, "feat", log), timed(graphs["update"].replay, main_s, "update", log))
+            h1 = time.perf_counter()
+            if it >= 3:
+                torch.cuda.synchronize()
+                print(f"timeline step {it}: host launch {1e3*(h1-h0):.2f} ms | " + " | ".join(
+                    f"{tag} {ref.elapsed_time(e0):.2f}-{ref.elapsed_time(e1):.2f}" for tag, e0, e1 in log), file=sys.stderr)
+        torch.cuda.synchronize()
 
     parts = None
     if use_graph and overlap and rank == 0:
@@ -372,7 +438,7 @@ def main():
                                    f"voxelised (0.04 m) clouds, batch {args.batch}/GPU, fwd + CE/contrast loss + bwd + "
                                    f"clip + AdamW",
                        "global_batch": args.batch * world, "points": args.points,
-                       "parallelism": f"dp{world}" + ("+syncbn+ddp" if use_ddp else ""),
+                       "parallelism": f"dp{world}" + ("+syncbn+ddp" if use_ddp else "+syncbn" if sync_bn else ""),
                        "launch": "hipGraph replay (fwd+loss+bwd | clip+AdamW)" if use_graph else "eager",
                        "pipeline": f"{3 + lanes} streams: FPS level 1 of {lanes} future batches in flight | FPS levels 2-4 "
                                                f"(t+2) | neighbourhood + loss geometry (t+1) | features (t)"

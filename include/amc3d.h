@@ -40,6 +40,13 @@ const char *amc3d_version(void);
 /* text of the last error on this thread ("" if none) */
 const char *amc3d_last_error(void);
 
+/* A HIP stream (hipStream_t) with a hardware queue of its own, for the long latency-bound furthest-point-sampling
+ * launches of a pipelined training loop: ordinary streams share four hardware queues per process, and whatever
+ * shares the queue of a running FPS kernel waits milliseconds for it.  (The reference launches everything on the
+ * legacy default stream; this is the hook its trainer would use to overlap batches.) */
+int amc3d_stream_create_dedicated(void **stream);
+int amc3d_stream_destroy(void *stream);
+
 /* ---- pointnet2_batch surface ------------------------------------------------ */
 
 /* replaces ball_query_wrapper_fast -> ball_query_kernel_launcher_fast
@@ -281,6 +288,31 @@ int amc3d_bn_backward(int B, int C, long L, int K, int relu, const float *x, con
                       const unsigned char *arg, const float *mean, const float *invstd, const float *gamma,
                       const float *beta, float *dx, float *dgamma, float *dbeta, void *workspace,
                       size_t workspace_bytes, void *stream);
+
+/* ---- the same BatchNorm with statistics over all ranks (torch.nn.SyncBatchNorm: the reference converts every BN
+ * layer to it when world_size > 1, examples/segmentation/main_AA.py:146-148, 820).  The per-channel sums leave the
+ * library between two launches so that the caller can all-reduce them (RCCL):
+ *     forward    amc3d_bn_sums -> all-reduce(sums[2C] ++ count) -> amc3d_bn_forward_synced
+ *     backward   amc3d_bn_backward_sums -> all-reduce(dsums[2C]) -> amc3d_bn_backward_synced
+ * Element counts are read from device memory: ranks may differ in size, and the sequence can be graph-captured. */
+/* sums (2C doubles) = {sum x, sum x^2} per channel over this rank's (B, L) */
+int amc3d_bn_sums(int B, int C, long L, const float *x, double *sums, void *workspace, size_t workspace_bytes,
+                  void *stream);
+/* amc3d_bn_forward's second launch from global statistics: sums_count = 2C sums, then the global element count */
+int amc3d_bn_forward_synced(int B, int C, long L, int K, int relu, float eps, float momentum, const float *x,
+                            const double *sums_count, const float *gamma, const float *beta, float *y,
+                            unsigned char *arg, float *mean, float *invstd, float *var_unbiased, float *running_mean,
+                            float *running_var, long long *num_batches_tracked, void *stream);
+/* dsums (2C doubles) = {sum dq, sum dq*xhat} per channel over this rank; dgamma / dbeta (C) = the same, rank-local
+ * (as torch's SyncBatchNorm leaves them; the gradient all-reduce averages parameter gradients) */
+int amc3d_bn_backward_sums(int B, int C, long L, int K, int relu, const float *x, const float *dy,
+                           const unsigned char *arg, const float *mean, const float *invstd, const float *gamma,
+                           const float *beta, double *dsums, float *dgamma, float *dbeta, void *workspace,
+                           size_t workspace_bytes, void *stream);
+/* dx (B,C,L) from the global dsums and the global element count (*count, device memory) */
+int amc3d_bn_backward_synced(int B, int C, long L, int K, int relu, const float *x, const float *dy,
+                             const unsigned char *arg, const float *mean, const float *invstd, const float *gamma,
+                             const float *beta, const double *dsums, const double *count, float *dx, void *stream);
 
 #ifdef __cplusplus
 }
