@@ -27,6 +27,17 @@ def _ptr(t):
 _dedicated = []  # (handle, ExternalStream): kept alive for the life of the process
 
 
+def _destroy_dedicated():
+    if not _dedicated:
+        return
+    try:
+        torch.cuda.synchronize()
+        for handle, _ in _dedicated:
+            _lib.load().amc3d_stream_destroy(handle)
+    finally:
+        _dedicated.clear()
+
+
 def dedicated_stream(device=None):
     """A torch stream with a hardware queue of its own (amc3d_stream_create_dedicated): for the FPS launches of a
     pipelined loop, which otherwise stall whichever stream shares their queue for milliseconds."""
@@ -35,6 +46,9 @@ def dedicated_stream(device=None):
     with torch.cuda.device(dev):
         _lib.check(_lib.load().amc3d_stream_create_dedicated(ctypes.byref(handle)), "stream_create_dedicated")
     s = torch.cuda.ExternalStream(handle.value, device=dev)
+    if not _dedicated:
+        import atexit
+        atexit.register(_destroy_dedicated)
     _dedicated.append((handle, s))
     return s
 
