@@ -1,0 +1,158 @@
+"""Evaluation loops around the hot path: validation batches and whole-room testing with boundary / inner mIoU
+(the reference's `validate_boundary_inner` and `test_boundary_inner`, examples/segmentation/main_AA.py:431-802;
+SURVEY.md section 8(f) rank 2).
+
+The reference's loops are welded to its dataset readers, transform registry, tqdm / wandb logging and result
+files; what they compute is restated here on arrays the caller already holds:
+
+    voxel_parts                 main_AA.py:91-116 (`load_data`, multi_voxel mode) + dataset/data_util.py:92-143
+    boundary_mask               main_AA.py:470-476, 628-633 (posmask_searching + the 0 < n+ < nsample test)
+    scatter_mean                torch_scatter.scatter(..., reduce='mean') of main_AA.py:662 (package absent here)
+    validate_boundary_inner     main_AA.py:431-513
+    test_cloud_boundary_inner   one iteration of the cloud loop of main_AA.py:556-684
+    summarize                   main_AA.py:484-506 / 746-770 (get_mious over the accumulated matrices)
+
+The model runs with model.eval(): BatchNorm uses its running statistics on the fused inference kernels
+(ops.bn_eval), FPS / ball query / grouped convolutions / 3-NN are the same HIP kernels as in training.
+"""
+import numpy as np
+import torch
+
+from . import activate
+
+
+def _fnv64(cells):
+    """FNV-1a over the integer voxel coordinates, as dataset/data_util.py:92-105 (uint64 wrap-around)."""
+    h = np.full(cells.shape[0], 14695981039346656037, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for j in range(cells.shape[1]):
+            h *= np.uint64(1099511628211)
+            h ^= cells[:, j]
+    return h
+
+
+def voxel_parts(coord, voxel_size, rng=None):
+    """Split a cloud into sub-clouds holding one point per occupied voxel each (test_mode 'multi_voxel'):
+    part i takes the (i mod count)-th point of every voxel, so count.max() parts cover every point and sparse voxels
+    repeat theirs.  Returns the list of index arrays (each shuffled with `rng`, as the reference shuffles them)."""
+    cells = np.floor(np.asarray(coord) / np.asarray(voxel_size)).astype(np.uint64)
+    key = _fnv64(cells)
+    order = np.argsort(key)
+    _, count = np.unique(key[order], return_counts=True)
+    first = np.cumsum(np.insert(count, 0, 0)[:-1])
+    rng = np.random.default_rng(0) if rng is None else rng
+    parts = []
+    for i in range(int(count.max())):
+        part = order[first + i % count]
+        rng.shuffle(part)
+        parts.append(part)
+    return parts
+
+
+@torch.no_grad()
+def boundary_mask(xyz, target, nsample, num_classes, ignore_index):
+    """(m) bool: points whose nsample-1 nearest neighbours contain between 1 and nsample-1 points of their own class.
+    (The upper bound is `< nsample`, not `< nsample - 1`, exactly as main_AA.py:475 writes it: a point all of whose
+    neighbours agree with it therefore counts as boundary too, and "inner" means no neighbour agrees.)"""
+    activate()
+    from openpoints.AMContrast3D.metrics import posmask_searching
+    posmask, _ = posmask_searching(xyz, target, nsample, num_classes, ignore_index)
+    same = posmask.sum(-1)
+    return torch.logical_and(0 < same, same < nsample)
+
+
+def scatter_mean(src, index, size=None):
+    """out[j] = mean of src[i] over index[i] == j (0 where no i): torch_scatter.scatter(src, index, dim=0,
+    reduce='mean') for 2-d src, which is how overlapping sub-cloud logits are voted (main_AA.py:662)."""
+    n = int(index.max().item()) + 1 if size is None else size
+    out = torch.zeros(n, src.shape[1], dtype=src.dtype, device=src.device)
+    out.index_add_(0, index, src)
+    cnt = torch.zeros(n, dtype=src.dtype, device=src.device)
+    cnt.index_add_(0, index, torch.ones_like(index, dtype=src.dtype))
+    return out / cnt.clamp(min=1).unsqueeze(1)
+
+
+def _matrices(num_classes, ignore_index):
+    activate()
+    from openpoints.utils import ConfusionMatrix
+    return [ConfusionMatrix(num_classes=num_classes, ignore_index=ignore_index) for _ in range(3)]
+
+
+def summarize(cm, cm_b=None, cm_i=None, distributed=False):
+    """(miou, macc, oa, ious, accs) for the whole set [+ the same five for boundary and inner points], with the
+    cross-rank sum of (tp, union, count) first when `distributed` (main_AA.py:459-462, 484-500)."""
+    activate()
+    from openpoints.utils import get_mious
+    out = ()
+    for m in (cm, cm_b, cm_i):
+        if m is None:
+            continue
+        tp, union, count = m.tp, m.union, m.count
+        if distributed:
+            import torch.distributed as dist
+            dist.all_reduce(tp), dist.all_reduce(union), dist.all_reduce(count)
+        out += tuple(get_mious(tp, union, count))
+    return out
+
+
+@torch.no_grad()
+def validate_boundary_inner(model, batches, num_classes, ignore_index, nsample, miou_B_I=True, distributed=False):
+    """Validation pass over batches of ONE cloud each (the reference's val loader uses batch size 1;
+    `data['pos'].squeeze()` at main_AA.py:469 assumes it): dicts with pos (1,N,3), x (1,C,N), y (1,N) on the GPU.
+    Returns summarize(...) of the whole / boundary / inner confusion matrices."""
+    model.eval()
+    cm, cm_b, cm_i = _matrices(num_classes, ignore_index)
+    for data in batches:
+        target = data["y"].reshape(data["y"].shape[0], -1)
+        logits, _ = model(data)
+        pred = logits.argmax(dim=1)
+        cm.update(pred, target)
+        if miou_B_I:
+            assert data["pos"].shape[0] == 1, "boundary / inner split is defined per cloud (batch size 1)"
+            b = boundary_mask(data["pos"][0], target[0], nsample, num_classes, ignore_index).unsqueeze(0)
+            cm_b.update(pred[b], target[b])
+            cm_i.update(pred[~b], target[~b])
+    return summarize(cm, cm_b, cm_i, distributed) if miou_B_I else summarize(cm, distributed=distributed)
+
+
+@torch.no_grad()
+def test_cloud_boundary_inner(model, coord, feat, label, parts, num_classes, ignore_index, nsample,
+                              make_input=None, miou_B_I=True):
+    """One whole cloud (room): every sub-cloud of `parts` goes through the model, overlapping logits are averaged per
+    point, and three confusion matrices are filled -- all points (voted prediction), boundary and inner points (per
+    sub-cloud predictions, as the reference keeps them: main_AA.py:634-641, 651-657, 671-676).
+
+    coord (n,3) float array, feat (n,c) float array or None, label (n) int tensor on the GPU, parts: index arrays.
+    make_input(coord_part, feat_part) -> model input dict; default: pos shifted to its minimum corner, x = feat and
+    the height channel (the S3DIS feature_keys 'x,heights', cfgs/s3dis/default.yaml).
+    Returns dict(pred, logits, cm, cm_b, cm_i)."""
+    model.eval()
+    dev = label.device
+    cm, cm_b, cm_i = _matrices(num_classes, ignore_index)
+    if make_input is None:
+        def make_input(coord_part, feat_part):
+            pos = torch.from_numpy(np.ascontiguousarray(coord_part, dtype=np.float32)).to(dev).unsqueeze(0)
+            cols = [torch.from_numpy(np.ascontiguousarray(feat_part, dtype=np.float32)).to(dev)] if feat_part is not None else []
+            x = torch.cat(cols + [pos[0, :, 2:3]], dim=1).t().contiguous().unsqueeze(0)
+            return {"pos": pos, "x": x}
+    all_logits, pb, pi, tb, ti = [], [], [], [], []
+    for part in parts:
+        coord_part = np.asarray(coord)[part]
+        coord_part = coord_part - coord_part.min(0)
+        data = make_input(coord_part, None if feat is None else np.asarray(feat)[part])
+        logits, _ = model(data)
+        all_logits.append(logits)
+        if miou_B_I:
+            label_part = label[torch.from_numpy(part).to(dev)]
+            b = boundary_mask(data["pos"][0], label_part, nsample, num_classes, ignore_index)
+            pred_part = logits.argmax(dim=1)[0]
+            pb.append(pred_part[b]); pi.append(pred_part[~b]); tb.append(label_part[b]); ti.append(label_part[~b])
+    flat = torch.cat([lg.transpose(1, 2).reshape(-1, num_classes) for lg in all_logits], dim=0)
+    index = torch.from_numpy(np.hstack(parts)).to(dev)
+    voted = scatter_mean(flat, index, size=label.shape[0]) if len(parts) > 1 else flat[torch.argsort(index)]
+    pred = voted.argmax(dim=1)
+    cm.update(pred, label)
+    if miou_B_I:
+        cm_b.update(torch.cat(pb), torch.cat(tb))
+        cm_i.update(torch.cat(pi), torch.cat(ti))
+    return {"pred": pred, "logits": voted, "cm": cm, "cm_b": cm_b, "cm_i": cm_i}

@@ -113,6 +113,14 @@ def _fusable_bn(bn, x):
             and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled())
 
 
+def _eval_bn(bn, x):
+    """inference-mode BatchNorm (any of the BatchNorm classes) on a contiguous fp32 GPU tensor outside autograd:
+    the fused kernels with the running statistics (ops.bn_eval)"""
+    return (isinstance(bn, nn.modules.batchnorm._BatchNorm) and not bn.training and bn.affine
+            and bn.track_running_stats and bn.running_mean is not None and x.is_cuda and x.dtype == torch.float32
+            and not torch.is_grad_enabled() and not torch.is_autocast_enabled())
+
+
 def _synced_bn_group(bn, x):
     """process group of a training-mode nn.SyncBatchNorm whose statistics really span several ranks (then the fused
     kernels exchange their per-channel sums: ops.SyncBatchNormFused), else None"""
@@ -173,7 +181,12 @@ def run_convblocks(blocks, x, pool_max=False, pre=None):
             y = pre if (bi == 0 and pre is not None) else conv1x1(sub[0], x)
             bn = sub[1]
             group = _synced_bn_group(bn, y)
-            if group is not None:
+            if _eval_bn(bn, y):
+                from amcontrast3d_amd.ops import bn_eval
+                pool = last and pool_max and y.dim() == 4 and y.shape[-1] <= 255
+                x = bn_eval(y, bn, len(sub) == 3, pool)
+                pooled = pooled or pool
+            elif group is not None:
                 pool = last and pool_max and y.dim() == 4 and y.shape[-1] <= 255
                 x, _, _ = SyncBatchNormFused.apply(y, bn.weight, bn.bias, bn.eps, len(sub) == 3, pool, bn, group)
                 pooled = pooled or pool

@@ -1,11 +1,12 @@
 """openpoints.utils -- the part the model/loss path needs (registry, config).
 
 When the reference tree is overlaid (see amcontrast3d_amd.activate), the
-remaining helper modules the trainer imports (logger, ckpt_util, metrics, ...)
+remaining helper modules the trainer imports (logger, ckpt_util, wandb, ...)
 resolve from the reference's own openpoints/utils directory.
 """
 from . import registry
 from .config import EasyConfig
+from .metrics import AverageMeter, ConfusionMatrix, get_mious
 from .registry import Registry, build_from_cfg
 
 
@@ -21,7 +22,6 @@ def _overlay_optional():
         'random': ['set_random_seed'],
         'logger': ['setup_logger_dist', 'generate_exp_directory', 'resume_exp_directory'],
         'wandb': ['Wandb'],
-        'metrics': ['AverageMeter', 'ConfusionMatrix', 'get_mious'],
         'ckpt_util': ['resume_model', 'resume_optimizer', 'resume_checkpoint', 'save_checkpoint', 'load_checkpoint',
                       'get_missing_parameters_message', 'get_unexpected_parameters_message'],
         'dist_utils': ['reduce_tensor', 'gather_tensor', 'find_free_port'],

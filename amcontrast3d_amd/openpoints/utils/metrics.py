@@ -1,0 +1,126 @@
+"""Segmentation metrics of the evaluation loops (drop-in for openpoints/utils/metrics.py:30-183).
+
+    AverageMeter      :30-47    running mean of a scalar
+    ConfusionMatrix   :50-170   bincount-accumulated (true, pred) matrix and everything derived from it
+    get_mious         :173-181  IoU / accuracy from (tp, union, count) vectors (after the cross-rank all-reduce)
+
+Integer work on the GPU (torch.bincount of true * C + pred); the matrix stays an int64 device tensor so that
+`dist.all_reduce(cm.tp)` etc. keep working as in examples/segmentation/main_AA.py:460-462.
+One deliberate difference: `update` does not overwrite the caller's `pred` / `true` tensors where
+true == ignore_index (the reference's flatten() views make its in-place writes visible outside).
+"""
+import numpy as np  # noqa: F401  (callers use the numpy arrays this returns)
+import torch
+
+
+class AverageMeter:
+    """last value, running sum, count and mean"""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+class ConfusionMatrix:
+    """value[t, p] = number of points of class t predicted as p.  `ignore_index` (a label < 0 or >= num_classes) is
+    mapped to one extra row/column that is dropped again."""
+
+    def __init__(self, num_classes, ignore_index=None):
+        self.value = 0
+        self.num_classes = num_classes
+        self.virtual_num_classes = num_classes + (1 if ignore_index is not None else 0)
+        self.ignore_index = ignore_index
+
+    @torch.no_grad()
+    def update(self, pred, true):
+        true, pred = true.reshape(-1), pred.reshape(-1)
+        v = self.virtual_num_classes
+        if self.ignore_index is not None:
+            ignored = true == self.ignore_index
+            true = torch.where(ignored, v - 1, true)
+            pred = torch.where(ignored, v - 1, pred)
+        bins = torch.bincount(true * v + pred, minlength=v * v).view(v, v)
+        self.value = self.value + bins[:self.num_classes, :self.num_classes]
+
+    def reset(self):
+        self.value = 0
+
+    # ---- per-class vectors --------------------------------------------------------------------
+    @property
+    def tp(self):
+        return self.value.diag()
+
+    @property
+    def actual(self):
+        return self.value.sum(dim=1)
+
+    @property
+    def predicted(self):
+        return self.value.sum(dim=0)
+
+    @property
+    def fn(self):
+        return self.actual - self.tp
+
+    @property
+    def fp(self):
+        return self.predicted - self.tp
+
+    @property
+    def tn(self):
+        return self.actual.sum() + self.tp - (self.actual + self.predicted)
+
+    @property
+    def count(self):
+        return self.actual
+
+    @property
+    def union(self):
+        return self.predicted + self.actual - self.tp
+
+    @property
+    def frequency(self):
+        c = self.actual
+        return c / c.sum().clamp(min=1)
+
+    @property
+    def total(self):
+        return self.value.sum()
+
+    @property
+    def overall_accuray(self):  # (sic) the name the reference's loops print
+        return self.tp.sum() / self.total
+
+    # ---- summaries ----------------------------------------------------------------------------
+    @staticmethod
+    def cal_acc(tp, count):
+        per_class = tp / count.clamp(min=1) * 100
+        overall = tp.sum() / count.sum() * 100
+        return torch.mean(per_class).item(), overall.item(), per_class.cpu().numpy()
+
+    def all_acc(self):
+        return self.cal_acc(self.tp, self.count)
+
+    def all_metrics(self):
+        tp = self.tp
+        iou = tp / self.union.clamp(min=1) * 100
+        acc = tp / self.count.clamp(min=1) * 100
+        overall = tp.sum() / self.total * 100
+        return torch.mean(iou).item(), torch.mean(acc).item(), overall.item(), iou.cpu().numpy(), acc.cpu().numpy()
+
+
+def get_mious(tp, union, count):
+    """(mIoU, mAcc, OA, IoU per class, accuracy per class), in per cent; 1e-10 guards empty classes (they count
+    as 100 %, as in the reference)"""
+    iou = (tp + 1e-10) / (union + 1e-10) * 100
+    acc = (tp + 1e-10) / (count + 1e-10) * 100
+    overall = tp.sum() / count.sum() * 100
+    return torch.mean(iou).item(), torch.mean(acc).item(), overall.item(), iou.cpu().numpy(), acc.cpu().numpy()

@@ -545,6 +545,31 @@ class BatchNormMax(Function):
         return dx, dgamma, dbeta, None, None, None
 
 
+@torch.no_grad()
+def bn_eval(x, bn, relu, pool=False):
+    """Inference-mode BatchNorm (running statistics) [+ReLU] [+max over the last, neighbour, dimension] in one pass:
+    the whole-room evaluation loop of the reference (examples/segmentation/main_AA.py:431-802) runs the same blocks with
+    model.eval().  y = ((x - running_mean) * rsqrt(running_var + eps)) * weight + bias, no gradient."""
+    _need_gpu(x, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    x = x.contiguous()
+    B, C = x.shape[0], x.shape[1]
+    invstd = torch.rsqrt(bn.running_var + bn.eps)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        if pool:
+            M, K = x.shape[-2], x.shape[-1]
+            y = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+            arg = torch.empty(x.shape[:-1], dtype=torch.uint8, device=x.device)
+            _lib.check(lib.amc3d_bn_max(B, C, M, K, int(bool(relu)), _ptr(x), _ptr(bn.running_mean), _ptr(invstd),
+                                        _ptr(bn.weight), _ptr(bn.bias), _ptr(y), _ptr(arg), _stream(x)), "bn_max")
+            return y
+        L = x.numel() // (B * C)
+        y = torch.empty_like(x)
+        _lib.check(lib.amc3d_bn_act(B, C, L, int(bool(relu)), _ptr(x), _ptr(bn.running_mean), _ptr(invstd),
+                                    _ptr(bn.weight), _ptr(bn.bias), _ptr(y), _stream(x)), "bn_act")
+        return y
+
+
 class SyncBatchNormFused(Function):
     """BatchNormAct (pool=False) / BatchNormMax (pool=True) with statistics over every rank of `group`:
     torch.nn.SyncBatchNorm's arithmetic (torch/nn/modules/_functions.py; the reference converts all BN layers to it

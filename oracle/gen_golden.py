@@ -237,6 +237,89 @@ def run_state_keys():
     print("state_keys:", {k: (v if isinstance(v, int) else len(v)) for k, v in keys.items()})
 
 
+def run_eval_case(name="eval_w8_room", n_room=5000, voxel=0.06, width=8, nsample=24, num_classes=13, ignore_index=None):
+    """Whole-room test of the reference in eval mode (examples/segmentation/main_AA.py:556-684 for one cloud):
+    the reference's model, voxelize, posmask_searching, ConfusionMatrix and get_mious are executed; the loop glue of
+    main_AA.py (not importable here: wandb / torch_scatter) and torch_scatter's mean are restated in this function."""
+    from openpoints.AMContrast3D.metrics import posmask_searching
+    from openpoints.dataset.data_util import voxelize
+    from openpoints.utils import ConfusionMatrix, get_mious
+    torch.manual_seed(0)
+    mcfg = cfg_of(configs.model_cfg("S", num_classes=num_classes, in_channels=4, dropout=0.5, width=width))
+    model = build_model_from_cfg(mcfg)
+    model.train()
+    with torch.no_grad():  # two training-mode passes so that the running statistics are not the initial 0 / 1
+        for k in range(2):
+            model(tensor_batch(synthetic.make_batch(2, 1024, first_id=500 + 2 * k, num_classes=num_classes)))
+    model.eval()
+    room = synthetic.make_batch(1, n_room, first_id=300, num_classes=num_classes)
+    coord = room["pos"][0].astype(np.float32)
+    coord = coord - coord.min(0)
+    feat = room["x"][0, :3].T.copy()
+    label_np = room["y"][0].astype(np.int64)
+    # 4 % label noise: isolated labels are what makes a point "inner" under the loop's 0 < n+ < nsample test
+    noise = np.random.default_rng(7)
+    flip = noise.random(n_room) < 0.04
+    label_np[flip] = noise.integers(0, num_classes, int(flip.sum()))
+    label = torch.from_numpy(label_np)
+
+    np.random.seed(0)
+    idx_sort, voxel_idx, count = voxelize(coord, voxel, mode=1)
+    parts = []
+    for i in range(count.max()):  # main_AA.py:109-113
+        part = idx_sort[np.cumsum(np.insert(count, 0, 0)[0:-1]) + i % count]
+        np.random.shuffle(part)
+        parts.append(part)
+
+    out = {"coord": coord, "feat": feat, "label": label_np, "voxel": np.float64(voxel), "nsample": np.int64(nsample)}
+    for k, v in model.state_dict().items():
+        out["w/" + k] = v.numpy().copy()
+    cm, cm_b, cm_i = (ConfusionMatrix(num_classes=num_classes, ignore_index=ignore_index) for _ in range(3))
+    all_logits, lb, li, tb, ti = [], [], [], [], []
+    with torch.no_grad():
+        for j, part in enumerate(parts):
+            cp = coord[part]
+            cp = cp - cp.min(0)
+            pos = torch.from_numpy(cp).unsqueeze(0)
+            x = torch.cat([torch.from_numpy(feat[part]), pos[0, :, 2:3]], 1).t().contiguous().unsqueeze(0)
+            logits, _ = model({"pos": pos, "x": x})
+            all_logits.append(logits)
+            label_part = label[part]
+            posmask, _ = posmask_searching(pos.squeeze(), label_part, nsample, num_classes, ignore_index)
+            point_mask = torch.sum(posmask.int(), -1)
+            boundary = torch.logical_and(0 < point_mask, point_mask < nsample).unsqueeze(0)
+            pred_part = logits.argmax(dim=1)
+            lb.append(torch.masked_select(pred_part, boundary)); li.append(torch.masked_select(pred_part, ~boundary))
+            tb.append(torch.masked_select(label_part.unsqueeze(0), boundary))
+            ti.append(torch.masked_select(label_part.unsqueeze(0), ~boundary))
+            out[f"part/{j}"] = part.astype(np.int32)
+            if j in (0, len(parts) - 1):  # per-part logits of the first and last sub-cloud only (fixture size)
+                out[f"logits/{j}"] = logits[0].numpy().copy()
+            out[f"boundary/{j}"] = np.packbits(boundary[0].numpy())
+    flat = torch.cat(all_logits, 0).transpose(1, 2).reshape(-1, num_classes) if len({lg.shape[2] for lg in all_logits}) == 1 \
+        else torch.cat([lg.transpose(1, 2).reshape(-1, num_classes) for lg in all_logits], 0)
+    index = torch.from_numpy(np.hstack(parts))
+    voted = torch.zeros(len(label), num_classes).index_add_(0, index, flat)  # torch_scatter 'mean': sum / max(count, 1)
+    voted = voted / torch.bincount(index, minlength=len(label)).clamp(min=1).unsqueeze(1)
+    pred = voted.argmax(dim=1)
+    cm.update(pred, label.clone())
+    cm_b.update(torch.cat(lb), torch.cat(tb))
+    cm_i.update(torch.cat(li), torch.cat(ti))
+    out["voted"], out["pred"] = voted.numpy(), pred.numpy()
+    for tag, m in (("all", cm), ("boundary", cm_b), ("inner", cm_i)):
+        out[f"cm/{tag}"] = m.value.numpy().copy()
+        miou, macc, oa, ious, accs = get_mious(m.tp, m.union, m.count)
+        out[f"mious/{tag}"] = np.array([miou, macc, oa], dtype=np.float64)
+        out[f"ious/{tag}"], out[f"accs/{tag}"] = ious, accs
+        out[f"all_metrics/{tag}"] = np.array(m.all_metrics()[:3], dtype=np.float64)
+    meta = {"num_classes": num_classes, "ignore_index": ignore_index, "width": width, "n_room": n_room,
+            "parts": len(parts), "torch": torch.__version__}
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: parts={[len(p) for p in parts]} mIoU={out['mious/all'][0]:.3f} boundary pts={int(cm_b.value.sum())} "
+          f"inner pts={int(cm_i.value.sum())} ({os.path.getsize(os.path.join(OUT, name + '.npz')) / 1e6:.2f} MB)")
+
+
 def run_mm_cases():
     # AMContrast3D++ with a narrow S-shaped backbone and stored weights: APM towers, masked refinement (DualMasks,
     # threshold lowered so that a good share of the points is refined at seed-0 init), three-term loss
@@ -249,6 +332,9 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "mm":
         run_mm_cases()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "eval":
+        run_eval_case()
         sys.exit(0)
     run_state_keys()
     run_ops_case()
@@ -265,3 +351,4 @@ if __name__ == "__main__":
     run_model_case("model_S_scannet_b2_n2048", "S", 2, 2048, num_classes=20, in_channels=7, dataset="scannet",
                    ignore_index=-100, ignore_frac=0.05, voxel_size=0.02, global_feat="max", grad_keys=G[:1])
     run_mm_cases()
+    run_eval_case()
