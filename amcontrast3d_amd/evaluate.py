@@ -117,7 +117,7 @@ def validate_boundary_inner(model, batches, num_classes, ignore_index, nsample, 
 
 @torch.no_grad()
 def test_cloud_boundary_inner(model, coord, feat, label, parts, num_classes, ignore_index, nsample,
-                              make_input=None, miou_B_I=True):
+                              make_input=None, miou_B_I=True, batch=8):
     """One whole cloud (room): every sub-cloud of `parts` goes through the model, overlapping logits are averaged per
     point, and three confusion matrices are filled -- all points (voted prediction), boundary and inner points (per
     sub-cloud predictions, as the reference keeps them: main_AA.py:634-641, 651-657, 671-676).
@@ -125,6 +125,11 @@ def test_cloud_boundary_inner(model, coord, feat, label, parts, num_classes, ign
     coord (n,3) float array, feat (n,c) float array or None, label (n) int tensor on the GPU, parts: index arrays.
     make_input(coord_part, feat_part) -> model input dict; default: pos shifted to its minimum corner, x = feat and
     the height channel (the S3DIS feature_keys 'x,heights', cfgs/s3dis/default.yaml).
+    batch: sub-clouds stacked per model call.  The reference feeds them one at a time (main_AA.py:575-611); in eval
+    mode nothing couples the clouds of a batch (BatchNorm uses running statistics, FPS / ball query / 3-NN work per
+    cloud), so the logits are the same, while the latency-bound FPS chain (8 ms for 24 k points on ONE workgroup) runs
+    for `batch` clouds side by side.  Sub-clouds of a voxel partition all have one point per voxel, hence equal size;
+    ragged parts fall back to single calls.
     Returns dict(pred, logits, cm, cm_b, cm_i)."""
     model.eval()
     dev = label.device
@@ -136,17 +141,25 @@ def test_cloud_boundary_inner(model, coord, feat, label, parts, num_classes, ign
             x = torch.cat(cols + [pos[0, :, 2:3]], dim=1).t().contiguous().unsqueeze(0)
             return {"pos": pos, "x": x}
     all_logits, pb, pi, tb, ti = [], [], [], [], []
+    inputs = []
     for part in parts:
         coord_part = np.asarray(coord)[part]
         coord_part = coord_part - coord_part.min(0)
-        data = make_input(coord_part, None if feat is None else np.asarray(feat)[part])
+        inputs.append(make_input(coord_part, None if feat is None else np.asarray(feat)[part]))
+    same_size = len({len(p) for p in parts}) == 1
+    step = max(1, int(batch)) if same_size else 1
+    for j0 in range(0, len(parts), step):
+        chunk = inputs[j0:j0 + step]
+        data = chunk[0] if len(chunk) == 1 else {k: torch.cat([d[k] for d in chunk], dim=0) for k in chunk[0]}
         logits, _ = model(data)
-        all_logits.append(logits)
-        if miou_B_I:
-            label_part = label[torch.from_numpy(part).to(dev)]
-            b = boundary_mask(data["pos"][0], label_part, nsample, num_classes, ignore_index)
-            pred_part = logits.argmax(dim=1)[0]
-            pb.append(pred_part[b]); pi.append(pred_part[~b]); tb.append(label_part[b]); ti.append(label_part[~b])
+        for j, d in enumerate(chunk):
+            lg = logits[j:j + 1]
+            all_logits.append(lg)
+            if miou_B_I:
+                label_part = label[torch.from_numpy(parts[j0 + j]).to(dev)]
+                b = boundary_mask(d["pos"][0], label_part, nsample, num_classes, ignore_index)
+                pred_part = lg.argmax(dim=1)[0]
+                pb.append(pred_part[b]); pi.append(pred_part[~b]); tb.append(label_part[b]); ti.append(label_part[~b])
     flat = torch.cat([lg.transpose(1, 2).reshape(-1, num_classes) for lg in all_logits], dim=0)
     index = torch.from_numpy(np.hstack(parts)).to(dev)
     voted = scatter_mean(flat, index, size=label.shape[0]) if len(parts) > 1 else flat[torch.argsort(index)]

@@ -67,6 +67,11 @@ def test_whole_cloud_matches_reference_run():
     pred = r["pred"].cpu().numpy()
     assert np.array_equal(pred[clear], g["pred"][clear])
     assert np.abs(r["cm"].value.cpu().numpy() - g["cm/all"]).sum() <= 2 * int((~clear).sum())
+    # one sub-cloud per call (the reference's schedule) gives the same logits as the stacked calls
+    r1 = evaluate.test_cloud_boundary_inner(model, g["coord"], g["feat"], label, parts, m["num_classes"],
+                                            m["ignore_index"], nsample, batch=1)
+    assert float((r1["logits"] - r["logits"]).abs().max()) <= 1e-5 * scale
+    assert np.array_equal(r1["cm_b"].value.sum(1).cpu().numpy(), g["cm/boundary"].sum(1))
     # boundary / inner membership is integer work on labels and neighbour indices: exact
     assert np.array_equal(r["cm_b"].value.sum(1).cpu().numpy(), g["cm/boundary"].sum(1))
     assert np.array_equal(r["cm_i"].value.sum(1).cpu().numpy(), g["cm/inner"].sum(1))
