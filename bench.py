@@ -143,10 +143,14 @@ def main():
     nb = synthetic.make_batch(args.batch, args.points, first_id=ids[0])
     data = {k: torch.from_numpy(v).to(dev) for k, v in nb.items()}
     params = list(model.parameters())
+    # N > 1: gradients live in one flat buffer, exchanged by a single RCCL all-reduce between the two captured halves
+    flatg = adist.FlatGradients(params) if (world > 1 and not use_ddp) or os.environ.get("AMC3D_FLAT_GRADS") else None
     torch.cuda.synchronize()
     out = {}
 
     def fwd_bwd():
+        if flatg is not None:
+            flatg.zero()  # part of the captured half: autograd then accumulates into the flat views in place
         if args.mm:  # examples/segmentation/main_MM.py:404-410: segmentation + regression objective
             logits, stage, _ = model(data)
             seg, _, _, reg = criterion(logits, data["y"], stage, 13, None, aargs)
@@ -265,12 +269,13 @@ def main():
                 f_b()
                 ev_b.record(s_b)
         f_feat()
-        if world > 1 and not use_ddp:
-            adist.allreduce_gradients(params)
+        if flatg is not None:
+            flatg.allreduce()
         f_update()
 
     def eager_step():
-        opt.zero_grad(set_to_none=True)
+        if flatg is None:
+            opt.zero_grad(set_to_none=True)
         run_step([lambda l=l: rotate(l) for l in range(lanes)], [lambda l=l: body_a(l) for l in range(lanes)], body_a2,
                  body_b, fwd_bwd, update)
 
@@ -281,7 +286,8 @@ def main():
         for _ in range(3):
             eager_step()
         torch.cuda.synchronize()
-        opt.zero_grad(set_to_none=True)
+        if flatg is None:
+            opt.zero_grad(set_to_none=True)
         names = ["a2", "b", "feat", "update"] + [f"rotate{l}" for l in range(lanes)] + [f"fps{l}" for l in range(lanes)]
         graphs = {k: torch.cuda.CUDAGraph() for k in names}
         cap = main_s if not os.environ.get("AMC3D_CAPTURE_SIDE") else torch.cuda.Stream()
@@ -322,6 +328,7 @@ def main():
     dt = time.perf_counter() - t0
     dt = adist.max_over_ranks(dt, dev)
     final_loss = float(out["loss"].detach())
+    assert flatg is None or flatg.intact(), "a parameter gradient left the flat all-reduce buffer"
 
     if use_graph and overlap and rank == 0 and os.environ.get("AMC3D_TIMELINE"):
         # GPU start/end of every pipeline part relative to the step's first launch (HIP events around each replay)

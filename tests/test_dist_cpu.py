@@ -36,6 +36,20 @@ def _worker(rank, world, port, q):
     dist.all_gather_object(gathered, [g.tolist() for g in local])
     want = [sum(torch.tensor(gathered[r_][i]) for r_ in range(world)) / world for i in range(len(local))]
     ok = all(torch.allclose(p.grad, w_, atol=1e-6) for p, w_ in zip(net.parameters(), want))
+    # flat gradient buffer: backward accumulates into the views in place; one all-reduce averages everything
+    torch.manual_seed(0)
+    net2 = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    net2.load_state_dict(net.state_dict())
+    fg = adist.FlatGradients(list(net2.parameters()))
+    net2(x).square().mean().backward()   # a first pass that zero() must erase
+    fg.zero()
+    net2(x).square().mean().backward()
+    flat_ok = fg.intact() and all(torch.allclose(p.grad, g, atol=1e-7) for p, g in zip(net2.parameters(), local))
+    fg.allreduce()
+    flat_ok = flat_ok and fg.intact() and all(torch.allclose(p.grad, w_, atol=1e-6) for p, w_ in zip(net2.parameters(), want))
+    torch.optim.SGD(net2.parameters(), lr=0.1).zero_grad(set_to_none=True)
+    flat_ok = flat_ok and not fg.intact()  # detects a replaced .grad
+    ok = ok and flat_ok
     # DDP wrapper (CPU branch) keeps replicas in sync after a step
     ddp = adist.wrap_data_parallel(torch.nn.Linear(4, 2), torch.device("cpu"), world)
     opt = torch.optim.SGD(ddp.parameters(), lr=0.1)
