@@ -18,6 +18,8 @@
 // MFMA operand convention (v_mfma_f32_32x32x2_f32): lane l supplies A[i = l & 31][kk = l >> 5] and
 // B[kk = l >> 5][j = l & 31]; step t of a chunk pairs k = t (lanes 0-31) with k = 8 + t (lanes 32-63) in both
 // operands -- any pairing is a valid order of the K sum as long as A and B agree.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace amc {
@@ -217,7 +219,8 @@ static int gemm_wgrad_splits(int b, int cin, int cout, long P, long *kper)
     // enough workgroups to fill the chip, at least 256 positions each
     const long tiles = (long)div_up(cout, GM_T) * div_up(cin, GM_T);
     long s = 1024 / (tiles * b);
-    const long cap = P / 256 > 1 ? P / 256 : 1;
+    static const long mink = getenv("AMC3D_WGRAD_MINK") ? atol(getenv("AMC3D_WGRAD_MINK")) : 256;
+    const long cap = P / mink > 1 ? P / mink : 1;
     if (s > cap) s = cap;
     if (s < 1) s = 1;
     long per = ((P + s - 1) / s + GM_KC - 1) / GM_KC * GM_KC;

@@ -8,6 +8,8 @@ the conv has no bias when a norm follows it.
 """
 import copy
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -142,9 +144,16 @@ def conv1x1(conv, x):
     if (type(conv) in (nn.Conv1d, nn.Conv2d, Conv1d, Conv2d) and x.is_cuda and x.dtype == torch.float32
             and not torch.is_autocast_enabled() and conv.groups == 1 and conv.padding_mode == 'zeros'
             and all(k == 1 for k in conv.kernel_size) and all(v == 1 for v in conv.stride)
-            and all(v == 0 for v in conv.padding) and x.dim() == conv.weight.dim() and _pw_pays(conv, x)):
-        from amcontrast3d_amd.ops import pointwise_conv
-        return pointwise_conv(x, conv.weight, conv.bias)
+            and all(v == 0 for v in conv.padding) and x.dim() == conv.weight.dim()):
+        if _pw_pays(conv, x):
+            from amcontrast3d_amd.ops import pointwise_conv
+            return pointwise_conv(x, conv.weight, conv.bias)
+        if (conv.bias is None and min(conv.in_channels, conv.out_channels) >= 64 and conv.in_channels % 4 == 0
+                and torch.is_grad_enabled() and not os.environ.get("AMC3D_NO_LIBRARY_GEMM")):
+            # deep and short (SA4, coarse FP stages): three plain library GEMMs instead of the convolution library,
+            # whose weight gradient is wrapped in layout transposes (scratch/pw_bench3.py: 30-50 us per layer)
+            from amcontrast3d_amd.ops import library_gemm_conv
+            return library_gemm_conv(x, conv.weight)
     return conv(x)
 
 

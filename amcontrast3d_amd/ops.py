@@ -758,6 +758,74 @@ def pointwise_conv(x, weight, bias=None):
     return PointwiseConv.apply(x, weight, bias)
 
 
+_wgrad_form = {}  # (B, Cin, Cout, P) -> "bmm" | "flat": the faster library form of the weight gradient, timed once
+
+
+def _library_wgrad(dy3, x3):
+    """dW (Cout,Cin) = sum_b dy[b] . x[b]^T as plain library GEMMs: batched GEMM + sum over the batch, or one GEMM
+    over (batch x positions) when the batched form hits a slow library heuristic (256x256x375: 97 vs 25 us).  The
+    choice is timed once per shape outside graph capture and cached."""
+    B, Cout, P = dy3.shape
+    Cin = x3.shape[1]
+    forms = {"bmm": lambda: torch.bmm(dy3, x3.transpose(1, 2)).sum(0),
+             "flat": lambda: torch.matmul(dy3.transpose(0, 1).reshape(Cout, B * P),
+                                          x3.transpose(0, 1).reshape(Cin, B * P).t())}
+    key = (B, Cin, Cout, P)
+    form = _wgrad_form.get(key)
+    if form is None:
+        if torch.cuda.is_current_stream_capturing():
+            return forms["bmm"]()  # no timing inside a capture; decided at the next eager call
+        best = None
+        for name, fn in forms.items():
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                fn()
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if best is None or t < best[0]:
+                best = (t, name)
+        form = _wgrad_form[key] = best[1]
+    return forms[form]()
+
+
+class LibraryGemmConv(Function):
+    """1x1 convolution of a deep, short layer (>= 64 channels on both sides, < 65536 positions: SetAbstraction 4 and the
+    coarse FeaturePropagation stages) as three plain library GEMMs.  These are small MFMA-bound GEMMs that rocBLAS does
+    at ~80 TFLOP/s, twice what csrc/gemm.hip reaches at this size; what is avoided is the convolution library's
+    weight-gradient path, which wraps an implicit-GEMM kernel in NCHW<->NHWC transposes (60-70 us per layer).
+    x (B,Cin,*spatial) fp32 contiguous, weight (Cout,Cin,1[,1]), no bias."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = x.contiguous()
+        B, Cin = x.shape[0], x.shape[1]
+        Cout = weight.shape[0]
+        w2 = weight.reshape(Cout, Cin)
+        # bmm with the weight expanded along the batch (stride 0): torch.matmul(2-d, 3-d) would fold the batch into one
+        # GEMM by way of a transposed copy of x
+        y = torch.bmm(w2.unsqueeze(0).expand(B, Cout, Cin), x.view(B, Cin, -1))
+        ctx.save_for_backward(x, w2)
+        ctx.wshape = tuple(weight.shape)
+        return y.view((B, Cout) + tuple(x.shape[2:]))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2 = ctx.saved_tensors
+        B, Cin = x.shape[0], x.shape[1]
+        dy3 = dy.contiguous().view(B, w2.shape[0], -1)
+        dx = (torch.bmm(w2.t().unsqueeze(0).expand(B, Cin, w2.shape[0]), dy3).view(x.shape)
+              if ctx.needs_input_grad[0] else None)
+        dw = _library_wgrad(dy3, x.view(B, Cin, -1)).view(ctx.wshape) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def library_gemm_conv(x, weight):
+    return LibraryGemmConv.apply(x, weight)
+
+
 class CrossEntropyMean(Function):
     """nn.CrossEntropyLoss()(logits.transpose(1, 2).reshape(-1, C), target.flatten()) -- default arguments: mean
     over the targets != ignore_index -- on the channel-major logits (B, C, N) as the model returns them

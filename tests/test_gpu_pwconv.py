@@ -1,6 +1,7 @@
 """Pointwise (1x1) convolution on fp32 MFMA (csrc/pwconv.hip) against torch's conv1d/conv2d, forward and
 backward, with an fp64 evaluation as the arbiter: the kernel may be no further from fp64 than a few times
 what torch's own fp32 kernel is."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -87,3 +88,28 @@ def test_model_blocks_route_1x1_convs_to_the_kernel():
     blk.train()
     ref = blk(x)
     assert torch.allclose(y, ref, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(8, 256, 256, (375,)), (4, 768, 256, (94,)), (2, 128, 192, (50, 32))])
+def test_library_gemm_conv_matches_torch_conv(shape):
+    """deep, short layers: the three-GEMM decomposition (ops.LibraryGemmConv) against nn.functional.conv, including the
+    once-per-shape choice of the weight-gradient form and its use under a later call"""
+    from amcontrast3d_amd import ops
+    B, ci, co, sp = shape
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, ci, *sp, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(co, ci, *([1] * len(sp)), generator=g) * 0.05).to(dev).requires_grad_(True)
+    go = torch.randn(B, co, *sp, generator=g).to(dev)
+    conv = torch.nn.functional.conv1d if len(sp) == 1 else torch.nn.functional.conv2d
+    yr = conv(x, w)
+    yr.backward(go)
+    want = (yr.detach(), x.grad.clone(), w.grad.clone())
+    for _ in range(2):  # first call times the two weight-gradient forms, the second uses the cached one
+        x.grad = w.grad = None
+        y = ops.library_gemm_conv(x, w)
+        y.backward(go)
+        for got, ref in zip((y.detach(), x.grad, w.grad), want):
+            assert got.shape == ref.shape
+            assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert (B, ci, co, int(np.prod(sp))) in ops._wgrad_form
