@@ -41,3 +41,54 @@ def test_knn_and_ambiguity_under_graph_replay():
         assert torch.equal(got[0], want[0]), it
         assert torch.equal(got[1], want[1]), it
         assert torch.equal(got[2], want[2]), it
+
+
+def test_flat_gradients_under_graph_replay():
+    """dist.FlatGradients (the N > 1 gradient buffer of bench.py): a captured forward + backward whose first node
+    zero-fills the flat buffer accumulates into the views in place, replay after replay, and gives the gradients of
+    the ordinary eager pass."""
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from amcontrast3d_amd import configs, dist as adist, synthetic
+    from openpoints.models import build_model_from_cfg
+    from openpoints.utils import EasyConfig
+    dev = torch.device(DEV)
+    torch.manual_seed(0)
+    c = EasyConfig()
+    c.update(configs.model_cfg("S", dropout=0, width=16))
+    model = build_model_from_cfg(c).to(dev).train()
+    for m in model.modules():  # frozen statistics bookkeeping: every pass sees the same buffers
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.momentum = 0.0
+    data = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.make_batch(2, 2048, first_id=60).items()}
+    probe = torch.randn(2, 13, 2048, generator=torch.Generator().manual_seed(2)).to(dev)
+    params = list(model.parameters())
+
+    def fwd_bwd():
+        (model(data)[0] * probe).sum().backward()
+
+    fwd_bwd()
+    want = [p.grad.clone() for p in params]
+    flat = adist.FlatGradients(params)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            flat.zero()
+            fwd_bwd()
+        torch.cuda.synchronize()
+        assert flat.intact()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            flat.zero()
+            fwd_bwd()
+    torch.cuda.synchronize()
+    for it in range(3):
+        flat.flat.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        assert flat.intact()
+        for p, w in zip(params, want):
+            err = float((p.grad - w).norm() / (w.norm() + 1e-12))
+            assert err <= 3e-2, (it, err)  # arg-max routing of the max-pool flips on near-ties (test_gpu_model.py)
+        assert bool(torch.isfinite(flat.flat).all())
