@@ -6,6 +6,7 @@ The reference's loops are welded to its dataset readers, transform registry, tqd
 files; what they compute is restated here on arrays the caller already holds:
 
     voxel_parts                 main_AA.py:91-116 (`load_data`, multi_voxel mode) + dataset/data_util.py:92-143
+    voxel_representatives       main_AA.py:99-107, 666 (`load_data`, nearest_neighbor mode)
     boundary_mask               main_AA.py:470-476, 628-633 (posmask_searching + the 0 < n+ < nsample test)
     scatter_mean                torch_scatter.scatter(..., reduce='mean') of main_AA.py:662 (package absent here)
     validate_boundary_inner     main_AA.py:431-513
@@ -47,6 +48,26 @@ def voxel_parts(coord, voxel_size, rng=None):
         rng.shuffle(part)
         parts.append(part)
     return parts
+
+
+def voxel_representatives(coord, voxel_size, rng=None):
+    """test_mode 'nearest_neighbor' (main_AA.py:99-107): ONE sub-cloud holding a random point of every occupied voxel;
+    afterwards every point takes the logits of its voxel's representative (main_AA.py:666).
+    Returns (part, expand): the representatives' indices (shuffled) and, for every point of the cloud, the position in
+    `part` of its voxel's representative -- test_cloud_boundary_inner(..., parts=[part], expand=expand)."""
+    cells = np.floor(np.asarray(coord) / np.asarray(voxel_size)).astype(np.uint64)
+    key = _fnv64(cells)
+    order = np.argsort(key)
+    _, voxel_of_sorted, count = np.unique(key[order], return_inverse=True, return_counts=True)
+    first = np.cumsum(np.insert(count, 0, 0)[:-1])
+    rng = np.random.default_rng(0) if rng is None else rng
+    pick = order[first + rng.integers(0, count.max(), count.size) % count]  # one point per voxel, voxel order
+    perm = rng.permutation(count.size)
+    part = pick[perm]
+    where = np.argsort(perm)                       # voxel -> position of its representative in `part`
+    expand = np.empty(len(key), dtype=np.int64)
+    expand[order] = where[voxel_of_sorted]         # undo the sort by hash
+    return part, expand
 
 
 @torch.no_grad()
@@ -117,7 +138,7 @@ def validate_boundary_inner(model, batches, num_classes, ignore_index, nsample, 
 
 @torch.no_grad()
 def test_cloud_boundary_inner(model, coord, feat, label, parts, num_classes, ignore_index, nsample,
-                              make_input=None, miou_B_I=True, batch=8):
+                              make_input=None, miou_B_I=True, batch=8, expand=None):
     """One whole cloud (room): every sub-cloud of `parts` goes through the model, overlapping logits are averaged per
     point, and three confusion matrices are filled -- all points (voted prediction), boundary and inner points (per
     sub-cloud predictions, as the reference keeps them: main_AA.py:634-641, 651-657, 671-676).
@@ -130,6 +151,7 @@ def test_cloud_boundary_inner(model, coord, feat, label, parts, num_classes, ign
     cloud), so the logits are the same, while the latency-bound FPS chain (8 ms for 24 k points on ONE workgroup) runs
     for `batch` clouds side by side.  Sub-clouds of a voxel partition all have one point per voxel, hence equal size;
     ragged parts fall back to single calls.
+    expand: with the single sub-cloud of voxel_representatives, the per-point index into it ('nearest_neighbor' mode).
     Returns dict(pred, logits, cm, cm_b, cm_i)."""
     model.eval()
     dev = label.device
@@ -162,7 +184,11 @@ def test_cloud_boundary_inner(model, coord, feat, label, parts, num_classes, ign
                 pb.append(pred_part[b]); pi.append(pred_part[~b]); tb.append(label_part[b]); ti.append(label_part[~b])
     flat = torch.cat([lg.transpose(1, 2).reshape(-1, num_classes) for lg in all_logits], dim=0)
     index = torch.from_numpy(np.hstack(parts)).to(dev)
-    voted = scatter_mean(flat, index, size=label.shape[0]) if len(parts) > 1 else flat[torch.argsort(index)]
+    if expand is not None:
+        assert len(parts) == 1, "expand belongs to the single sub-cloud of voxel_representatives"
+        voted = flat[torch.from_numpy(np.asarray(expand)).to(dev)]
+    else:
+        voted = scatter_mean(flat, index, size=label.shape[0]) if len(parts) > 1 else flat[torch.argsort(index)]
     pred = voted.argmax(dim=1)
     cm.update(pred, label)
     if miou_B_I:

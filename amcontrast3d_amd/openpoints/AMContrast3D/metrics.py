@@ -23,3 +23,49 @@ def posmask_searching(xyz, target, nsample, num_classes, ignore_index):
     neighbor_idx = neighbor_idx[..., 1:].contiguous()  # drop the self match
     posmask = ops.posmask_from_labels(target.to(torch.int32).contiguous(), neighbor_idx)
     return posmask, neighbor_idx
+
+
+@torch.no_grad()
+def ambiguity_metrics(p, label, pred, posmask_test, nsample_test, neighbor_idx_test, cctype, ccbeta, vis,
+                      cm_0, cm_low, cm_semi, cm_high, cm_1, nu):
+    """Accuracy of a prediction per ambiguity level (AMContrast3D/metrics.py:33-157; called per test cloud when
+    ambiguity_args.action is set, examples/segmentation/main_AA.py:686-702).
+
+    a_i of every point (the fused kernels of AEF.ambiguity_function) is binned by floor(10 a + 1) in 1..11; five
+    groups -- a = 0, low (< nu), semi (the nu bin), high, a = 1 -- get a confusion matrix each (the caller's
+    cm_0 .. cm_1 are updated, as in the reference).  Returns, like the reference:
+        ambiguity_soft (m), ratio {bin: accuracy}, ambiguity_count [5 shares in %], ratio_low_semi_high (the constant
+        [1.0] * 5 the reference returns), cls {class: [5 shares in % of that class]}, and the rounded mIoU / mAcc / OA
+        lists plus per-class counts of the five matrices.
+    The reference prints these as it goes; this returns them only.  Its per-class thresholds are the literal bins 6
+    and 11 (S3DIS nu = 0.5) regardless of `nu`; kept."""
+    from openpoints.utils import get_mious
+    from .AEF.ambiguity import ambiguity_function
+    ambiguity_soft, ambiguity_count = ambiguity_function(p, posmask_test, nsample_test, neighbor_idx_test, cctype,
+                                                         ccbeta, vis, nu)
+    label, pred = label.reshape(-1), pred.reshape(-1)
+    mapping = torch.floor(ambiguity_soft * 10 + 1)
+    nu_m = nu * 10 + 1
+    groups = [mapping == 1, (1 < mapping) & (mapping < nu_m), mapping == nu_m, (nu_m < mapping) & (mapping < 11),
+              mapping == 11]
+    mious, maccs, oas, counts = [], [], [], []
+    for cm, g in zip((cm_0, cm_low, cm_semi, cm_high, cm_1), groups):
+        cm.update(pred[g], label[g])
+        miou, macc, oa, _, _ = get_mious(cm.tp, cm.union, cm.count)
+        mious.append(round(miou, 2)); maccs.append(round(macc, 2)); oas.append(round(oa, 2))
+        counts.append(cm.count.tolist())
+    # accuracy per bin: one bincount over bin * correct (bin 0 collects the wrong predictions)
+    bins = mapping.long()
+    total = torch.bincount(bins, minlength=12)
+    right = torch.bincount(bins * (pred == label).long(), minlength=12)
+    total_l, right_l = total.tolist(), right.tolist()
+    ratio = {float(k): right_l[k] / total_l[k] for k in range(1, 12) if total_l[k] > 0}
+    cls = {}
+    classes = torch.unique(label)
+    lab_bins = torch.bincount(label * 12 + bins, minlength=(int(classes.max()) + 1) * 12).view(-1, 12).tolist()
+    for c in classes.tolist():
+        row = lab_bins[c]
+        n = sum(row)
+        shares = [row[1], sum(row[2:6]), row[6], sum(row[7:11]), row[11]]
+        cls[c] = [round(s / n * 100, 2) for s in shares]
+    return (ambiguity_soft, ratio, ambiguity_count, [1.0, 1.0, 1.0, 1.0, 1.0], cls, mious, maccs, oas, counts)

@@ -10,7 +10,7 @@ CPU restatement of the reference's evaluation arithmetic around the hot path (SU
                              here; its documented mean is sum / max(count, 1) per index
     whole-cloud test loop    examples/segmentation/main_AA.py:556-684 (one cloud)
 
-Pinned by tests/golden/eval_S_room.npz, recorded from the reference's own model (eval mode), ConfusionMatrix,
+Pinned by tests/golden/eval_w8_room.npz, recorded from the reference's own model (eval mode), ConfusionMatrix,
 get_mious, posmask_searching and voxelize (oracle/gen_golden.py eval).  examples/segmentation/main_AA.py itself cannot
 be imported in the build container (wandb / torch_scatter / tensorboard missing), so its loop body is restated from
 the text and only its ingredients are pinned: "loop parity unpinned beyond its ingredients".
@@ -125,3 +125,26 @@ def test_cloud(sd, cfg, coord, feat, label, parts, num_classes, ignore_index, ns
             "cm": confusion(pred, label, num_classes, ignore_index),
             "cm_b": confusion(np.concatenate(pb), np.concatenate(tb), num_classes, ignore_index),
             "cm_i": confusion(np.concatenate(pi), np.concatenate(ti), num_classes, ignore_index)}
+
+
+def ambiguity_metrics(p, label, pred, nsample, num_classes, ignore_index, beta, nu):
+    """AMContrast3D/metrics.py:33-157 for cctype Method2: bins, five confusion matrices, accuracy per bin and the
+    per-class shares; the a_i come from model_ref.ambiguity (AEF/ambiguity.py:11-71)."""
+    posmask, nidx = posmask_searching(p, label, nsample, num_classes, ignore_index)
+    a = model_ref.ambiguity(torch.as_tensor(p, dtype=torch.float32), torch.from_numpy(posmask), torch.from_numpy(nidx),
+                            beta).numpy()
+    mapping = np.floor(a * np.float32(10) + np.float32(1)).astype(np.int64)
+    nu_m = nu * 10 + 1
+    groups = [mapping == 1, (1 < mapping) & (mapping < nu_m), mapping == nu_m, (nu_m < mapping) & (mapping < 11), mapping == 11]
+    mats = [confusion(pred[g], label[g], num_classes, ignore_index) for g in groups]
+    ratio = {}
+    for k in np.unique(mapping):
+        sel = mapping == k
+        ratio[float(k)] = float((pred[sel] == label[sel]).sum()) / float(sel.sum())
+    cls = {}
+    for c in np.unique(label):
+        mc = mapping[label == c]
+        n = len(mc)
+        cls[int(c)] = [round(float(s) / n * 100, 2) for s in
+                       ((mc == 1).sum(), ((1 < mc) & (mc < 6)).sum(), (mc == 6).sum(), ((6 < mc) & (mc < 11)).sum(), (mc == 11).sum())]
+    return {"a": a, "mapping": mapping, "mats": mats, "ratio": ratio, "cls": cls}

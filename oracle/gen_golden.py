@@ -312,8 +312,22 @@ def run_eval_case(name="eval_w8_room", n_room=5000, voxel=0.06, width=8, nsample
         out[f"mious/{tag}"] = np.array([miou, macc, oa], dtype=np.float64)
         out[f"ious/{tag}"], out[f"accs/{tag}"] = ious, accs
         out[f"all_metrics/{tag}"] = np.array(m.all_metrics()[:3], dtype=np.float64)
+    # ---- accuracy per ambiguity level (main_AA.py:686-702 with ambiguity_args.action) on the whole cloud ----------
+    from openpoints.AMContrast3D.metrics import ambiguity_metrics
+    p_all = torch.from_numpy(coord)
+    posmask_test, nidx_test = posmask_searching(p_all, label, nsample, num_classes, ignore_index)
+    cms = [ConfusionMatrix(num_classes=num_classes, ignore_index=ignore_index) for _ in range(5)]
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):  # the reference prints every table
+        a_soft, ratio, a_count, ratio_lsh, cls, l_miou, l_macc, l_oa, l_count = ambiguity_metrics(
+            p_all, label, pred, posmask_test, nsample, nidx_test, "Method2", 0.04, False, *cms, 0.5)
+    out["amb/a"] = a_soft.numpy().astype(np.float32)
+    for j, m in enumerate(cms):
+        out[f"amb/cm/{j}"] = m.value.numpy().copy()
+    amb = {"ratio": {str(k): v for k, v in ratio.items()}, "count": list(a_count), "ratio_low_semi_high": ratio_lsh,
+           "cls": {str(k): v for k, v in cls.items()}, "miou": l_miou, "macc": l_macc, "oa": l_oa, "count_per_class": l_count}
     meta = {"num_classes": num_classes, "ignore_index": ignore_index, "width": width, "n_room": n_room,
-            "parts": len(parts), "torch": torch.__version__}
+            "parts": len(parts), "torch": torch.__version__, "ambiguity_metrics": amb}
     out["meta"] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(f"{name}: parts={[len(p) for p in parts]} mIoU={out['mious/all'][0]:.3f} boundary pts={int(cm_b.value.sum())} "

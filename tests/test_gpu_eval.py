@@ -141,3 +141,43 @@ def test_validate_boundary_inner_against_oracle():
         want = eval_ref.get_mious(*eval_ref.tp_union_count(mat))
         np.testing.assert_allclose(out[5 * j:5 * j + 3], want[:3], rtol=2e-6)
         np.testing.assert_allclose(out[5 * j + 3], want[3], rtol=2e-6)
+
+
+def test_ambiguity_metrics_matches_reference_run():
+    """openpoints.AMContrast3D.metrics.ambiguity_metrics on the GPU against what the reference's own function returned
+    for the same cloud, labels and prediction (fixture meta 'ambiguity_metrics', amb/*)"""
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from openpoints.AMContrast3D.metrics import ambiguity_metrics, posmask_searching
+    from openpoints.utils import ConfusionMatrix
+    from test_oracle_eval import check_ambiguity_outputs
+    dev = torch.device("cuda:0")
+    g, m, _, _ = setup()
+    p = torch.from_numpy(g["coord"]).to(dev)
+    label, pred = torch.from_numpy(g["label"]).to(dev), torch.from_numpy(g["pred"]).to(dev)
+    nsample = int(g["nsample"])
+    posmask, nidx = posmask_searching(p, label, nsample, m["num_classes"], m["ignore_index"])
+    cms = [ConfusionMatrix(num_classes=m["num_classes"], ignore_index=m["ignore_index"]) for _ in range(5)]
+    a, ratio, count, ratio_lsh, cls, l_miou, l_macc, l_oa, l_count = ambiguity_metrics(
+        p, label, pred, posmask, nsample, nidx, "Method2", 0.04, False, *cms, 0.5)
+    check_ambiguity_outputs(a.cpu().numpy(), [c.value.cpu().numpy() for c in cms], ratio, cls,
+                            [l_miou, l_macc, l_oa, l_count], g, m, g["label"])
+    amb = m["ambiguity_metrics"]
+    assert ratio_lsh == amb["ratio_low_semi_high"]
+    np.testing.assert_allclose(list(count), amb["count"], atol=0.011)
+
+
+def test_nearest_neighbour_mode():
+    from amcontrast3d_amd import evaluate
+    dev = torch.device("cuda:0")
+    g, m, _, _ = setup()
+    model = build_model(m, g, dev)
+    label = torch.from_numpy(g["label"]).to(dev)
+    part, expand = evaluate.voxel_representatives(g["coord"], float(g["voxel"]), rng=np.random.default_rng(1))
+    r = evaluate.test_cloud_boundary_inner(model, g["coord"], g["feat"], label, [part], m["num_classes"], m["ignore_index"],
+                                           int(g["nsample"]), expand=expand)
+    single = evaluate.test_cloud_boundary_inner(model, g["coord"][part], g["feat"][part], label[torch.from_numpy(part).to(dev)],
+                                                [np.arange(len(part))], m["num_classes"], m["ignore_index"], int(g["nsample"]))
+    assert r["pred"].shape == label.shape
+    assert torch.equal(r["logits"], single["logits"][torch.from_numpy(expand).to(dev)])
+    assert int(r["cm"].total) == len(label) and int(r["cm_b"].total + r["cm_i"].total) == len(part)

@@ -130,3 +130,63 @@ def test_product_voxel_parts_and_scatter_mean_on_cpu():
     want = eval_ref.scatter_mean(src, index, 125)
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
     assert np.all(got[120:] == 0)
+
+
+def _amb_expected(g, m):
+    amb = m["ambiguity_metrics"]
+    return amb, [g[f"amb/cm/{j}"] for j in range(5)]
+
+
+def bin_edge_free(a, tol=1e-4):
+    """points whose bin floor(10 a + 1) cannot flip under a 1e-5 perturbation of a"""
+    t = a.astype(np.float64) * 10 + 1
+    return np.abs(t - np.round(t)) > tol
+
+
+def check_ambiguity_outputs(a, mats, ratio, cls, lists, g, m, label):
+    """shared by the CPU (oracle) and GPU (product) tests: everything ambiguity_metrics returns against the fixture;
+    counts may differ by the points sitting within 1e-5 of a bin edge (none in this fixture, asserted)"""
+    amb, ref_mats = _amb_expected(g, m)
+    assert np.abs(a - g["amb/a"]).max() <= 1e-5
+    moved = int((np.floor(a * np.float32(10) + np.float32(1)) != np.floor(g["amb/a"] * np.float32(10) + np.float32(1))).sum())
+    assert moved <= int((~bin_edge_free(g["amb/a"])).sum())
+    for got, ref in zip(mats, ref_mats):
+        assert np.abs(np.asarray(got) - ref).sum() <= 2 * moved
+    if moved == 0:
+        assert {float(k): v for k, v in amb["ratio"].items()} == pytest.approx(ratio, rel=1e-12)
+        assert {int(k): v for k, v in amb["cls"].items()} == {int(k): v for k, v in cls.items()}
+        if lists is not None:
+            for key, got in zip(("miou", "macc", "oa"), lists[:3]):
+                np.testing.assert_allclose(np.array(got, dtype=np.float64), np.array(amb[key], dtype=np.float64), atol=0.011,
+                                           equal_nan=True)
+            assert lists[3] == amb["count_per_class"]
+
+
+def test_ambiguity_metrics_restatement():
+    g, m, _, _ = setup()
+    r = eval_ref.ambiguity_metrics(g["coord"], g["label"], g["pred"], int(g["nsample"]), m["num_classes"],
+                                   m["ignore_index"], 0.04, 0.5)
+    lists = [[], [], [], []]
+    for mat in r["mats"]:
+        with np.errstate(invalid="ignore", divide="ignore"):
+            miou, macc, oa, _, _ = eval_ref.get_mious(*eval_ref.tp_union_count(mat))
+        lists[0].append(round(miou, 2)); lists[1].append(round(macc, 2)); lists[2].append(round(oa, 2))
+        lists[3].append(mat.sum(1).tolist())
+    check_ambiguity_outputs(r["a"], r["mats"], r["ratio"], r["cls"], lists, g, m, g["label"])
+    amb = m["ambiguity_metrics"]
+    assert amb["ratio_low_semi_high"] == [1.0] * 5 and len(amb["count"]) == 5
+    assert abs(sum(amb["count"]) - 100) < 0.05
+
+
+def test_product_voxel_representatives_on_cpu():
+    """'nearest_neighbor' test mode: one representative per occupied voxel, every point mapped to the representative
+    of its own voxel (main_AA.py:99-107, 666)"""
+    from amcontrast3d_amd import evaluate
+    g, m, parts, _ = setup()
+    coord, v = g["coord"], float(g["voxel"])
+    part, expand = evaluate.voxel_representatives(coord, v, rng=np.random.default_rng(1))
+    cells = np.floor(coord / v).astype(np.int64)
+    assert len(part) == len(parts[0]) == len(np.unique(cells, axis=0))            # one per occupied voxel
+    assert len(np.unique(cells[part], axis=0)) == len(part)
+    assert expand.shape == (len(coord),) and np.array_equal(cells[part[expand]], cells)
+    assert np.array_equal(expand[part], np.arange(len(part)))                       # a representative maps to itself
