@@ -137,8 +137,27 @@ def validate_boundary_inner(model, batches, num_classes, ignore_index, nsample, 
 
 
 @torch.no_grad()
+def boundary_masks_stacked(pos, labels, nsample, num_classes, ignore_index):
+    """boundary_mask for P equally sized clouds in one k-NN call: pos (P,n,3), labels (P,n) -> (P,n) bool.  The clouds
+    are the segments of one knnquery (offsets n, 2n, ...), which searches every segment on its own -- the same lists
+    as P separate calls (main_AA.py:628 calls posmask_searching per sub-cloud)."""
+    activate()
+    from openpoints.cpp.pointops.functions import pointops
+    from . import ops
+    P, n = labels.shape
+    xyz = pos.reshape(P * n, 3).contiguous()
+    target = labels.reshape(-1)
+    if ignore_index is not None:
+        target = torch.where(target == ignore_index, num_classes, target)
+    o = torch.arange(1, P + 1, dtype=torch.int32, device=xyz.device) * n
+    idx, _ = pointops.knnquery(nsample, xyz, xyz, o, o)
+    same = ops.posmask_from_labels(target.to(torch.int32).contiguous(), idx[..., 1:].contiguous()).sum(-1)
+    return torch.logical_and(0 < same, same < nsample).view(P, n)
+
+
+@torch.no_grad()
 def test_cloud_boundary_inner(model, coord, feat, label, parts, num_classes, ignore_index, nsample,
-                              make_input=None, miou_B_I=True, batch=8, expand=None):
+                              make_input=None, miou_B_I=True, batch=64, expand=None):
     """One whole cloud (room): every sub-cloud of `parts` goes through the model, overlapping logits are averaged per
     point, and three confusion matrices are filled -- all points (voted prediction), boundary and inner points (per
     sub-cloud predictions, as the reference keeps them: main_AA.py:634-641, 651-657, 671-676).
@@ -148,42 +167,62 @@ def test_cloud_boundary_inner(model, coord, feat, label, parts, num_classes, ign
     the height channel (the S3DIS feature_keys 'x,heights', cfgs/s3dis/default.yaml).
     batch: sub-clouds stacked per model call.  The reference feeds them one at a time (main_AA.py:575-611); in eval
     mode nothing couples the clouds of a batch (BatchNorm uses running statistics, FPS / ball query / 3-NN work per
-    cloud), so the logits are the same, while the latency-bound FPS chain (8 ms for 24 k points on ONE workgroup) runs
-    for `batch` clouds side by side.  Sub-clouds of a voxel partition all have one point per voxel, hence equal size;
-    ragged parts fall back to single calls.
+    cloud), so the logits are the same -- but the FPS chain is latency-bound, 8 ms for 24 k points on ONE workgroup
+    per cloud, and 5/6 of the model time at 8 clouds per call (scratch/eval_phases.py): stacking a whole room runs all
+    its chains side by side.  Sub-clouds of a voxel partition have one point per voxel, hence equal size; with the
+    default make_input they are also gathered and shifted on the GPU (one upload of the room instead of one per
+    sub-cloud) and their boundary masks come from one segmented k-NN call.  Ragged parts fall back to single calls.
     expand: with the single sub-cloud of voxel_representatives, the per-point index into it ('nearest_neighbor' mode).
     Returns dict(pred, logits, cm, cm_b, cm_i)."""
     model.eval()
     dev = label.device
     cm, cm_b, cm_i = _matrices(num_classes, ignore_index)
-    if make_input is None:
-        def make_input(coord_part, feat_part):
-            pos = torch.from_numpy(np.ascontiguousarray(coord_part, dtype=np.float32)).to(dev).unsqueeze(0)
-            cols = [torch.from_numpy(np.ascontiguousarray(feat_part, dtype=np.float32)).to(dev)] if feat_part is not None else []
-            x = torch.cat(cols + [pos[0, :, 2:3]], dim=1).t().contiguous().unsqueeze(0)
-            return {"pos": pos, "x": x}
-    all_logits, pb, pi, tb, ti = [], [], [], [], []
-    inputs = []
-    for part in parts:
-        coord_part = np.asarray(coord)[part]
-        coord_part = coord_part - coord_part.min(0)
-        inputs.append(make_input(coord_part, None if feat is None else np.asarray(feat)[part]))
     same_size = len({len(p) for p in parts}) == 1
     step = max(1, int(batch)) if same_size else 1
-    for j0 in range(0, len(parts), step):
-        chunk = inputs[j0:j0 + step]
-        data = chunk[0] if len(chunk) == 1 else {k: torch.cat([d[k] for d in chunk], dim=0) for k in chunk[0]}
-        logits, _ = model(data)
-        for j, d in enumerate(chunk):
-            lg = logits[j:j + 1]
-            all_logits.append(lg)
-            if miou_B_I:
-                label_part = label[torch.from_numpy(parts[j0 + j]).to(dev)]
-                b = boundary_mask(d["pos"][0], label_part, nsample, num_classes, ignore_index)
-                pred_part = lg.argmax(dim=1)[0]
-                pb.append(pred_part[b]); pi.append(pred_part[~b]); tb.append(label_part[b]); ti.append(label_part[~b])
-    flat = torch.cat([lg.transpose(1, 2).reshape(-1, num_classes) for lg in all_logits], dim=0)
     index = torch.from_numpy(np.hstack(parts)).to(dev)
+    all_logits, pb, pi, tb, ti = [], [], [], [], []
+
+    def split_by_boundary(pred_stack, label_stack, b):
+        pb.append(pred_stack[b]); pi.append(pred_stack[~b]); tb.append(label_stack[b]); ti.append(label_stack[~b])
+
+    if make_input is None and same_size:
+        # the room goes to the GPU once; sub-clouds are gathered, shifted to their minimum corner (in the array's own
+        # precision, as numpy does it at main_AA.py:578-579) and stacked there
+        idx = index.view(len(parts), -1)
+        room = torch.from_numpy(np.ascontiguousarray(coord)).to(dev)
+        room_f = None if feat is None else torch.from_numpy(np.ascontiguousarray(feat, dtype=np.float32)).to(dev)
+        for j0 in range(0, len(parts), step):
+            sel = idx[j0:j0 + step]
+            pos = room[sel]
+            pos = (pos - pos.amin(dim=1, keepdim=True)).float()
+            cols = ([room_f[sel]] if room_f is not None else []) + [pos[..., 2:3]]
+            data = {"pos": pos.contiguous(), "x": torch.cat(cols, dim=2).transpose(1, 2).contiguous()}
+            logits, _ = model(data)
+            all_logits.append(logits)
+            if miou_B_I:
+                split_by_boundary(logits.argmax(dim=1), label[sel],
+                                  boundary_masks_stacked(data["pos"], label[sel], nsample, num_classes, ignore_index))
+    else:
+        if make_input is None:
+            def make_input(coord_part, feat_part):
+                pos = torch.from_numpy(np.ascontiguousarray(coord_part, dtype=np.float32)).to(dev).unsqueeze(0)
+                cols = [torch.from_numpy(np.ascontiguousarray(feat_part, dtype=np.float32)).to(dev)] if feat_part is not None else []
+                return {"pos": pos, "x": torch.cat(cols + [pos[0, :, 2:3]], dim=1).t().contiguous().unsqueeze(0)}
+        inputs = []
+        for part in parts:
+            coord_part = np.asarray(coord)[part]
+            inputs.append(make_input(coord_part - coord_part.min(0), None if feat is None else np.asarray(feat)[part]))
+        for j0 in range(0, len(parts), step):
+            chunk = inputs[j0:j0 + step]
+            data = chunk[0] if len(chunk) == 1 else {k: torch.cat([d[k] for d in chunk], dim=0) for k in chunk[0]}
+            logits, _ = model(data)
+            all_logits.append(logits)
+            if miou_B_I:
+                for j, d in enumerate(chunk):
+                    label_part = label[torch.from_numpy(parts[j0 + j]).to(dev)]
+                    b = boundary_mask(d["pos"][0], label_part, nsample, num_classes, ignore_index)
+                    split_by_boundary(logits[j].argmax(dim=0), label_part, b)
+    flat = torch.cat([lg.transpose(1, 2).reshape(-1, num_classes) for lg in all_logits], dim=0)
     if expand is not None:
         assert len(parts) == 1, "expand belongs to the single sub-cloud of voxel_representatives"
         voted = flat[torch.from_numpy(np.asarray(expand)).to(dev)]

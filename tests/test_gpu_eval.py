@@ -71,7 +71,16 @@ def test_whole_cloud_matches_reference_run():
     r1 = evaluate.test_cloud_boundary_inner(model, g["coord"], g["feat"], label, parts, m["num_classes"],
                                             m["ignore_index"], nsample, batch=1)
     assert float((r1["logits"] - r["logits"]).abs().max()) <= 1e-5 * scale
-    assert np.array_equal(r1["cm_b"].value.sum(1).cpu().numpy(), g["cm/boundary"].sum(1))
+    # the general path (caller-supplied make_input: host-side staging, per-cloud boundary masks) against the default
+    def make_input(coord_part, feat_part):
+        pos = torch.from_numpy(np.ascontiguousarray(coord_part, dtype=np.float32)).to(dev).unsqueeze(0)
+        x = torch.cat([torch.from_numpy(feat_part).to(dev), pos[0, :, 2:3]], 1).t().contiguous().unsqueeze(0)
+        return {"pos": pos, "x": x}
+    r2 = evaluate.test_cloud_boundary_inner(model, g["coord"], g["feat"], label, parts, m["num_classes"],
+                                            m["ignore_index"], nsample, make_input=make_input, batch=2)
+    assert float((r2["logits"] - r["logits"]).abs().max()) <= 1e-5 * scale
+    for tag in ("cm_b", "cm_i"):
+        assert torch.equal(r2[tag].value.sum(1), r[tag].value.sum(1))
     # boundary / inner membership is integer work on labels and neighbour indices: exact
     assert np.array_equal(r["cm_b"].value.sum(1).cpu().numpy(), g["cm/boundary"].sum(1))
     assert np.array_equal(r["cm_i"].value.sum(1).cpu().numpy(), g["cm/inner"].sum(1))
