@@ -59,6 +59,10 @@ def parse():
     ap.add_argument("--ddp", action="store_true",
                     help="N > 1: torch's SyncBatchNorm + DistributedDataParallel wrappers (eager), the literal "
                          "main_AA.py:146-152 recipe, as a cross-check of the two paths above")
+    ap.add_argument("--eval", action="store_true",
+                    help="instead of the train step: whole-room testing (amcontrast3d_amd.evaluate, the reference's "
+                         "test_boundary_inner) of a synthetic --room-points room; its own JSON line")
+    ap.add_argument("--room-points", type=int, default=300000)
     ap.add_argument("--cpu-baseline-batch", type=int, default=2,
                     help="clouds in the CPU sample (bounded: the full batch of 8 takes minutes on the host)")
     return ap.parse_args()
@@ -112,8 +116,67 @@ def cpu_baseline(cfg, model, batch_np, aargs_dict, points_per_step):
                       f"(oracle/model_ref.py + pointops_ref.c, OpenMP/torch {cores} threads; no optimizer step)"}
 
 
+def eval_main(args):
+    """one room = voxel partition into sub-clouds, eval-mode model on every sub-cloud,
+    mean vote per point, whole / boundary / inner confusion matrices.  A 'step' is one whole room."""
+    import numpy as np
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from amcontrast3d_amd import _lib, configs, evaluate, synthetic
+    from openpoints.models import build_model_from_cfg
+    from openpoints.utils import EasyConfig
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the product path)"
+    dev = torch.device("cuda", 0)
+    _lib.load()
+    torch.manual_seed(0)
+    c = EasyConfig(); c.update(configs.model_cfg(args.variant, dropout=0.5))
+    model = build_model_from_cfg(c).to(dev).eval()
+    room = synthetic.make_batch(1, args.room_points, first_id=900, voxel_size=0.02)
+    coord = room["pos"][0] - room["pos"][0].min(0)
+    feat = room["x"][0, :3].T.copy()
+    label_np = room["y"][0].astype(np.int64)
+    label = torch.from_numpy(label_np).to(dev)
+    parts = evaluate.voxel_parts(coord, 0.04)
+
+    def one_room():
+        return evaluate.test_cloud_boundary_inner(model, coord, feat, label, parts, 13, None, 24)
+
+    for _ in range(args.warmup):
+        one_room()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = one_room()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    npts = len(parts) * len(parts[0])
+    line = {"metric": "whole-room test sub-cloud points/sec (eval-mode model + vote + boundary/inner matrices)",
+            "value": round(npts / dt, 1), "unit": "points/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"PointNeXt-{args.variant}, one room of {args.room_points} points in {len(parts)} "
+                                   f"sub-clouds of {len(parts[0])} points (voxel 0.04), inputs on the host"},
+            "miou_whole_boundary_inner": [round(v, 3) for v in evaluate.summarize(r["cm"], r["cm_b"], r["cm_i"])[0:15:5]]}
+    if not args.no_cpu_baseline:
+        from oracle import eval_ref, pointops_ref
+        pointops_ref.build()
+        cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("AMC3D_CPU_THREADS", "16")))
+        pointops_ref.set_threads(cores); torch.set_num_threads(cores)
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        cfg = json.loads(json.dumps(configs.model_cfg(args.variant, dropout=0)))
+        t0 = time.perf_counter()
+        eval_ref.test_cloud(sd, cfg, coord, feat, label_np, parts[:2], 13, None, 24)
+        dtc = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": round(2 * len(parts[0]) / dtc, 1), "unit": "points/s", "cores": cores, "kind": "port",
+                                "sample": f"2 of the {len(parts)} sub-clouds, {dtc:.1f} s (oracle/eval_ref.py on model_ref.py + "
+                                          f"pointops_ref.c, {cores} threads)"}
+    print(json.dumps(line))
+
+
 def main():
     args = parse()
+    if args.eval:
+        return eval_main(args)
     from amcontrast3d_amd import _lib, configs, dist as adist, synthetic, timing
     rank, local, world = adist.init_from_env()
     if world != args.gpus and not (world == 1 and args.gpus == 1):

@@ -1,5 +1,6 @@
 """Whole-room evaluation throughput (amcontrast3d_amd.evaluate.test_cloud_boundary_inner) on the MI355X, with the
-oracle's CPU restatement timed on one sub-cloud beside it.  python scratch/eval_bench.py [room_points] [variant]"""
+per-sub-cloud forward and boundary-mask times (the CPU baseline is in `bench.py --eval`).
+python scratch/eval_bench.py [room_points] [variant]"""
 import json, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -44,13 +45,4 @@ out = {"room_points": n_room, "sub_clouds": len(parts), "points_per_sub_cloud": 
        "whole_room_s": round(dt_full, 4), "whole_room_without_boundary_split_s": round(dt_plain, 4),
        "sub_cloud_points_per_s": round(len(parts) * len(parts[0]) / dt_full), "forward_ms_per_sub_cloud": round(fwd * 1e3, 2),
        "boundary_mask_ms_per_sub_cloud": round(bm * 1e3, 2)}
-if "--cpu" in sys.argv:
-    from oracle import eval_ref, pointops_ref
-    pointops_ref.build(); pointops_ref.set_threads(16); torch.set_num_threads(16)
-    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    cfg = json.loads(json.dumps(configs.model_cfg(variant, dropout=0)))
-    t = time.perf_counter()
-    eval_ref.test_cloud(sd, cfg, coord, feat, room["y"][0].astype(np.int64), parts[:1], 13, None, 24)
-    dtc = time.perf_counter() - t
-    out["cpu_oracle_points_per_s"] = round(len(parts[0]) / dtc); out["cpu_sample"] = f"1 sub-cloud, {dtc:.1f} s, 16 threads"
 print(json.dumps(out))
