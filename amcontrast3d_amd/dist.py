@@ -120,8 +120,9 @@ class FlatGradients:
         return True
 
     def allreduce(self):
-        """average over ranks: one collective"""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        """average over ranks: one collective (also issued in a one-rank group, so that a single-GPU rehearsal
+        exercises the same RCCL call)"""
+        if not (dist.is_available() and dist.is_initialized()):
             return
         if dist.get_backend() == "nccl":
             dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
