@@ -1,0 +1,270 @@
+"""Building blocks of the PointNeXt backbone on the gfx950 kernels: the geometry / feature split.
+
+Classes the reference defines in openpoints/models/backbone/pointnext_AA.py and that keep their names, constructor
+keywords, attribute names and module nesting (hence state-dict keys) here:
+
+    LocalAggregation                 pointnext_AA.py:22-73
+    SetAbstraction                   :76-170
+    FeaturePropogation               :173-226   (spelling kept: it is in checkpoints' class paths)
+    InvResMLP / ResBlock             :229-308
+
+Every block has a coordinate-only ``plan*`` method (FPS picks, ball-query indices, relative positions, 3-NN indices
+and weights) and a ``forward`` that consumes such a plan, building it itself when none is handed in -- one code
+path whether or not a trainer prepares the geometry of the next batch ahead of time.  They are re-exported by
+pointnext_AA.py, where the reference's importers expect them.
+"""
+import logging
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from ..layers import (CHANNEL_MAP, create_act, create_convblock1d, create_convblock2d, create_grouper,
+                      furthest_point_sample, fused_first_conv, get_aggregation_feautres, random_sample,
+                      run_convblocks,
+                      three_interpolate, three_nn)
+
+
+def get_reduction_fn(reduction):
+    reduction = 'mean' if reduction.lower() == 'avg' else reduction
+    assert reduction in ['sum', 'max', 'mean']
+    if reduction == 'max':
+        return lambda x: torch.max(x, dim=-1, keepdim=False)[0]
+    if reduction == 'mean':
+        return lambda x: torch.mean(x, dim=-1, keepdim=False)
+    return lambda x: torch.sum(x, dim=-1, keepdim=False)
+
+
+class LocalAggregation(nn.Module):
+    """Grouped MLP over the neighbourhood of every point of one set, then pooling."""
+
+    def __init__(self, channels: List[int], norm_args={'norm': 'bn1d'}, act_args={'act': 'relu'},
+                 group_args={'NAME': 'ballquery', 'radius': 0.1, 'nsample': 16}, conv_args=None,
+                 feature_type='dp_fj', reduction='max', last_act=True, **kwargs):
+        super().__init__()
+        if kwargs:
+            logging.warning(f"kwargs: {kwargs} are not used in {__class__.__name__}")
+        channels[0] = CHANNEL_MAP[feature_type](channels[0])
+        last = len(channels) - 2
+        self.convs = nn.Sequential(*[
+            create_convblock2d(channels[i], channels[i + 1], norm_args=norm_args,
+                               act_args=None if (i == last and not last_act) else act_args, **(conv_args or {}))
+            for i in range(len(channels) - 1)])
+        self.grouper = create_grouper(group_args)
+        self.reduction = reduction.lower()
+        self.pool = get_reduction_fn(self.reduction)
+        self.feature_type = feature_type
+
+    @torch.no_grad()
+    def plan(self, p):
+        """coordinate-only part: neighbour indices and relative positions of the self query"""
+        if not hasattr(self.grouper, 'query'):
+            return None
+        idx = self.grouper.query(p, p)
+        return {'idx': idx, 'dp': self.grouper.relative_positions(idx, p, p)}
+
+    def forward(self, pf, geom=None):
+        p, f = pf
+        if geom is None:
+            geom = self.plan(p)
+        pre = fused_first_conv(self.convs, f, geom, self.feature_type)
+        if pre is not None:  # gather + concat + first conv in one MFMA kernel
+            y = run_convblocks(self.convs, None, pool_max=self.reduction == 'max', pre=pre)
+            return y if self.reduction == 'max' else self.pool(y)
+        dp, fj = self.grouper(p, p, f, geom=geom)
+        fj = get_aggregation_feautres(p, dp, f, fj, self.feature_type)
+        if self.reduction == 'max':
+            return run_convblocks(self.convs, fj, pool_max=True)
+        return self.pool(run_convblocks(self.convs, fj))
+
+
+class SetAbstraction(nn.Module):
+    """FPS -> ball-query grouping -> grouped MLP -> max over the neighbourhood
+    (-> + skip connection, ReLU).  With ``is_head`` it is the point-wise stem MLP."""
+
+    def __init__(self, in_channels, out_channels, layers=1, stride=1,
+                 group_args={'NAME': 'ballquery', 'radius': 0.1, 'nsample': 16},
+                 norm_args={'norm': 'bn1d'}, act_args={'act': 'relu'}, conv_args=None, sampler='fps',
+                 feature_type='dp_fj', use_res=False, is_head=False, **kwargs):
+        super().__init__()
+        self.stride = stride
+        self.is_head = is_head
+        self.all_aggr = not is_head and stride == 1
+        self.use_res = use_res and not self.all_aggr and not self.is_head
+        self.feature_type = feature_type
+
+        mid = out_channels // 2 if stride > 1 else out_channels
+        channels = [in_channels] + [mid] * (layers - 1) + [out_channels]
+        if not is_head:
+            channels[0] = CHANNEL_MAP[feature_type](channels[0])
+
+        if self.use_res:
+            self.skipconv = create_convblock1d(in_channels, channels[-1], norm_args=None, act_args=None) \
+                if in_channels != channels[-1] else nn.Identity()
+            self.act = create_act(act_args)
+
+        make = create_convblock1d if is_head else create_convblock2d
+        last = len(channels) - 2
+        self.convs = nn.Sequential(*[
+            make(channels[i], channels[i + 1], norm_args=None if is_head else norm_args,
+                 act_args=None if (i == last and (self.use_res or is_head)) else act_args, **(conv_args or {}))
+            for i in range(len(channels) - 1)])
+
+        if not is_head:
+            if self.all_aggr:
+                group_args.nsample = None
+                group_args.radius = None
+            self.grouper = create_grouper(group_args)
+            self.pool = lambda x: torch.max(x, dim=-1, keepdim=False)[0]
+            if sampler.lower() == 'fps':
+                self.sample_fn = furthest_point_sample
+            elif sampler.lower() == 'random':
+                self.sample_fn = random_sample
+
+    @torch.no_grad()
+    def plan_sample(self, p):
+        """FPS picks and the sub-sampled cloud (the serial part of the geometry)"""
+        if self.is_head or self.all_aggr:
+            return {'fps_idx': None, 'new_p': p}
+        idx = self.sample_fn(p, p.shape[1] // self.stride).long()
+        return {'fps_idx': idx, 'new_p': torch.gather(p, 1, idx.unsqueeze(-1).expand(-1, -1, 3))}
+
+    @torch.no_grad()
+    def plan_group(self, p, g):
+        """neighbour indices and relative positions around the sampled points (in place into g)"""
+        if not self.is_head and hasattr(self.grouper, 'query'):
+            g['idx'] = self.grouper.query(g['new_p'], p)
+            g['dp'] = self.grouper.relative_positions(g['idx'], g['new_p'], p)
+        return g
+
+    def plan(self, p):
+        """coordinate-only part: FPS picks, the sub-sampled cloud, neighbour indices, relative positions"""
+        return self.plan_group(p, self.plan_sample(p))
+
+    def forward(self, pf, geom=None):
+        p, f = pf
+        if self.is_head:
+            return p, run_convblocks(self.convs, f)
+        if geom is None:
+            geom = self.plan(p)
+        idx, new_p = geom['fps_idx'], geom['new_p']
+        fi = None
+        if self.use_res or 'df' in self.feature_type:
+            fi = torch.gather(f, -1, idx.unsqueeze(1).expand(-1, f.shape[1], -1))
+            if self.use_res:
+                identity = run_convblocks((self.skipconv,), fi)
+        pre = fused_first_conv(self.convs, f, geom, self.feature_type)
+        if pre is not None:  # gather + concat + first conv in one MFMA kernel
+            f = run_convblocks(self.convs, None, pool_max=True, pre=pre)
+        else:
+            dp, fj = self.grouper(new_p, p, f, geom=geom if 'idx' in geom else None)
+            fj = get_aggregation_feautres(new_p, dp, fi, fj, feature_type=self.feature_type)
+            f = run_convblocks(self.convs, fj, pool_max=True)  # conv/BN/ReLU stack + max over the neighbours
+        if self.use_res:
+            f = self.act(f + identity)
+        return new_p, f
+
+
+class FeaturePropogation(nn.Module):
+    """PointNet++ feature propagation: 3-NN inverse-distance interpolation of the
+    coarse features onto the fine set, concat with the skip features, point-wise MLP."""
+
+    def __init__(self, mlp, upsample=True, norm_args={'norm': 'bn1d'}, act_args={'act': 'relu'}):
+        super().__init__()
+        if not upsample:
+            self.linear2 = nn.Sequential(nn.Linear(mlp[0], mlp[1]), nn.ReLU(inplace=True))
+            mlp[1] *= 2
+            self.linear1 = nn.Sequential(*[
+                create_convblock1d(mlp[i], mlp[i + 1], norm_args=norm_args, act_args=act_args)
+                for i in range(1, len(mlp) - 1)])
+        else:
+            self.convs = nn.Sequential(*[
+                create_convblock1d(mlp[i], mlp[i + 1], norm_args=norm_args, act_args=act_args)
+                for i in range(len(mlp) - 1)])
+        self.pool = lambda x: torch.mean(x, dim=-1, keepdim=False)
+
+    @staticmethod
+    @torch.no_grad()
+    def plan(p1, p2):
+        """coordinate-only part: the 3 nearest coarse points of every fine point and their
+        inverse-distance weights (upsampling.py:97-100)"""
+        dist, idx = three_nn(p1, p2)
+        dist_recip = 1.0 / (dist + 1e-8)
+        weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+        return {'idx': idx, 'weight': weight}
+
+    def forward(self, pf1, pf2=None, geom=None):
+        if pf2 is None:  # global branch (not used by the segmentation decoder)
+            _, f = pf1
+            g = self.linear2(self.pool(f))
+            return self.linear1(torch.cat((f, g.unsqueeze(-1).expand(-1, -1, f.shape[-1])), dim=1))
+        p1, f1 = pf1
+        p2, f2 = pf2
+        if geom is None:
+            geom = self.plan(p1, p2)
+        up = three_interpolate(f2, geom['idx'], geom['weight'])
+        return run_convblocks(self.convs, up if f1 is None else torch.cat((f1, up), dim=1))
+
+
+class InvResMLP(nn.Module):
+    """LocalAggregation (C->C) + point-wise C->expansion*C->C with a residual."""
+
+    def __init__(self, in_channels, norm_args=None, act_args=None,
+                 aggr_args={'feature_type': 'dp_fj', "reduction": 'max'}, group_args={'NAME': 'ballquery'},
+                 conv_args=None, expansion=1, use_res=True, num_posconvs=2, less_act=False, **kwargs):
+        super().__init__()
+        self.use_res = use_res
+        mid_channels = int(in_channels * expansion)
+        self.convs = LocalAggregation([in_channels, in_channels], norm_args=norm_args,
+                                      act_args=act_args if num_posconvs > 0 else None, group_args=group_args,
+                                      conv_args=conv_args, **aggr_args, **kwargs)
+        if num_posconvs < 1:
+            channels = []
+        elif num_posconvs == 1:
+            channels = [in_channels, in_channels]
+        else:
+            channels = [in_channels, mid_channels, in_channels]
+        last = len(channels) - 2
+        self.pwconv = nn.Sequential(*[
+            create_convblock1d(channels[i], channels[i + 1], norm_args=norm_args,
+                               act_args=act_args if (i != last and not less_act) else None, **(conv_args or {}))
+            for i in range(len(channels) - 1)])
+        self.act = create_act(act_args)
+
+    def plan(self, p):
+        return self.convs.plan(p)
+
+    def forward(self, pf, geom=None):
+        p, f = pf
+        identity = f
+        f = run_convblocks(self.pwconv, self.convs([p, f], geom=geom))
+        if f.shape[-1] == identity.shape[-1] and self.use_res:
+            f += identity
+        return [p, self.act(f)]
+
+
+class ResBlock(nn.Module):
+    def __init__(self, in_channels, norm_args=None, act_args=None,
+                 aggr_args={'feature_type': 'dp_fj', "reduction": 'max'}, group_args={'NAME': 'ballquery'},
+                 conv_args=None, expansion=1, use_res=True, **kwargs):
+        super().__init__()
+        self.use_res = use_res
+        mid_channels = in_channels * expansion
+        self.convs = LocalAggregation([in_channels, in_channels, mid_channels, in_channels], norm_args=norm_args,
+                                      act_args=None, group_args=group_args, conv_args=conv_args, **aggr_args,
+                                      **kwargs)
+        self.act = create_act(act_args)
+
+    def plan(self, p):
+        return self.convs.plan(p)
+
+    def forward(self, pf, geom=None):
+        p, f = pf
+        identity = f
+        f = self.convs([p, f], geom=geom)
+        if f.shape[-1] == identity.shape[-1] and self.use_res:
+            f += identity
+        return [p, self.act(f)]
+
+
+_BLOCKS = {'InvResMLP': InvResMLP, 'ResBlock': ResBlock}
