@@ -1,9 +1,11 @@
-"""MODELS registry (models/build.py:1-13)."""
-from openpoints.utils import registry
+"""The model registry of the drop-in package.
 
-MODELS = registry.Registry('models')
+`MODELS` maps a class name to the class (the `@MODELS.register_module()` decorators of backbone/ and segmentation/
+fill it on import); `build_model_from_cfg(cfg, **default_args)` looks up `cfg.NAME` and calls the class with the
+remaining keys of `cfg` as keyword arguments -- the entry point examples/segmentation/main_AA.py:142 uses
+(reference: openpoints/models/build.py:1-13, openpoints/utils/registry.py:8-294).
+"""
+from openpoints.utils.registry import Registry
 
-
-def build_model_from_cfg(cfg, **kwargs):
-    """Build the model named by ``cfg.NAME``; remaining keys are ctor kwargs."""
-    return MODELS.build(cfg, **kwargs)
+MODELS = Registry('models')
+build_model_from_cfg = MODELS.build
