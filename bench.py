@@ -319,17 +319,21 @@ def main():
             main_s.wait_event(ev_b)
             f_rotate[lane]()
             ev_main.record(main_s)
+            skip = os.environ.get("AMC3D_SKIP", "")  # diagnostic: leave pipeline parts out (results go stale, timing only)
             with torch.cuda.stream(s_a[lane]):
                 s_a[lane].wait_event(ev_main)
-                f_a[lane]()
+                if "fps" not in skip:
+                    f_a[lane]()
                 ev_lane[lane].record(s_a[lane])
             with torch.cuda.stream(s_a2):
                 s_a2.wait_event(ev_main)
-                f_a2()
+                if "a2" not in skip:
+                    f_a2()
                 ev_a2.record(s_a2)
             with torch.cuda.stream(s_b):
                 s_b.wait_event(ev_main)
-                f_b()
+                if "geo" not in skip:
+                    f_b()
                 ev_b.record(s_b)
         f_feat()
         if flatg is not None:
