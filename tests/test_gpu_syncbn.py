@@ -24,9 +24,12 @@ def _free_port():
     return p
 
 
-def _case(pool, seed=0):
+def _case(pool, seed=0, odd=False):
     g = torch.Generator().manual_seed(seed)
-    shape = (4, 24, 50, 32) if pool else (4, 24, 1000)
+    if odd:  # lengths that are not multiples of 4 (scalar load paths), K = 20 neighbours
+        shape = (4, 24, 37, 20) if pool else (4, 24, 333)
+    else:
+        shape = (4, 24, 50, 32) if pool else (4, 24, 1000)
     x = torch.randn(shape, generator=g) * 2 + 0.5
     gamma = torch.rand(24, generator=g) + 0.5
     beta = torch.randn(24, generator=g) * 0.2
@@ -52,9 +55,10 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     out = {}
-    for pool in (False, True):
-        x, gamma, beta, gout = [t.to(dev) for t in _case(pool)]
-        half = slice(2 * rank, 2 * rank + 2)
+    for pool, odd in ((False, False), (True, False), (False, True), (True, True)):
+        x, gamma, beta, gout = [t.to(dev) for t in _case(pool, odd=odd)]
+        # ranks of unequal size in the odd cases: 3 + 1 clouds (element counts are exchanged, not assumed)
+        half = (slice(0, 3) if rank == 0 else slice(3, 4)) if odd else slice(2 * rank, 2 * rank + 2)
         bn = torch.nn.BatchNorm2d(24) if pool else torch.nn.BatchNorm1d(24)
         bn = bn.to(dev)
         y, dx, dg, db = _run_fused(ops.SyncBatchNormFused.apply, x[half].contiguous(), gamma, beta, gout[half].contiguous(),
@@ -75,7 +79,7 @@ def _worker(rank, world, port, q):
         if pool:
             yt = yt.max(dim=-1)[0]
         yt.backward(gout[half])
-        out[pool] = dict(
+        out[(pool, odd)] = dict(
             y_full=float((y - yf[half]).abs().max()), dx_full=float((dx - dxf[half]).abs().max()),
             dg_full=float((both[0] - dgf).abs().max() / dgf.abs().max()),
             db_full=float((both[1] - dbf).abs().max() / dbf.abs().max()),
@@ -103,11 +107,10 @@ def test_two_ranks_match_whole_batch_and_torch_syncbn():
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank in range(world):
-        for pool in (False, True):
-            r = res[rank][pool]
+        for key, r in res[rank].items():
             assert r.pop("tracked") == 1
             for k, v in r.items():
-                assert v <= TOL, (rank, pool, k, v)
+                assert v <= TOL, (rank, key, k, v)
 
 
 def _model_worker(rank, world, port, q):
