@@ -137,6 +137,8 @@ class ContrastHead(nn.Module):
                         self.ftype)
         neighbor_idx, posmask, ambiguity_soft = g['neighbor_idx'], g['posmask'], g['ambiguity']
         features = fetch_pxo(n, i, stageACE_list, self.ftype)[1]
+        if features.dtype != torch.float32:  # embeddings produced under autocast (use_amp): the loss is evaluated in fp32
+            features = features.float()
         k = neighbor_idx.shape[1]
         target_ai = ambiguity_soft
         output_ai = stageACE_list['ambiguity'][i].flatten() if 'ambiguity' in stageACE_list.keys() else None

@@ -228,3 +228,23 @@ def test_mm_precomputed_geometry_is_the_same_computation():
     logits1, stage1, r1 = model(d2)
     seg1 = criterion(logits1, data["y"], stage1, 13, None, aa)[0]
     assert torch.equal(logits0, logits1) and float(seg0) == float(seg1) and abs(r0 - r1) < 1e-9
+
+
+def test_bf16_autocast_step_runs():
+    """use_amp in the reference wraps model and criterion in autocast (examples/segmentation/main_AA.py:389-394;
+    BASELINE config 5 asks for bf16): the fused fp32 kernels step aside for the autocast-aware torch modules, the
+    searches and the loss stay fp32.  A smoke test of that fallback: finite, and close to the fp32 step."""
+    dev = torch.device("cuda:0")
+    model, criterion = build(configs.model_cfg("S", dropout=0), dev)
+    from amcontrast3d_amd import synthetic
+    aargs = easy(configs.ambiguity_args("s3dis"))
+    data = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.make_batch(2, 4096, first_id=5).items()}
+    logits32, stage = model(data)
+    loss32 = criterion(logits32, data["y"], stage, 13, None, aargs)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        logits, stage = model(data)
+        loss = criterion(logits.float(), data["y"], stage, 13, None, aargs)
+    loss.backward()
+    assert logits.dtype == torch.bfloat16
+    assert abs(float(loss) - float(loss32)) <= 2e-2 * abs(float(loss32))
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
