@@ -1,0 +1,84 @@
+"""The training loop around the hot path: `train_one_epoch` of examples/segmentation/main_AA.py:370-428, the direct
+caller of model + criterion, with the same arguments, the same per-iteration order of operations and the same return
+value (loss average, mIoU, mAcc, OA, per-class IoU / accuracy of the training predictions).
+
+What differs from the reference's loop, with identical arithmetic per batch:
+  * the coordinate-only half of every step (FPS, ball queries, 3-NN, the loss's k-NN / votes / ambiguities) is computed
+    for the NEXT batches on side queues while the current batch trains (pipeline.GeometryPrefetcher);
+  * the loss is accumulated on the device and read back once per epoch (the reference calls `loss.item()` every
+    iteration, main_AA.py:419, which drains the GPU each step); `print_freq` progress lines therefore show the loss of
+    the last *completed* read-back;
+  * no tqdm / wandb.
+Data: each batch is the reference's collated dict -- 'pos' (B,N,3), 'y' (B,N) or (B,N,1), and the keys named by
+`cfg.feature_keys` ('x', 'heights', ...) point-major, as its datasets produce them (dataset/data_util.py:177-189).
+"""
+import torch
+
+from . import activate
+from .pipeline import GeometryPrefetcher
+
+
+def get_features_by_keys(data, keys="pos,x"):
+    """(B,N,c1), (B,N,c2), ... -> (B, c1+c2+..., N) contiguous: the model's 'x' (dataset/data_util.py:177-189)"""
+    parts = [data[k] for k in keys.split(",")]
+    x = parts[0] if len(parts) == 1 else torch.cat(parts, dim=-1)
+    return x.transpose(1, 2).contiguous()
+
+
+def _to_device_batches(train_loader, cfg, device):
+    for data in train_loader:
+        for key in list(data.keys()):
+            if torch.is_tensor(data[key]):
+                data[key] = data[key].to(device, non_blocking=True)
+        data["y"] = data["y"].squeeze(-1) if data["y"].dim() == 3 else data["y"]
+        data["x"] = get_features_by_keys(data, cfg.feature_keys)
+        yield data
+
+
+def train_one_epoch(model, train_loader, criterion, optimizer, scheduler, scaler, epoch, cfg, prefetch_depth=2,
+                    device=None):
+    """One pass over `train_loader`.  cfg needs num_classes, ignore_index, ambiguity_args, feature_keys, use_amp,
+    step_per_update, grad_norm_clip (None / 0: off), sched_on_epoch -- the fields main_AA.py reads."""
+    activate()
+    from openpoints.utils import ConfusionMatrix
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    cm = ConfusionMatrix(num_classes=cfg.num_classes, ignore_index=cfg.ignore_index)
+    model.train()
+    head = getattr(criterion, "contrast_head", None)
+    batches = _to_device_batches(train_loader, cfg, device)
+    use_amp = bool(cfg.get("use_amp", False)) if hasattr(cfg, "get") else bool(getattr(cfg, "use_amp", False))
+    if head is not None and prefetch_depth > 0 and not use_amp:
+        batches = GeometryPrefetcher(batches, model, head, cfg.num_classes, cfg.ignore_index, cfg.ambiguity_args,
+                                     depth=prefetch_depth)
+    clip = cfg.get("grad_norm_clip", None) if hasattr(cfg, "get") else getattr(cfg, "grad_norm_clip", None)
+    loss_sum = torch.zeros((), dtype=torch.float64, device=device)
+    last_loss, n_batches, num_iter = None, 0, 0
+    for data in batches:
+        num_iter += 1
+        target = data["y"]
+        with torch.autocast("cuda", enabled=use_amp):
+            logits, stage = model(data)
+            loss = criterion(logits, target, stage, cfg.num_classes, cfg.ignore_index, cfg.ambiguity_args)
+        if use_amp:
+            scaler.scale(loss).backward()
+        else:
+            loss.backward()
+        if num_iter == cfg.step_per_update:
+            # (with use_amp the reference clips the still-scaled gradients, main_AA.py:402-409; kept as it is)
+            if clip is not None and clip > 0.:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), clip, norm_type=2)
+            num_iter = 0
+            if use_amp:
+                scaler.step(optimizer)
+                scaler.update()
+            else:
+                optimizer.step()
+            optimizer.zero_grad()
+            if not cfg.sched_on_epoch:
+                scheduler.step(epoch)
+        cm.update(logits.argmax(dim=1), target)
+        last_loss = loss.detach()
+        loss_sum += last_loss.double()
+        n_batches += 1
+    miou, macc, oa, ious, accs = cm.all_metrics()
+    return (float(loss_sum) / max(1, n_batches), miou, macc, oa, ious, accs)
