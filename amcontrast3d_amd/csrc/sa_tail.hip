@@ -10,13 +10,19 @@
 //                                                 i.e. ONE centroid's neighbours; a lane owns one output channel)
 // With that operand order a lane holds its channel's 16 of the 32 neighbour values (the other 16 sit in lane + 32),
 // so per-channel sums, the max over the neighbours and its arg-max are in-register reductions:
-//     mode 0  forward statistics of BN2          -> per-workgroup partial sums (fp64)
-//     mode 1  BN2 [+ReLU] + max over neighbours  -> pooled (B, C2, M) + 1-byte arg-max
+//     mode 0  forward: statistics of BN2 (per-workgroup partial sums, fp64) AND the raw max / min of every
+//             (b, c2, centroid) over its 32 neighbours.  BN2's affine and the ReLU are monotone in fp32 (every
+//             operation of ((x - mean) * invstd) * gamma + beta rounds monotonically), so
+//             max_k relu(bn2(z_k)) = relu(bn2(max_k z_k)) for gamma >= 0 and relu(bn2(min_k z_k)) for gamma < 0:
+//             the finalize kernel that turns the sums into mean / invstd also writes the pooled (B, C2, M) output
+//             from the raw extrema -- one recomputation pass forward, not two
 //     mode 2  backward statistics                -> sum dq, sum dq * xhat (dq: pooled gradient at the arg-max)
 //     mode 3  backward: dz = BN2-backward(dq) per element (dense), then on the same tile
 //               dx1 = W2^T . dz   (written, (B, C1, M, 32))   and   dW2 += dz . x1^T  (per-workgroup partials)
-// The recomputation is bit-identical in every pass (same instruction sequence), so the arg-max of mode 1 is the
-// arg-max modes 2 and 3 see.  BN1's own backward (from dx1) stays with bn.hip.
+// The recomputation is bit-identical in every pass (same instruction sequence).  Modes 2 and 3 find the arg-max
+// themselves: the first neighbour (ascending index, torch.max's rule) attaining the maximum of the normalised values --
+// exactly the element the reference's max-pool routes the gradient to, also when two raw values round to the same
+// normalised value or a ReLU clamps several to zero.  BN1's own backward (from dx1) stays with bn.hip.
 #include "common.h"
 
 namespace amc {
@@ -39,12 +45,10 @@ struct SatArgs {
     int relu2;
     // mode 0 / 2: per-workgroup partial sums, [c2][part][2] doubles
     double *partial;
-    // mode 1
-    float *pooled;
-    unsigned char *arg;
+    // mode 0: raw extrema over the neighbours, (B, C2, M) each
+    float *rmax, *rmin;
     // mode 2 / 3
     const float *dpooled;
-    const unsigned char *arg_in;
     const float *mean_dq, *mean_dqx;       // mode 3: per-channel means of dq and dq * xhat over all B*M*32 positions
     float *dx1;                            // mode 3: (B, C1, M, 32)
     float *partial_w;                      // mode 3: [part][C2][C1]
@@ -144,26 +148,15 @@ __global__ __launch_bounds__(256) void sat_kernel(SatArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s1 += acc[ct][r]; s2 += acc[ct][r] * acc[ct][r]; }
                 if (live) { acc_a[ct] += (double)s1; acc_b[ct] += (double)s2; }
-            }
-        }
-        if (MODE == 1) {
+                float mx = acc[ct][0], mn = acc[ct][0];
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                float best = -__builtin_inff();
-                int bs = 0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {  // ascending s within this half: strict '>' keeps the first maximum
-                    float y = sat_bn(acc[ct][r], m2[ct], is2[ct], g2[ct], b2[ct]);
-                    if (a.relu2) y = fmaxf(y, 0.f);
-                    if (y > best) { best = y; bs = (r & 3) + 8 * (r >> 2) + 4 * kh; }
-                }
-                const float ob = __shfl_xor(best, 32, 64);
-                const int os = __shfl_xor(bs, 32, 64);
-                if (ob > best || (ob == best && os < bs)) { best = ob; bs = os; }  // torch.max: first index on ties
+                for (int r = 1; r < 16; ++r) { mx = fmaxf(mx, acc[ct][r]); mn = fminf(mn, acc[ct][r]); }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mn = fminf(mn, __shfl_xor(mn, 32, 64));
                 const int c2 = ct * 32 + pl;
                 if (live && kh == 0 && c2 < C2) {
-                    a.pooled[((size_t)b * C2 + c2) * M + m] = best;
-                    a.arg[((size_t)b * C2 + c2) * M + m] = (unsigned char)bs;
+                    a.rmax[((size_t)b * C2 + c2) * M + m] = mx;
+                    a.rmin[((size_t)b * C2 + c2) * M + m] = mn;
                 }
             }
         }
@@ -173,7 +166,20 @@ __global__ __launch_bounds__(256) void sat_kernel(SatArgs a)
                 const int c2 = ct * 32 + pl;
                 const bool ok = live && c2 < C2;
                 const float gq = ok ? a.dpooled[((size_t)b * C2 + c2) * M + m] : 0.f;
-                const int as = ok ? (int)a.arg_in[((size_t)b * C2 + c2) * M + m] : 0;
+                // arg-max of the forward max-pool: first neighbour attaining the maximum of [relu](bn2(z))
+                float best = -__builtin_inff();
+                int as = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {  // ascending s within this half: strict '>' keeps the first maximum
+                    float y = sat_bn(acc[ct][r], m2[ct], is2[ct], g2[ct], b2[ct]);
+                    if (a.relu2) y = fmaxf(y, 0.f);
+                    if (y > best) { best = y; as = (r & 3) + 8 * (r >> 2) + 4 * kh; }
+                }
+                {
+                    const float ob = __shfl_xor(best, 32, 64);
+                    const int os = __shfl_xor(as, 32, 64);
+                    if (ob > best || (ob == best && os < as)) { best = ob; as = os; }  // torch.max: first index on ties
+                }
                 const bool owner = ok && ((as >> 2) & 1) == kh;       // the half that holds neighbour `as`
                 const int rstar = (as & 3) + 4 * (as >> 3);
                 if (MODE == 2) {
@@ -292,9 +298,13 @@ __global__ __launch_bounds__(256) void sat_finalize_kernel(int C2, int nparts, d
                                                            float *__restrict__ o0, float *__restrict__ o1,
                                                            float *__restrict__ o2, float *__restrict__ o3,
                                                            float *__restrict__ running_mean, float *__restrict__ running_var,
-                                                           long long *__restrict__ tracked)
+                                                           long long *__restrict__ tracked, int B, int M, int relu2,
+                                                           const float *__restrict__ gamma2, const float *__restrict__ beta2,
+                                                           const float *__restrict__ rmax, const float *__restrict__ rmin,
+                                                           float *__restrict__ pooled)
 {
     __shared__ double s_a[4], s_b[4];
+    __shared__ float s_stat[2];
     const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
     for (int k = threadIdx.x; k < nparts; k += 256) {
@@ -304,29 +314,43 @@ __global__ __launch_bounds__(256) void sat_finalize_kernel(int C2, int nparts, d
     for (int s = 32; s >= 1; s >>= 1) { s1 += __shfl_xor(s1, s, 64); s2 += __shfl_xor(s2, s, 64); }
     if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = s1; s_b[threadIdx.x >> 6] = s2; }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    s1 = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
-    s2 = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
-    if (backward) {  // o0 = dbeta = sum dq, o1 = dgamma = sum dq xhat, o2 / o3 = their means
-        o0[c] = (float)s1; o1[c] = (float)s2; o2[c] = (float)(s1 / count); o3[c] = (float)(s2 / count);
-        return;
+    if (threadIdx.x == 0) {
+        s1 = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
+        s2 = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
+        if (backward) {  // o0 = dbeta = sum dq, o1 = dgamma = sum dq xhat, o2 / o3 = their means
+            o0[c] = (float)s1; o1[c] = (float)s2; o2[c] = (float)(s1 / count); o3[c] = (float)(s2 / count);
+        } else {
+            const double mu = s1 / count;
+            double var = s2 / count - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const float mf = (float)mu, vu = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+            const float isf = (float)(1.0 / sqrt(var + (double)eps));
+            o0[c] = mf; o1[c] = isf; o2[c] = vu;
+            s_stat[0] = mf; s_stat[1] = isf;
+            if (running_mean && momentum >= 0.f) {
+                running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * mf;
+                running_var[c] = running_var[c] * (1.f - momentum) + momentum * vu;
+                if (c == 0 && tracked) *tracked += 1;
+            }
+        }
     }
-    const double mu = s1 / count;
-    double var = s2 / count - mu * mu;
-    if (var < 0.0) var = 0.0;
-    const float mf = (float)mu, vu = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
-    o0[c] = mf; o1[c] = (float)(1.0 / sqrt(var + (double)eps)); o2[c] = vu;
-    if (running_mean && momentum >= 0.f) {
-        running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * mf;
-        running_var[c] = running_var[c] * (1.f - momentum) + momentum * vu;
-        if (c == 0 && tracked) *tracked += 1;
+    if (backward || !pooled) return;
+    __syncthreads();
+    // the max-pool of the normalised values, from the raw extrema (monotonicity: see the file header)
+    const float mf = s_stat[0], isf = s_stat[1], g = gamma2[c], bt = beta2[c];
+    const float *src = g >= 0.f ? rmax : rmin;
+    for (int i = threadIdx.x; i < B * M; i += 256) {
+        const int bb = i / M, m = i - bb * M;
+        const size_t q = ((size_t)bb * C2 + c) * M + m;
+        float y = sat_bn(src[q], mf, isf, g, bt);
+        pooled[q] = relu2 ? fmaxf(y, 0.f) : y;
     }
 }
 
 static bool sat_aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 static bool sat_supported(int C1, int C2, int K) { return K == 32 && C1 >= 2 && C1 <= SAT_MAX_C1 && C1 % 2 == 0 && C2 >= 1 && C2 <= SAT_MAX_C2; }
-// the recomputation costs 2-4x the layer's MFMA work: it pays while the layer is HBM-bound (measured on MI355X:
-// 32 -> 64 channels faster fused, 64 -> 128 faster layer by layer)
+// the recomputation costs 2-3x the layer's MFMA work: it pays while the layer is HBM-bound (measured on MI355X:
+// 32 -> 64 channels faster fused, 64 -> 128 faster layer by layer, also with the single forward pass)
 static bool sat_pays(int C1, int C2) { return (long)C1 * C2 <= 32 * 64; }
 
 static size_t sat_lds(int C1, int C2, int mode)
@@ -365,21 +389,24 @@ AMC_API size_t amc3d_sa_tail_workspace_bytes(int B, int C1, int C2, int M)
 {
     if (B <= 0 || M <= 0) return 0;
     const size_t parts = (size_t)B * div_up(div_up(M, 4), SAT_TILES);
-    return parts * C2 * 2 * sizeof(double) + parts * (size_t)C2 * C1 * sizeof(float) + 4 * (size_t)C2 * sizeof(float) + 64;
+    const size_t shared = parts * C2 * 2 * sizeof(double);                                   // statistics partials
+    const size_t fwd = 2 * (size_t)B * C2 * M * sizeof(float);                               // raw max / min
+    const size_t bwd = parts * (size_t)C2 * C1 * sizeof(float) + 4 * (size_t)C2 * sizeof(float);  // dW2 partials, means
+    return shared + (fwd > bwd ? fwd : bwd) + 64;
 }
 
-// pooled (B,C2,M), arg (B,C2,M) = max_k [relu2](bn2(W2 . relu(bn1(y1)))) with batch statistics for BN2 (returned in
+// pooled (B,C2,M) = max_k [relu2](bn2(W2 . relu(bn1(y1)))) with batch statistics for BN2 (returned in
 // mean2, invstd2, var_unbiased2; running buffers updated when given, momentum < 0: not here)
 AMC_API int amc3d_sa_tail_forward(int B, int C1, int C2, int M, int K, const float *y1, const float *mean1,
                                   const float *invstd1, const float *gamma1, const float *beta1, const float *w2,
                                   const float *gamma2, const float *beta2, float eps2, float momentum2, int relu2,
-                                  float *pooled, unsigned char *arg, float *mean2, float *invstd2, float *var_unbiased2,
+                                  float *pooled, float *mean2, float *invstd2, float *var_unbiased2,
                                   float *running_mean2, float *running_var2, long long *tracked2, void *workspace,
                                   size_t workspace_bytes, void *stream_)
 {
     if (B <= 0 || M <= 0) return 0;
     if (!sat_supported(C1, C2, K) || !y1 || !mean1 || !invstd1 || !gamma1 || !beta1 || !w2 || !gamma2 || !beta2 || !pooled ||
-        !arg || !mean2 || !invstd2 || !var_unbiased2 || !workspace || !sat_aligned16(y1) ||
+        !mean2 || !invstd2 || !var_unbiased2 || !workspace || !sat_aligned16(y1) ||
         workspace_bytes < amc3d_sa_tail_workspace_bytes(B, C1, C2, M))
         return bad_arg("amc3d_sa_tail_forward: unsupported shape, null pointer or workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
@@ -387,12 +414,13 @@ AMC_API int amc3d_sa_tail_forward(int B, int C1, int C2, int M, int K, const flo
     SatArgs a{};
     a.B = B; a.C1 = C1; a.C2 = C2; a.M = M; a.y1 = y1; a.mean1 = mean1; a.invstd1 = invstd1; a.g1 = gamma1; a.b1 = beta1;
     a.w2 = w2; a.g2 = gamma2; a.b2 = beta2; a.relu2 = relu2; a.partial = (double *)workspace;
+    a.rmax = (float *)((char *)workspace + (size_t)groups * B * C2 * 2 * sizeof(double));
+    a.rmin = a.rmax + (size_t)B * C2 * M;
     sat_launch<0>(a, groups, stream);
     hipLaunchKernelGGL(sat_finalize_kernel, dim3(C2), dim3(256), 0, stream, C2, groups * B,
                        (double)B * (double)M * 32.0, eps2, momentum2, 0, (const double *)workspace, mean2, invstd2,
-                       var_unbiased2, (float *)nullptr, running_mean2, running_var2, tracked2);
-    a.mean2 = mean2; a.invstd2 = invstd2; a.pooled = pooled; a.arg = arg;
-    sat_launch<1>(a, groups, stream);
+                       var_unbiased2, (float *)nullptr, running_mean2, running_var2, tracked2, B, M, relu2, gamma2, beta2,
+                       (const float *)a.rmax, (const float *)a.rmin, pooled);
     return launch_status("amc3d_sa_tail_forward");
 }
 
@@ -401,12 +429,12 @@ AMC_API int amc3d_sa_tail_forward(int B, int C1, int C2, int M, int K, const flo
 AMC_API int amc3d_sa_tail_backward(int B, int C1, int C2, int M, int K, const float *y1, const float *mean1,
                                    const float *invstd1, const float *gamma1, const float *beta1, const float *w2,
                                    const float *mean2, const float *invstd2, const float *gamma2, const float *beta2,
-                                   int relu2, const float *dpooled, const unsigned char *arg, float *dx1, float *dw2,
+                                   int relu2, const float *dpooled, float *dx1, float *dw2,
                                    float *dgamma2, float *dbeta2, void *workspace, size_t workspace_bytes, void *stream_)
 {
     if (B <= 0 || M <= 0) return 0;
     if (!sat_supported(C1, C2, K) || !y1 || !mean1 || !invstd1 || !gamma1 || !beta1 || !w2 || !mean2 || !invstd2 || !gamma2 ||
-        !beta2 || !dpooled || !arg || !dx1 || !dw2 || !dgamma2 || !dbeta2 || !workspace || !sat_aligned16(y1) ||
+        !beta2 || !dpooled || !dx1 || !dw2 || !dgamma2 || !dbeta2 || !workspace || !sat_aligned16(y1) ||
         workspace_bytes < amc3d_sa_tail_workspace_bytes(B, C1, C2, M))
         return bad_arg("amc3d_sa_tail_backward: unsupported shape, null pointer or workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
@@ -418,11 +446,12 @@ AMC_API int amc3d_sa_tail_backward(int B, int C1, int C2, int M, int K, const fl
     SatArgs a{};
     a.B = B; a.C1 = C1; a.C2 = C2; a.M = M; a.y1 = y1; a.mean1 = mean1; a.invstd1 = invstd1; a.g1 = gamma1; a.b1 = beta1;
     a.w2 = w2; a.mean2 = mean2; a.invstd2 = invstd2; a.g2 = gamma2; a.b2 = beta2; a.relu2 = relu2;
-    a.dpooled = dpooled; a.arg_in = arg; a.partial = partial;
+    a.dpooled = dpooled; a.partial = partial;
     sat_launch<2>(a, groups, stream);
     hipLaunchKernelGGL(sat_finalize_kernel, dim3(C2), dim3(256), 0, stream, C2, groups * B,
                        (double)B * (double)M * 32.0, 0.f, -1.f, 1, (const double *)partial, dbeta2, dgamma2, means, means + C2,
-                       (float *)nullptr, (float *)nullptr, (long long *)nullptr);
+                       (float *)nullptr, (float *)nullptr, (long long *)nullptr, B, M, relu2, (const float *)nullptr,
+                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
     a.mean_dq = means; a.mean_dqx = means + C2; a.dx1 = dx1; a.partial_w = partial_w;
     sat_launch<3>(a, groups, stream);
     if (int st = launch_status("amc3d_sa_tail_backward")) return st;

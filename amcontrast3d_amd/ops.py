@@ -891,7 +891,6 @@ class SATail(Function):
         mean2 = torch.empty(C2, dtype=torch.float32, device=dev)
         invstd2, var2 = torch.empty_like(mean2), torch.empty_like(mean2)
         pooled = torch.empty(B, C2, M, dtype=torch.float32, device=dev)
-        arg = torch.empty(B, C2, M, dtype=torch.uint8, device=dev)
         work1, wb1 = _bn_ws(C1, dev)
         wb = int(lib.amc3d_sa_tail_workspace_bytes(B, C1, C2, M))
         work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
@@ -902,19 +901,19 @@ class SATail(Function):
                                           _ptr(work1), wb1, _stream(y1)), "bn_stats")
             _lib.check(lib.amc3d_sa_tail_forward(B, C1, C2, M, K, _ptr(y1), _ptr(mean1), _ptr(invstd1), _ptr(g1), _ptr(b1),
                                                  _ptr(w2f), _ptr(g2), _ptr(b2), float(eps2), mom2, int(bool(relu2)),
-                                                 _ptr(pooled), _ptr(arg), _ptr(mean2), _ptr(invstd2), _ptr(var2), rm2, rv2,
+                                                 _ptr(pooled), _ptr(mean2), _ptr(invstd2), _ptr(var2), rm2, rv2,
                                                  nbt2, _ptr(work), wb, _stream(y1)), "sa_tail_forward")
         if bn1 is not None and bn1.track_running_stats and bn1.running_mean is not None:
             bn_update_running(bn1, mean1, var1)
         if bn2 is not None and bn2.track_running_stats and bn2.running_mean is not None and bn2.momentum is None:
             bn_update_running(bn2, mean2, var2)  # cumulative average: its own launch
-        ctx.save_for_backward(y1, g1, b1, w2f, g2, b2, mean1, invstd1, mean2, invstd2, arg)
+        ctx.save_for_backward(y1, g1, b1, w2f, g2, b2, mean1, invstd1, mean2, invstd2)
         ctx.relu2, ctx.wshape = bool(relu2), tuple(w2.shape)
         return pooled
 
     @staticmethod
     def backward(ctx, dpooled):
-        y1, g1, b1, w2f, g2, b2, mean1, invstd1, mean2, invstd2, arg = ctx.saved_tensors
+        y1, g1, b1, w2f, g2, b2, mean1, invstd1, mean2, invstd2 = ctx.saved_tensors
         B, C1, M, K = y1.shape
         C2 = w2f.shape[0]
         dev = y1.device
@@ -932,7 +931,7 @@ class SATail(Function):
         with torch.cuda.device(dev), timing.span("sa_tail_backward", y1.numel() * 4 * 6 + dpooled.numel() * 10, flops):
             _lib.check(lib.amc3d_sa_tail_backward(B, C1, C2, M, K, _ptr(y1), _ptr(mean1), _ptr(invstd1), _ptr(g1), _ptr(b1),
                                                   _ptr(w2f), _ptr(mean2), _ptr(invstd2), _ptr(g2), _ptr(b2), int(ctx.relu2),
-                                                  _ptr(dpooled), _ptr(arg), _ptr(dx1), _ptr(dw2), _ptr(dg2), _ptr(db2),
+                                                  _ptr(dpooled), _ptr(dx1), _ptr(dw2), _ptr(dg2), _ptr(db2),
                                                   _ptr(work), wb, _stream(y1)), "sa_tail_backward")
             # BN1 + ReLU backward on the raw y1 (csrc/bn.hip)
             _lib.check(lib.amc3d_bn_backward(B, C1, M * K, 1, 1, _ptr(y1), _ptr(dx1), None, _ptr(mean1), _ptr(invstd1),

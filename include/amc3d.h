@@ -237,19 +237,21 @@ int amc3d_pointwise_conv_backward(int b, int cin, int cout, long P, const float 
 int amc3d_sa_tail_supported(int C1, int C2, int K);
 int amc3d_sa_tail_pays(int C1, int C2);  /* 1 where the fused tail is faster than the layer-by-layer kernels (HBM-bound widths) */
 size_t amc3d_sa_tail_workspace_bytes(int B, int C1, int C2, int M);
-/* pooled (B,C2,M), arg (B,C2,M) bytes; mean2 / invstd2 / var_unbiased2 (C2) are BN2's batch statistics; running
- * buffers of BN2 are updated when given (momentum2 < 0: left to the caller) */
+/* pooled (B,C2,M); mean2 / invstd2 / var_unbiased2 (C2) are BN2's batch statistics; running buffers of BN2 are
+ * updated when given (momentum2 < 0: left to the caller).  One recomputation pass: it emits the statistics and the
+ * raw max / min over the neighbours, from which the pooled output follows because BN's affine and the ReLU are
+ * monotone in fp32; the backward finds the arg-max itself (first neighbour attaining the maximum, torch.max's rule) */
 int amc3d_sa_tail_forward(int B, int C1, int C2, int M, int K, const float *y1, const float *mean1,
                           const float *invstd1, const float *gamma1, const float *beta1, const float *w2,
                           const float *gamma2, const float *beta2, float eps2, float momentum2, int relu2,
-                          float *pooled, unsigned char *arg, float *mean2, float *invstd2, float *var_unbiased2,
+                          float *pooled, float *mean2, float *invstd2, float *var_unbiased2,
                           float *running_mean2, float *running_var2, long long *num_batches_tracked2,
                           void *workspace, size_t workspace_bytes, void *stream);
 /* dx1 (B,C1,M,32) = gradient w.r.t. relu(bn1(y1)); dw2 (C2,C1) deterministic; dgamma2, dbeta2 (C2) */
 int amc3d_sa_tail_backward(int B, int C1, int C2, int M, int K, const float *y1, const float *mean1,
                            const float *invstd1, const float *gamma1, const float *beta1, const float *w2,
                            const float *mean2, const float *invstd2, const float *gamma2, const float *beta2,
-                           int relu2, const float *dpooled, const unsigned char *arg, float *dx1, float *dw2,
+                           int relu2, const float *dpooled, float *dx1, float *dw2,
                            float *dgamma2, float *dbeta2, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- training-mode BatchNorm fused with ReLU / neighbourhood max-pool ---------------------------
