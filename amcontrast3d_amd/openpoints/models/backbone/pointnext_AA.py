@@ -25,12 +25,6 @@ import torch
 import torch.nn as nn
 
 from ..build import MODELS
-from ..layers import (CHANNEL_MAP, create_act, create_convblock1d, create_convblock2d, create_grouper,
-                      furthest_point_sample, fused_first_conv, get_aggregation_feautres, random_sample,
-                      run_convblocks,
-                      three_interpolate, three_nn)
-
-
 from .pointnext_blocks import (_BLOCKS, FeaturePropogation, InvResMLP, LocalAggregation, ResBlock,  # noqa: F401
                                SetAbstraction, get_reduction_fn)
 

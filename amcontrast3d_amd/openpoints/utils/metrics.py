@@ -9,7 +9,6 @@ Integer work on the GPU (torch.bincount of true * C + pred); the matrix stays an
 One deliberate difference: `update` does not overwrite the caller's `pred` / `true` tensors where
 true == ignore_index (the reference's flatten() views make its in-place writes visible outside).
 """
-import numpy as np  # noqa: F401  (callers use the numpy arrays this returns)
 import torch
 
 
