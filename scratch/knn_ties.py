@@ -14,7 +14,7 @@ for k in (24, 4):
     wb = int(lib.amc3d_knnquery_workspace_bytes(n, n, k, 1))
     work = torch.zeros(wb, dtype=torch.uint8, device=dev)
     idx = torch.empty(n, k, dtype=torch.int32, device=dev); d2 = torch.empty(n, k, device=dev)
-    st = lib.amc3d_knnquery(n, k, n, 1, p.data_ptr(), p.data_ptr(), o.data_ptr(), o.data_ptr(), idx.data_ptr(), d2.data_ptr(), work.data_ptr(), wb, torch.cuda.current_stream().cuda_stream)
+    st = lib.amc3d_knnquery(n, k, n, 1, p.data_ptr(), p.data_ptr(), o.data_ptr(), o.data_ptr(), idx.data_ptr(), d2.data_ptr(), work.data_ptr(), wb, 0, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     print("k", k, "status", st, "fallback queries:", int(work[1024:1028].view(torch.int32)[0]), "of", n)
     gp = work[0:40].view(torch.float32)
