@@ -396,6 +396,16 @@ def main():
     dt = adist.max_over_ranks(dt, dev)
     final_loss = float(out["loss"].detach())
     assert flatg is None or flatg.intact(), "a parameter gradient left the flat all-reduce buffer"
+    # data-parallel sanity: after the timed steps every rank must hold the same weights (the gradient exchange is the
+    # only thing that keeps them equal: ranks see different scenes)
+    replicas_in_sync = None
+    if world > 1:
+        import torch.distributed as tdist
+        chk = torch.stack([p.detach().double().sum() for p in params] + [p.detach().double().abs().sum() for p in params])
+        lo, hi = chk.clone(), chk.clone()
+        tdist.all_reduce(lo, op=tdist.ReduceOp.MIN)
+        tdist.all_reduce(hi, op=tdist.ReduceOp.MAX)
+        replicas_in_sync = bool(torch.equal(lo, hi))
 
     if use_graph and overlap and rank == 0 and os.environ.get("AMC3D_TIMELINE"):
         # GPU start/end of every pipeline part relative to the step's first launch (HIP events around each replay)
@@ -518,6 +528,7 @@ def main():
                                                f"(t+2) | neighbourhood + loss geometry (t+1) | features (t)"
                                    if overlap_was else "none"},
             "loss": round(final_loss, 6),
+            "replicas_in_sync": replicas_in_sync,
             "roofline": roofline,
             "roofline_hbm": roofline_hbm,
             "roofline_mfma": roofline_mfma,
