@@ -4,7 +4,7 @@
     ConfusionMatrix   :50-170   bincount-accumulated (true, pred) matrix and everything derived from it
     get_mious         :173-181  IoU / accuracy from (tp, union, count) vectors (after the cross-rank all-reduce)
 
-Integer work on the GPU (torch.bincount of true * C + pred); the matrix stays an int64 device tensor so that
+Integer work on the GPU (a scatter-add histogram of true * C + pred, no host read-back); the matrix stays an int64 device tensor so that
 `dist.all_reduce(cm.tp)` etc. keep working as in examples/segmentation/main_AA.py:460-462.
 One deliberate difference: `update` does not overwrite the caller's `pred` / `true` tensors where
 true == ignore_index (the reference's flatten() views make its in-place writes visible outside).
@@ -46,8 +46,12 @@ class ConfusionMatrix:
             ignored = true == self.ignore_index
             true = torch.where(ignored, v - 1, true)
             pred = torch.where(ignored, v - 1, pred)
-        bins = torch.bincount(true * v + pred, minlength=v * v).view(v, v)
-        self.value = self.value + bins[:self.num_classes, :self.num_classes]
+        # a histogram by scatter-add rather than torch.bincount: bincount reads its maximum back to the host, which
+        # would drain the GPU once per training step (train_one_epoch updates the matrix every iteration)
+        key = true * v + pred
+        bins = torch.zeros(v * v, dtype=torch.int64, device=key.device)
+        bins.scatter_add_(0, key, torch.ones_like(key, dtype=torch.int64))
+        self.value = self.value + bins.view(v, v)[:self.num_classes, :self.num_classes]
 
     def reset(self):
         self.value = 0

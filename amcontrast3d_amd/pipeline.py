@@ -16,16 +16,63 @@ The batches yielded are the caller's dicts (pos, y already on the GPU; 'x' etc. 
 Results are identical to the un-prefetched path: the same kernels on the same inputs, only earlier and on another
 stream (tests/test_gpu_pipeline.py).  bench.py implements the same schedule with hipGraphs and static buffers.
 
-Both side streams own their hardware queue (ops.dedicated_stream).  Ordinary HIP streams of a process share four
-queues round-robin, and a stream that lands on the queue of a running FPS kernel waits milliseconds for it -- the
-training stream, a graph's internal branch or RCCL's, depending on how many streams were created before (measured:
-the same loop at 10.4 or 14 ms/step with and without a process group alive).
+The two side streams are picked from PyTorch's pool so that they and the caller's stream sit on three different
+hardware queues (probed once per process, _side_streams): ordinary HIP streams share four queues round-robin, and a
+stream that lands on the queue of a running FPS kernel waits milliseconds for it.
 """
 import collections
 
 import torch
 
 from . import geometry
+
+
+_streams = {}  # device -> (FPS stream, geometry stream): shared by every prefetcher of the process
+
+
+def _shares_queue(a, b, cycles=3_000_000):
+    """True when work on stream `b` has to wait for work on stream `a`: both were mapped onto the same hardware queue.
+    Probe: a ~1.5 ms spin kernel on `a`, a tiny kernel on `b`, and the host time until `b` is idle."""
+    import time
+    torch.cuda.synchronize()
+    with torch.cuda.stream(b):
+        probe = torch.zeros(8, device=f"cuda:{b.device_index}")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(cycles)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(b):
+        probe.add_(1)
+    b.synchronize()
+    dt = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    return dt > 0.5e-3
+
+
+def _side_streams(dev):
+    """One pair of side streams per device, however many prefetchers (one per epoch) come and go -- the caching
+    allocator keeps a memory pool per stream, so a fresh pair per epoch would strand the previous epoch's blocks
+    (measured: +0.4 GiB reserved per epoch) -- chosen so that the caller's stream and the two side streams sit on three
+    different hardware queues.  Ordinary HIP streams share four queues per process, handed out round-robin; a stream
+    that lands on the queue of the FPS stream waits ~10 ms per step for it, and which one does depends on every stream
+    created before.  Streams with a queue of their own (ops.dedicated_stream, what bench.py's
+    captured pipeline uses) are not an option for this eager loop: launched kernel by kernel they lose the overlap
+    altogether (measured: 21 ms/step against 9.8 with pooled streams), so the pool is probed instead."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _streams:
+        cur = torch.cuda.current_stream(dev)
+        chosen = []
+        with torch.cuda.device(dev):
+            for _ in range(12):  # successive pool streams cycle through the hardware queues
+                cand = torch.cuda.Stream(dev)
+                if not any(_shares_queue(r, cand) for r in [cur] + chosen):
+                    chosen.append(cand)
+                if len(chosen) == 2:
+                    break
+            while len(chosen) < 2:  # fewer than three free queues (GPU_MAX_HW_QUEUES < 3): overlap what can be overlapped
+                chosen.append(torch.cuda.Stream(dev))
+        _streams[key] = tuple(chosen)
+    return _streams[key]
 
 
 class GeometryPrefetcher:
@@ -48,8 +95,7 @@ class GeometryPrefetcher:
     def _launch(self, data):
         dev = data["pos"].device
         if self.s_fps is None:
-            from . import ops
-            self.s_fps, self.s_rest = ops.dedicated_stream(dev), ops.dedicated_stream(dev)
+            self.s_fps, self.s_rest = _side_streams(dev)
         cur = torch.cuda.current_stream(dev)
         self.s_fps.wait_stream(cur)  # pos / y were produced (copied to the GPU) on the caller's stream
         with torch.cuda.stream(self.s_fps):
