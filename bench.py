@@ -254,7 +254,13 @@ def main():
     #   Q_geo : FPS levels 2-4, then the neighbourhood / loss geometry of the same batch
     from amcontrast3d_amd import ops as _ops
     qplan = os.environ.get("AMC3D_QUEUES", "fps,geo")  # others, for scratch/queue_sweep.sh: "pooled", "fps,a2,b", ...
-    if qplan == "pooled":
+    if not use_graph and "AMC3D_QUEUES" not in os.environ:
+        # launched kernel by kernel, dedicated queues lose the overlap (pipeline.py): two pooled streams probed to sit
+        # on hardware queues of their own, as the eager GeometryPrefetcher uses them
+        from amcontrast3d_amd import pipeline as _pipeline
+        s_fps_pool, s_geo_pool = _pipeline._side_streams(dev)
+        s_a, s_a2, s_b = [s_fps_pool] * lanes, s_geo_pool, s_geo_pool
+    elif qplan == "pooled":
         s_a = [torch.cuda.Stream(priority=prio[1]) for _ in range(lanes)]
         s_a2, s_b = torch.cuda.Stream(priority=prio[2]), torch.cuda.Stream(priority=prio[3])
     else:
