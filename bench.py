@@ -254,7 +254,7 @@ def main():
     #   Q_geo : FPS levels 2-4, then the neighbourhood / loss geometry of the same batch
     from amcontrast3d_amd import ops as _ops
     qplan = os.environ.get("AMC3D_QUEUES", "fps,geo")  # others, for scratch/queue_sweep.sh: "pooled", "fps,a2,b", ...
-    if not use_graph and "AMC3D_QUEUES" not in os.environ:
+    if (not use_graph and "AMC3D_QUEUES" not in os.environ) or qplan == "probed":
         # launched kernel by kernel, dedicated queues lose the overlap (pipeline.py): two pooled streams probed to sit
         # on hardware queues of their own, as the eager GeometryPrefetcher uses them
         from amcontrast3d_amd import pipeline as _pipeline
