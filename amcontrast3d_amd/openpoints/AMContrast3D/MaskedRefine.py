@@ -11,6 +11,8 @@ import torch
 
 from openpoints.cpp.pointops.functions import pointops
 
+RATE_ON_DEVICE = False  # True: refine rates are returned as device tensors (no host read-back per stage)
+
 
 class RefinementMethod:
     def __init__(self, stage_list, p, f, a, i, B, K, fusion, threshold_max, threshold, gamma):
@@ -90,7 +92,8 @@ class RefinementMethod:
     def self_mask(self):
         mask = self.ambiguity.le(self.threshold_max) * self.ambiguity.ge(self.threshold)
         count = torch.count_nonzero(mask.long())
-        if mask.is_cuda and torch.cuda.is_current_stream_capturing():
-            # under hipGraph capture the percentage stays a 0-dim tensor (the reference's .item() is a host sync)
+        if mask.is_cuda and (RATE_ON_DEVICE or torch.cuda.is_current_stream_capturing()):
+            # under hipGraph capture, or when the caller asked for it (amcontrast3d_amd.train keeps the GPU running
+            # ahead), the percentage stays a 0-dim tensor: the reference's .item() is a host sync per stage
             return mask, count.to(torch.float32) / self.ambiguity.numel() * 100
         return mask, (count.item() / self.ambiguity.numel()) * 100

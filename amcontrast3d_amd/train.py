@@ -35,10 +35,44 @@ def _to_device_batches(train_loader, cfg, device):
         yield data
 
 
+def train_one_epoch_mm(model, train_loader, criterion, optimizer, scheduler, scaler, epoch, cfg, prefetch_depth=2,
+                       device=None):
+    """The AMContrast3D++ loop (examples/segmentation/main_MM.py:370-449): the model returns (logits, stage list,
+    refine rate), CrossEntropyAcePre returns (segmentation, w1 CE, w2 contrast, w3 regression) and the step minimises
+    segmentation + regression.  Returns the reference's tuple: averages of (loss, segmentation, CE, contrast,
+    regression, refine rate), then mIoU, mAcc, OA, per-class IoU / accuracy."""
+    activate()
+    from openpoints.AMContrast3D import MaskedRefine
+
+    def step_loss(data, target):
+        logits, stage, rate = model(data)
+        seg, ce, am, reg = criterion(logits, target, stage, cfg.num_classes, cfg.ignore_index, cfg.ambiguity_args)
+        rate = rate if torch.is_tensor(rate) else torch.tensor(float(rate), device=logits.device)
+        return logits, seg + reg, (seg, ce, am, reg, rate)
+
+    keep = MaskedRefine.RATE_ON_DEVICE
+    MaskedRefine.RATE_ON_DEVICE = True  # no .item() per refinement stage: the loop stays ahead of the GPU
+    try:
+        return _run_epoch(model, train_loader, criterion, optimizer, scheduler, scaler, epoch, cfg, prefetch_depth, device,
+                          step_loss, extras=5)
+    finally:
+        MaskedRefine.RATE_ON_DEVICE = keep
+
+
 def train_one_epoch(model, train_loader, criterion, optimizer, scheduler, scaler, epoch, cfg, prefetch_depth=2,
                     device=None):
     """One pass over `train_loader`.  cfg needs num_classes, ignore_index, ambiguity_args, feature_keys, use_amp,
     step_per_update, grad_norm_clip (None / 0: off), sched_on_epoch -- the fields main_AA.py reads."""
+    def step_loss(data, target):
+        logits, stage = model(data)
+        return logits, criterion(logits, target, stage, cfg.num_classes, cfg.ignore_index, cfg.ambiguity_args), ()
+
+    return _run_epoch(model, train_loader, criterion, optimizer, scheduler, scaler, epoch, cfg, prefetch_depth, device,
+                      step_loss, extras=0)
+
+
+def _run_epoch(model, train_loader, criterion, optimizer, scheduler, scaler, epoch, cfg, prefetch_depth, device, step_loss,
+               extras):
     activate()
     from openpoints.utils import ConfusionMatrix
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -51,14 +85,13 @@ def train_one_epoch(model, train_loader, criterion, optimizer, scheduler, scaler
         batches = GeometryPrefetcher(batches, model, head, cfg.num_classes, cfg.ignore_index, cfg.ambiguity_args,
                                      depth=prefetch_depth)
     clip = cfg.get("grad_norm_clip", None) if hasattr(cfg, "get") else getattr(cfg, "grad_norm_clip", None)
-    loss_sum = torch.zeros((), dtype=torch.float64, device=device)
-    last_loss, n_batches, num_iter = None, 0, 0
+    loss_sum = torch.zeros(1 + extras, dtype=torch.float64, device=device)
+    n_batches, num_iter = 0, 0
     for data in batches:
         num_iter += 1
         target = data["y"]
         with torch.autocast("cuda", enabled=use_amp):
-            logits, stage = model(data)
-            loss = criterion(logits, target, stage, cfg.num_classes, cfg.ignore_index, cfg.ambiguity_args)
+            logits, loss, parts = step_loss(data, target)
         if use_amp:
             scaler.scale(loss).backward()
         else:
@@ -77,8 +110,7 @@ def train_one_epoch(model, train_loader, criterion, optimizer, scheduler, scaler
             if not cfg.sched_on_epoch:
                 scheduler.step(epoch)
         cm.update(logits.argmax(dim=1), target)
-        last_loss = loss.detach()
-        loss_sum += last_loss.double()
+        loss_sum += torch.stack([loss.detach()] + [v.detach() for v in parts]).double()
         n_batches += 1
     miou, macc, oa, ious, accs = cm.all_metrics()
-    return (float(loss_sum) / max(1, n_batches), miou, macc, oa, ious, accs)
+    return tuple((loss_sum / max(1, n_batches)).tolist()) + (miou, macc, oa, ious, accs)

@@ -74,3 +74,44 @@ def test_train_one_epoch_learns():
     for _ in range(3):
         last = train.train_one_epoch(model, _loader(3), crit, opt, None, None, 2, cfg)[0]
     assert np.isfinite(last) and last < first
+
+
+def test_train_one_epoch_mm_matches_hand_written_loop():
+    """the AMContrast3D++ loop (main_MM.py:370-449): six averaged quantities and the confusion-matrix metrics"""
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from amcontrast3d_amd import train
+    from openpoints.loss import build_criterion_from_cfg
+    from openpoints.models import build_model_from_cfg
+    from openpoints.utils import ConfusionMatrix, EasyConfig
+    dev = torch.device("cuda:0")
+
+    def setup():
+        torch.manual_seed(0)
+        c = EasyConfig(); c.update(configs.model_cfg_mm("S", dropout=0, width=16, threshold=0.5))
+        model = build_model_from_cfg(c).to(dev)
+        cc = EasyConfig(); cc.update(configs.criterion_cfg_mm())
+        cfg = EasyConfig()
+        cfg.update({"num_classes": 13, "ignore_index": None, "ambiguity_args": configs.ambiguity_args_mm("s3dis"),
+                    "feature_keys": "x,heights", "use_amp": False, "step_per_update": 1, "grad_norm_clip": 10, "sched_on_epoch": True})
+        return model, build_criterion_from_cfg(cc).to(dev), cfg, torch.optim.SGD(model.parameters(), lr=0.0)
+
+    model, crit, cfg, opt = setup()
+    got = train.train_one_epoch_mm(model, _loader(3), crit, opt, None, None, 1, cfg)
+    assert len(got) == 11
+    model2, crit2, cfg2, opt2 = setup()
+    cm = ConfusionMatrix(num_classes=13, ignore_index=None)
+    rows = []
+    for data in _loader(3):
+        data = {k: v.to(dev) for k, v in data.items()}
+        data["x"] = train.get_features_by_keys(data, "x,heights")
+        logits, stage, rate = model2(data)
+        seg, ce, am, reg = crit2(logits, data["y"], stage, 13, None, cfg2.ambiguity_args)
+        (seg + reg).backward()
+        opt2.step(); opt2.zero_grad()
+        cm.update(logits.argmax(dim=1), data["y"])
+        rows.append([float(seg + reg), float(seg), float(ce), float(am), float(reg), float(rate)])
+    want = np.mean(np.array(rows), axis=0)
+    np.testing.assert_allclose(got[:6], want, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(got[6:9], cm.all_metrics()[:3], rtol=1e-6)
+    assert 0.0 < got[5] < 100.0  # some, not all, points refined
