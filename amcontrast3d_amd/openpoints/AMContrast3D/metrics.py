@@ -69,3 +69,48 @@ def ambiguity_metrics(p, label, pred, posmask_test, nsample_test, neighbor_idx_t
         shares = [row[1], sum(row[2:6]), row[6], sum(row[7:11]), row[11]]
         cls[c] = [round(s / n * 100, 2) for s in shares]
     return (ambiguity_soft, ratio, ambiguity_count, [1.0, 1.0, 1.0, 1.0, 1.0], cls, mious, maccs, oas, counts)
+
+
+def ambiguity_summary(num_classes, ambiguity_vs_accuracy_list, ambiguity_vs_count_list, ambiguity_vs_accuracy_lowsemihigh_list,
+                      ambiguity_vs_cls_list, ambiguity_cm_miou, ambiguity_cm_macc, ambiguity_cm_oa, ambiguity_cm_count):
+    """Averages over the test clouds of what ambiguity_metrics returned for each (AMContrast3D/metrics.py:10-30; called
+    once at the end of test_boundary_inner, examples/segmentation/main_AA.py:790-794).  Prints the tables like the
+    reference and returns them: per-class shares per ambiguity group, group shares, and mIoU / mAcc / OA / per-class
+    counts of the five groups (a = 0, low, semi, high, a = 1)."""
+    import numpy as np
+    per_class = {}
+    for c in range(num_classes):
+        rows = [per_cloud[c] for per_cloud in ambiguity_vs_cls_list if c in per_cloud]
+        per_class[c] = np.around(np.mean(rows, axis=0), decimals=3) if rows else None
+        print('count per cls: ', c, per_class[c])
+    out = {
+        'cls': per_class,
+        'count': np.around(np.mean(ambiguity_vs_count_list, axis=0), decimals=3),
+        'acc_low_semi_high': np.around(np.mean(ambiguity_vs_accuracy_lowsemihigh_list, axis=0), decimals=3),
+        'miou': np.around(np.mean(ambiguity_cm_miou, axis=0), decimals=2),
+        'macc': np.around(np.mean(ambiguity_cm_macc, axis=0), decimals=2),
+        'oa': np.around(np.mean(ambiguity_cm_oa, axis=0), decimals=2),
+        'count_per_class': np.around(np.mean(ambiguity_cm_count, axis=0), decimals=0),
+    }
+    print('count per a_i: 0, low=(0,0.5), semi=0.5, high=(0.5,1), 1:', out['count'])
+    print('acc per a_i: 0, low=(0,0.5), semi=0.5, high=(0.5,1), 1:', out['acc_low_semi_high'])
+    for key in ('miou', 'macc', 'oa'):
+        print(f'{key} per ambiguity:', out[key])
+    for name, row in zip(('0', 'low', 'semi', 'high', '1'), out['count_per_class']):
+        print(f'count-{name}:', row)
+    return out
+
+
+def vis_tsne(stageACE_list_all):
+    """t-SNE scatter plots of the stage embeddings (AMContrast3D/metrics.py:187-...): a visualisation aid that needs
+    seaborn / matplotlib; not part of this package.  With AMC3D_REFERENCE_ROOT set the reference's own function runs."""
+    import importlib.util
+    import os
+    root = os.environ.get('AMC3D_REFERENCE_ROOT')
+    path = os.path.join(root, 'openpoints', 'AMContrast3D', 'metrics.py') if root else None
+    if not path or not os.path.exists(path):
+        raise NotImplementedError('vis_tsne is a plotting helper of the reference; set AMC3D_REFERENCE_ROOT to use it')
+    spec = importlib.util.spec_from_file_location('_reference_amcontrast3d_metrics', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.vis_tsne(stageACE_list_all)

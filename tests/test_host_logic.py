@@ -195,3 +195,19 @@ def test_mm_registry_and_state_keys():
     xl.update(configs.model_cfg_mm("XL"))  # cfgs/s3dis/AMContrast3D-MM.yaml shape
     apm = build_model_from_cfg(xl.APM_args)
     assert [apm.layer_0[0].in_features, apm.layer_3[0].in_features] == [3 + 64, 3 + 512]
+
+
+def test_trainer_import_surface_of_the_metrics_modules():
+    """examples/segmentation/main_AA.py:16,31 / main_MM.py:16,27 import these names; this package's modules shadow the
+    reference's under the path overlay, so they must all exist"""
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from openpoints.AMContrast3D.metrics import ambiguity_metrics, ambiguity_summary, posmask_searching, vis_tsne  # noqa: F401
+    from openpoints.utils import AverageMeter, ConfusionMatrix, get_mious  # noqa: F401
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = ambiguity_summary(2, [{}], [[10, 20, 30, 20, 20], [20, 20, 20, 20, 20]], [[1.0] * 5] * 2,
+                                [{0: [1, 2, 3, 4, 5]}, {0: [3, 2, 3, 4, 5]}], [[1, 2, 3, 4, 5]] * 2, [[1, 2, 3, 4, 5]] * 2,
+                                [[1, 2, 3, 4, 5]] * 2, [[[1, 2]] * 5] * 2)
+    assert list(out["count"]) == [15, 20, 25, 20, 20] and list(out["cls"][0]) == [2, 2, 3, 4, 5] and out["cls"][1] is None
