@@ -91,33 +91,62 @@ def allreduce_gradients(params, bucket_bytes=32 << 20):
 
 
 class FlatGradients:
-    """Every parameter's .grad as a view of ONE buffer, so that the data-parallel exchange of a step is a single
-    all-reduce on memory the optimizer reads directly: no bucket assembly and no copy-back (allreduce_gradients needs
-    ~2 launches per parameter for those, ~0.7 ms of eager launches per PointNeXt-S step during which the GPU idles
-    between the captured backward and the captured optimizer step).  Autograd accumulates into an existing .grad in
-    place, so the views survive backward passes and graph replays; zero() replaces optimizer.zero_grad()."""
+    """Every parameter's gradient in ONE buffer, so that the data-parallel exchange of a step is a single all-reduce
+    on memory the optimizer reads directly: no bucket assembly and no copy-back (allreduce_gradients needs ~2 launches
+    per parameter for those, ~0.7 ms of eager launches per PointNeXt-S step during which the GPU idles between the
+    captured backward and the captured optimizer step).
 
-    def __init__(self, params):
+    Two ways to get the gradients there:
+      accumulate=True   .grad is a view of the buffer from the start; autograd accumulates into an existing .grad in
+                        place, zero() replaces optimizer.zero_grad().  One `add_` per parameter and step (0.17 ms).
+      accumulate=False  backward runs with .grad = None (autograd just keeps the tensors it produced); gather() then
+                        copies them into the buffer with one multi-tensor copy and points .grad at the views, which
+                        is what the optimizer (and a graph capturing it) reads; release() sets .grad = None again
+                        before the next backward.  Under graph capture gather() is part of the captured half.
+    """
+
+    def __init__(self, params, accumulate=True):
         self.params = [p for p in params if p.requires_grad]
         assert self.params and len({(p.device, p.dtype) for p in self.params}) == 1
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=self.params[0].dtype, device=self.params[0].device)
-        off = 0
+        self.accumulate = accumulate
+        self.views, off = [], 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        if accumulate:
+            for p, v in zip(self.params, self.views):
+                p.grad = v
 
     def zero(self):
-        self.flat.fill_(0)  # a kernel, not a memset (capturable: hipMemset nodes race under graph replay on ROCm 7.2)
+        """start of a step: accumulate mode clears the buffer (a kernel, not a memset -- hipMemset nodes race under
+        graph replay on ROCm 7.2); copy mode hands autograd empty .grad slots"""
+        if self.accumulate:
+            self.flat.fill_(0)
+        else:
+            self.release()
+
+    def release(self):
+        for p in self.params:
+            p.grad = None
+
+    def gather(self):
+        """copy mode, after backward: fresh gradients -> buffer (one multi-tensor copy), .grad -> views"""
+        if self.accumulate:
+            return
+        have = [(v, p.grad) for p, v in zip(self.params, self.views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        missing = [v for p, v in zip(self.params, self.views) if p.grad is None]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v in missing:  # a parameter that took no part in this backward
+            v.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def intact(self):
-        """the views are still in place (nothing replaced a .grad, e.g. zero_grad(set_to_none=True))"""
-        off = 0
-        for p in self.params:
-            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
-                return False
-            off += p.numel()
-        return True
+        """the views are in place (after gather() in copy mode): nothing replaced a .grad behind our back"""
+        return all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(self.params, self.views))
 
     def allreduce(self):
         """average over ranks: one collective (also issued in a one-rank group, so that a single-GPU rehearsal

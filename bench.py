@@ -207,13 +207,14 @@ def main():
     data = {k: torch.from_numpy(v).to(dev) for k, v in nb.items()}
     params = list(model.parameters())
     # N > 1: gradients live in one flat buffer, exchanged by a single RCCL all-reduce between the two captured halves
-    flatg = adist.FlatGradients(params) if (world > 1 and not use_ddp) or os.environ.get("AMC3D_FLAT_GRADS") else None
+    flatg = (adist.FlatGradients(params, accumulate=bool(os.environ.get("AMC3D_FLAT_ACCUMULATE")))
+             if (world > 1 and not use_ddp) or os.environ.get("AMC3D_FLAT_GRADS") else None)
     torch.cuda.synchronize()
     out = {}
 
     def fwd_bwd():
         if flatg is not None:
-            flatg.zero()  # part of the captured half: autograd then accumulates into the flat views in place
+            flatg.zero()  # part of the captured half (a fill in accumulate mode; .grad = None in copy mode)
         if args.mm:  # examples/segmentation/main_MM.py:404-410: segmentation + regression objective
             logits, stage, _ = model(data)
             seg, _, _, reg = criterion(logits, data["y"], stage, 13, None, aargs)
@@ -222,6 +223,8 @@ def main():
             logits, stage = model(data)
             out["loss"] = criterion(logits, data["y"], stage, 13, None, aargs)
         out["loss"].backward()
+        if flatg is not None:
+            flatg.gather()  # copy mode: one multi-tensor copy into the all-reduce buffer, .grad -> its views
 
     # Software pipeline over consecutive batches.  The coordinate-only half of a step
     # (amcontrast3d_amd/geometry.py) does not depend on features or weights, so it runs ahead, on two side

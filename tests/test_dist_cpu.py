@@ -49,6 +49,15 @@ def _worker(rank, world, port, q):
     flat_ok = flat_ok and fg.intact() and all(torch.allclose(p.grad, w_, atol=1e-6) for p, w_ in zip(net2.parameters(), want))
     torch.optim.SGD(net2.parameters(), lr=0.1).zero_grad(set_to_none=True)
     flat_ok = flat_ok and not fg.intact()  # detects a replaced .grad
+    # copy mode: backward with empty .grad slots, then one multi-tensor copy into the buffer
+    fc = adist.FlatGradients(list(net2.parameters()), accumulate=False)
+    for _ in range(2):  # the second pass must not see the first one's gradients
+        fc.zero()
+        net2(x).square().mean().backward()
+        fc.gather()
+    flat_ok = flat_ok and fc.intact() and all(torch.allclose(p.grad, g, atol=1e-7) for p, g in zip(net2.parameters(), local))
+    fc.allreduce()
+    flat_ok = flat_ok and fc.intact() and all(torch.allclose(p.grad, w_, atol=1e-6) for p, w_ in zip(net2.parameters(), want))
     ok = ok and flat_ok
     # DDP wrapper (CPU branch) keeps replicas in sync after a step
     ddp = adist.wrap_data_parallel(torch.nn.Linear(4, 2), torch.device("cpu"), world)

@@ -43,7 +43,8 @@ def test_knn_and_ambiguity_under_graph_replay():
         assert torch.equal(got[2], want[2]), it
 
 
-def test_flat_gradients_under_graph_replay():
+@pytest.mark.parametrize("accumulate", [True, False])
+def test_flat_gradients_under_graph_replay(accumulate):
     """dist.FlatGradients (the N > 1 gradient buffer of bench.py): a captured forward + backward whose first node
     zero-fills the flat buffer accumulates into the views in place, replay after replay, and gives the gradients of
     the ordinary eager pass."""
@@ -69,19 +70,23 @@ def test_flat_gradients_under_graph_replay():
 
     fwd_bwd()
     want = [p.grad.clone() for p in params]
-    flat = adist.FlatGradients(params)
+    for p in params:
+        p.grad = None
+    flat = adist.FlatGradients(params, accumulate=accumulate)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _ in range(2):
             flat.zero()
             fwd_bwd()
+            flat.gather()
         torch.cuda.synchronize()
         assert flat.intact()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=side):
             flat.zero()
             fwd_bwd()
+            flat.gather()
     torch.cuda.synchronize()
     for it in range(3):
         flat.flat.fill_(float("nan"))
