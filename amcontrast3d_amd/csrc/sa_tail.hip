@@ -51,6 +51,7 @@ struct SatArgs {
     const float *dpooled;
     const float *mean_dq, *mean_dqx;       // mode 3: per-channel means of dq and dq * xhat over all B*M*32 positions
     float *dx1;                            // mode 3: (B, C1, M, 32)
+    unsigned char *arg_out;                // mode 2, optional: (B, C2, M) the arg-max the gradient is routed to
     float *partial_w;                      // mode 3: [part][C2][C1]
 };
 
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(256) void sat_kernel(SatArgs a)
                 const bool owner = ok && ((as >> 2) & 1) == kh;       // the half that holds neighbour `as`
                 const int rstar = (as & 3) + 4 * (as >> 3);
                 if (MODE == 2) {
+                    if (a.arg_out && ok && kh == 0) a.arg_out[((size_t)b * C2 + c2) * M + m] = (unsigned char)as;
                     float xv = 0.f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) xv = r == rstar ? acc[ct][r] : xv;
@@ -430,7 +432,8 @@ AMC_API int amc3d_sa_tail_backward(int B, int C1, int C2, int M, int K, const fl
                                    const float *invstd1, const float *gamma1, const float *beta1, const float *w2,
                                    const float *mean2, const float *invstd2, const float *gamma2, const float *beta2,
                                    int relu2, const float *dpooled, float *dx1, float *dw2,
-                                   float *dgamma2, float *dbeta2, void *workspace, size_t workspace_bytes, void *stream_)
+                                   float *dgamma2, float *dbeta2, unsigned char *arg_out, void *workspace,
+                                   size_t workspace_bytes, void *stream_)
 {
     if (B <= 0 || M <= 0) return 0;
     if (!sat_supported(C1, C2, K) || !y1 || !mean1 || !invstd1 || !gamma1 || !beta1 || !w2 || !mean2 || !invstd2 || !gamma2 ||
@@ -446,7 +449,7 @@ AMC_API int amc3d_sa_tail_backward(int B, int C1, int C2, int M, int K, const fl
     SatArgs a{};
     a.B = B; a.C1 = C1; a.C2 = C2; a.M = M; a.y1 = y1; a.mean1 = mean1; a.invstd1 = invstd1; a.g1 = gamma1; a.b1 = beta1;
     a.w2 = w2; a.mean2 = mean2; a.invstd2 = invstd2; a.g2 = gamma2; a.b2 = beta2; a.relu2 = relu2;
-    a.dpooled = dpooled; a.partial = partial;
+    a.dpooled = dpooled; a.partial = partial; a.arg_out = arg_out;
     sat_launch<2>(a, groups, stream);
     hipLaunchKernelGGL(sat_finalize_kernel, dim3(C2), dim3(256), 0, stream, C2, groups * B,
                        (double)B * (double)M * 32.0, 0.f, -1.f, 1, (const double *)partial, dbeta2, dgamma2, means, means + C2,

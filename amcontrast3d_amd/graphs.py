@@ -1,0 +1,95 @@
+"""hipGraph capture of a train step that contains collectives: a chain of graphs with the collectives between them.
+
+Why.  At world_size > 1 the reference turns every BatchNorm into SyncBatchNorm (examples/segmentation/main_AA.py:146-148,
+820): 34 layers x (one statistics all-reduce forward, one backward) sit in the middle of the feature half of a step.
+Launching that half kernel by kernel is launch-bound (~700 launches); capturing it as ONE hipGraph would put RCCL
+collectives inside a graph.  `SegmentedGraph` does neither: the step function runs once under stream capture, and every
+time it reaches a collective (`collective(fn)`, called by ops.SyncBatchNormFused) the capture is ended, `fn` is kept as
+an eager call, and a new capture begins in the same memory pool.  Replay = graph, collective, graph, collective, ...
+in the recorded order on the current stream: the kernels are replayed as graphs, the collectives are ordinary
+`torch.distributed` calls between them, as they would be in an eager loop.
+
+Backward.  autograd normally runs CUDA nodes on a worker thread, and a stream capture must be ended by the thread that
+began it; `capture()` therefore runs the function under `torch.autograd.set_multithreading_enabled(False)`, which keeps
+backward on the calling thread.
+
+During the capturing pass the collectives are executed too (on memory whose producing kernels were captured, not run:
+the values are meaningless, the call sequence is what matters): every rank issues the same collectives in the same
+order in that pass as in every replay.
+"""
+import torch
+
+_active = None  # the SegmentedGraph that is capturing on this thread, if any
+
+
+def collective(fn):
+    """Run `fn` (a torch.distributed call) now; inside SegmentedGraph.capture() also cut the graph here."""
+    if _active is not None:
+        return _active._cut(fn)
+    return fn()
+
+
+class SegmentedGraph:
+    def __init__(self, capture_error_mode="thread_local"):
+        self.mode = capture_error_mode
+        self.items = []      # torch.cuda.CUDAGraph | callable, in replay order
+        self.pool = None
+        self._cur = None
+
+    # -- capture ---------------------------------------------------------------------------------
+    def _begin(self):
+        self._cur = torch.cuda.CUDAGraph()
+        self._cur.capture_begin(pool=self.pool, capture_error_mode=self.mode)
+
+    def _end(self):
+        self._cur.capture_end()
+        self.items.append(self._cur)
+        self._cur = None
+
+    def _cut(self, fn):
+        self._end()
+        self.items.append(fn)
+        out = fn()  # keeps the ranks' collective sequences aligned during the capturing pass
+        self._begin()
+        return out
+
+    def capture(self, fn, stream=None):
+        """Capture fn() -- forward, loss, backward, anything -- on `stream` (default: the current stream, which must
+        not be the legacy default stream).  Collectives inside must go through graphs.collective()."""
+        global _active
+        assert _active is None and not self.items, "one capture per SegmentedGraph"
+        stream = stream if stream is not None else torch.cuda.current_stream()
+        self.pool = torch.cuda.graph_pool_handle()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream), torch.autograd.set_multithreading_enabled(False):
+            _active = self
+            try:
+                self._begin()
+                fn()
+                self._end()
+            finally:
+                _active = None
+                if self._cur is not None:  # fn raised inside a capture: leave the stream usable
+                    try:
+                        self._cur.capture_end()
+                    except Exception:
+                        pass
+                    self._cur = None
+        torch.cuda.synchronize()
+        return self
+
+    # -- replay ----------------------------------------------------------------------------------
+    def replay(self):
+        for it in self.items:
+            if isinstance(it, torch.cuda.CUDAGraph):
+                it.replay()
+            else:
+                it()
+
+    @property
+    def segments(self):
+        return sum(isinstance(it, torch.cuda.CUDAGraph) for it in self.items)
+
+    @property
+    def collectives(self):
+        return len(self.items) - self.segments

@@ -64,6 +64,33 @@ def _need_gpu(*ts):
                                "there is no CPU fallback" % t.device)
 
 
+def _need_dtype(dtype, **named):
+    """The C-ABI takes raw pointers: a float64 / bf16 coordinate or an int64 index would be reinterpreted silently.
+    The reference's pybind layer throws on data_ptr<float>() / data_ptr<int>() of another dtype (ball_query.cpp:29-38);
+    so does this."""
+    for name, t in named.items():
+        if t is not None and t.dtype != dtype:
+            raise RuntimeError(f"expected {name} to be {dtype}, got {t.dtype}")
+
+
+# tests only: {sequence number of the max-pool in forward order: arg-max (B,C,M) uint8} while a dict is installed
+# (pool_log(d)); the oracle then routes its max-pool gradients through the same elements (tests/test_gpu_fullsize.py)
+_pool_log = None
+_pool_seq = 0
+
+
+def pool_log(d):
+    """install (dict) or remove (None) the arg-max log; resets the forward-order counter"""
+    global _pool_log, _pool_seq
+    _pool_log, _pool_seq = d, 0
+
+
+def _next_pool_seq():
+    global _pool_seq
+    _pool_seq += 1
+    return _pool_seq - 1
+
+
 def _grid_ws(b, n_support, m_queries, device):
     """caller-owned scratch of the grid searches (ball query, 3-NN); the library falls back to the all-pairs
     kernels by itself where a grid does not pay (small clouds)"""
@@ -78,6 +105,7 @@ class BallQuery(Function):
         assert new_xyz.is_contiguous()
         assert xyz.is_contiguous()
         _need_gpu(xyz, new_xyz)
+        _need_dtype(torch.float32, xyz=xyz, new_xyz=new_xyz)
         B, N, _ = xyz.size()
         npoint = new_xyz.size(1)
         idx = torch.empty(B, npoint, nsample, dtype=torch.int32, device=xyz.device)
@@ -104,6 +132,8 @@ class GroupingOperation(Function):
         assert features.is_contiguous()
         assert idx.is_contiguous()
         _need_gpu(features, idx)
+        _need_dtype(torch.float32, features=features)
+        _need_dtype(torch.int32, idx=idx)
         B, nfeatures, nsample = idx.size()
         _, C, N = features.size()
         output = torch.empty(B, C, nfeatures, nsample, dtype=torch.float32, device=features.device)
@@ -133,11 +163,14 @@ grouping_operation = GroupingOperation.apply
 
 class GatherOperation(Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, features, idx):
         """features (B,C,N), idx (B,npoint) int32 -> (B,C,npoint)"""
         assert features.is_contiguous()
         assert idx.is_contiguous()
         _need_gpu(features, idx)
+        _need_dtype(torch.float32, features=features)
+        _need_dtype(torch.int32, idx=idx)
         B, npoint = idx.size()
         _, C, N = features.size()
         output = torch.empty(B, C, npoint, dtype=torch.float32, device=features.device)
@@ -148,6 +181,7 @@ class GatherOperation(Function):
         return output
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_out):
         idx, C, N = ctx.for_backwards
         B, npoint = idx.size()
@@ -168,6 +202,7 @@ class FurthestPointSampling(Function):
         """xyz (B,N,3) -> (B,npoint) int32, first index 0"""
         assert xyz.is_contiguous()
         _need_gpu(xyz)
+        _need_dtype(torch.float32, xyz=xyz)
         B, N, _ = xyz.size()
         output = torch.empty(B, npoint, dtype=torch.int32, device=xyz.device)
         # the reference's (B,N) scratch of running minima (filled with 1e10) lives in registers (N <= 24576) or in
@@ -201,6 +236,7 @@ class ThreeNN(Function):
         assert unknown.is_contiguous()
         assert known.is_contiguous()
         _need_gpu(unknown, known)
+        _need_dtype(torch.float32, unknown=unknown, known=known)
         B, N, _ = unknown.size()
         m = known.size(1)
         dist2 = torch.empty(B, N, 3, dtype=torch.float32, device=unknown.device)
@@ -229,6 +265,8 @@ class ThreeInterpolate(Function):
         assert idx.is_contiguous()
         assert weight.is_contiguous()
         _need_gpu(features, idx, weight)
+        _need_dtype(torch.float32, features=features, weight=weight)
+        _need_dtype(torch.int32, idx=idx)
         B, c, m = features.size()
         n = idx.size(1)
         ctx.three_interpolate_for_backward = (idx, weight, m)
@@ -295,6 +333,8 @@ class KNNQuery(Function):
             new_xyz = xyz
         assert xyz.is_contiguous() and new_xyz.is_contiguous()
         _need_gpu(xyz, new_xyz, offset, new_offset)
+        _need_dtype(torch.float32, xyz=xyz, new_xyz=new_xyz)
+        _need_dtype(torch.int32, offset=offset, new_offset=new_offset)
         nsample = int(nsample)
         n, m, nb = xyz.shape[0], new_xyz.shape[0], offset.shape[0]
         idx = torch.empty(m, nsample, dtype=torch.int32, device=xyz.device)
@@ -524,6 +564,8 @@ class BatchNormMax(Function):
                                             nbt, _ptr(work), wb, _stream(x)), "bn_forward")
         ctx.save_for_backward(x, gamma, beta, mean, invstd, arg)
         ctx.relu = bool(relu)
+        if _pool_log is not None:
+            _pool_log[_next_pool_seq()] = arg
         ctx.mark_non_differentiable(mean, var_u)
         ctx.set_materialize_grads(False)  # no zero tensors for the statistics' (absent) gradients
         return y, mean, var_u
@@ -593,7 +635,8 @@ class SyncBatchNormFused(Function):
         work, wb = _bn_ws(C, dev)
         with torch.cuda.device(dev):
             _lib.check(lib.amc3d_bn_sums(B, C, L, _ptr(x), _ptr(sums), _ptr(work), wb, _stream(x)), "bn_sums")
-        dist.all_reduce(sums, group=group)
+        from . import graphs
+        graphs.collective(lambda: dist.all_reduce(sums, group=group))  # eager, between two captured segments (graphs.py)
         mean = torch.empty(C, dtype=torch.float32, device=dev)
         invstd = torch.empty_like(mean)
         var_u = torch.empty_like(mean)
@@ -635,7 +678,9 @@ class SyncBatchNormFused(Function):
             _lib.check(lib.amc3d_bn_backward_sums(B, C, L, K, int(ctx.relu), _ptr(x), _ptr(dy), aptr, _ptr(mean),
                                                   _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dsums), _ptr(dgamma),
                                                   _ptr(dbeta), _ptr(work), wb, _stream(x)), "bn_backward_sums")
-        dist.all_reduce(dsums, group=ctx.group)
+        from . import graphs
+        group = ctx.group
+        graphs.collective(lambda: dist.all_reduce(dsums, group=group))
         with torch.cuda.device(x.device):
             _lib.check(lib.amc3d_bn_backward_synced(B, C, L, K, int(ctx.relu), _ptr(x), _ptr(dy), aptr, _ptr(mean),
                                                     _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dsums),
@@ -758,37 +803,19 @@ def pointwise_conv(x, weight, bias=None):
     return PointwiseConv.apply(x, weight, bias)
 
 
-_wgrad_form = {}  # (B, Cin, Cout, P) -> "bmm" | "flat": the faster library form of the weight gradient, timed once
-
-
 def _library_wgrad(dy3, x3):
     """dW (Cout,Cin) = sum_b dy[b] . x[b]^T as plain library GEMMs: batched GEMM + sum over the batch, or one GEMM
-    over (batch x positions) when the batched form hits a slow library heuristic (256x256x375: 97 vs 25 us).  The
-    choice is timed once per shape outside graph capture and cached."""
+    over (batch x positions) where the batched form hits a slow library heuristic (256x256x375: 97 vs 25 us,
+    measured once on MI355X).  The form is a pure function of the shape -- the same in eager and captured runs and on
+    every rank, so the summation order (hence the bits of dW) never depends on timing; AMC3D_WGRAD_FORM=bmm|flat
+    overrides it."""
+    import os
     B, Cout, P = dy3.shape
     Cin = x3.shape[1]
-    forms = {"bmm": lambda: torch.bmm(dy3, x3.transpose(1, 2)).sum(0),
-             "flat": lambda: torch.matmul(dy3.transpose(0, 1).reshape(Cout, B * P),
-                                          x3.transpose(0, 1).reshape(Cin, B * P).t())}
-    key = (B, Cin, Cout, P)
-    form = _wgrad_form.get(key)
-    if form is None:
-        if torch.cuda.is_current_stream_capturing():
-            return forms["bmm"]()  # no timing inside a capture; decided at the next eager call
-        best = None
-        for name, fn in forms.items():
-            fn()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                fn()
-            e1.record()
-            e1.synchronize()
-            t = e0.elapsed_time(e1)
-            if best is None or t < best[0]:
-                best = (t, name)
-        form = _wgrad_form[key] = best[1]
-    return forms[form]()
+    form = os.environ.get("AMC3D_WGRAD_FORM") or ("flat" if P < 1024 and min(Cin, Cout) >= 128 else "bmm")
+    if form == "flat":
+        return torch.matmul(dy3.transpose(0, 1).reshape(Cout, B * P), x3.transpose(0, 1).reshape(Cin, B * P).t())
+    return torch.bmm(dy3, x3.transpose(1, 2)).sum(0)
 
 
 class LibraryGemmConv(Function):
@@ -804,6 +831,7 @@ class LibraryGemmConv(Function):
         B, Cin = x.shape[0], x.shape[1]
         Cout = weight.shape[0]
         w2 = weight.reshape(Cout, Cin)
+        timing.note("library_gemm_conv")
         # bmm with the weight expanded along the batch (stride 0): torch.matmul(2-d, 3-d) would fold the batch into one
         # GEMM by way of a transposed copy of x
         y = torch.bmm(w2.unsqueeze(0).expand(B, Cout, Cin), x.view(B, Cin, -1))
@@ -909,6 +937,7 @@ class SATail(Function):
             bn_update_running(bn2, mean2, var2)  # cumulative average: its own launch
         ctx.save_for_backward(y1, g1, b1, w2f, g2, b2, mean1, invstd1, mean2, invstd2)
         ctx.relu2, ctx.wshape = bool(relu2), tuple(w2.shape)
+        ctx.pool_seq = _next_pool_seq() if _pool_log is not None else None
         return pooled
 
     @staticmethod
@@ -927,11 +956,15 @@ class SATail(Function):
         dy1 = torch.empty_like(y1)
         dg1, db1 = torch.empty_like(g1), torch.empty_like(b1)
         work1, wb1 = _bn_ws(C1, dev, extra=C1 * 8)
+        arg = None
+        if ctx.pool_seq is not None and _pool_log is not None:  # tests: the forward pass keeps no arg-max, backward re-derives it
+            arg = _pool_log[ctx.pool_seq] = torch.empty(B, C2, M, dtype=torch.uint8, device=dev)
         flops = 2.0 * B * M * K * C1 * C2 * 4  # recompute twice + dx1 + dW2
         with torch.cuda.device(dev), timing.span("sa_tail_backward", y1.numel() * 4 * 6 + dpooled.numel() * 10, flops):
             _lib.check(lib.amc3d_sa_tail_backward(B, C1, C2, M, K, _ptr(y1), _ptr(mean1), _ptr(invstd1), _ptr(g1), _ptr(b1),
                                                   _ptr(w2f), _ptr(mean2), _ptr(invstd2), _ptr(g2), _ptr(b2), int(ctx.relu2),
                                                   _ptr(dpooled), _ptr(dx1), _ptr(dw2), _ptr(dg2), _ptr(db2),
+                                                  _ptr(arg) if arg is not None else None,
                                                   _ptr(work), wb, _stream(y1)), "sa_tail_backward")
             # BN1 + ReLU backward on the raw y1 (csrc/bn.hip)
             _lib.check(lib.amc3d_bn_backward(B, C1, M * K, 1, 1, _ptr(y1), _ptr(dx1), None, _ptr(mean1), _ptr(invstd1),

@@ -11,6 +11,23 @@ import torch
 
 _enabled = False
 _records = []  # (name, start_event, end_event, algorithmic_bytes, flops)
+calls = None   # a collections.Counter while count_calls() is active: operator name -> launches (dispatch evidence)
+
+
+class count_calls:
+    """with timing.count_calls() as c: ... -> c[name] = number of C-ABI launches of that operator inside the block
+    (no events, no synchronisation): the parity tests assert with it that a size took the kernels the bench times."""
+
+    def __enter__(self):
+        global calls
+        self.prev = calls
+        calls = collections.Counter()
+        return calls
+
+    def __exit__(self, *exc):
+        global calls
+        calls = self.prev
+        return False
 
 
 def enable(flag=True):
@@ -24,12 +41,20 @@ def enabled():
     return _enabled
 
 
+def note(name):
+    """count a dispatch that is not a C-ABI launch of its own (e.g. a library GEMM) while count_calls() is active"""
+    if calls is not None:
+        calls[name] += 1
+
+
 class span:
     """with timing.span('knnquery', bytes): launch(...)"""
     __slots__ = ("name", "nbytes", "flops", "start")
 
     def __init__(self, name, nbytes=0, flops=0.0):
         self.name, self.nbytes, self.flops, self.start = name, nbytes, flops, None
+        if calls is not None:
+            calls[name] += 1
 
     def __enter__(self):
         if _enabled:

@@ -11,14 +11,21 @@ sharded across ranks, one process per GPU, DDP + SyncBN over RCCL exactly as
 examples/segmentation/main_AA.py:146-152 does).  Inputs are resident in HBM before the timed
 region.  Rank 0 prints ONE JSON line.
 
+`--gpus N` without a torchrun environment starts the N ranks itself (a torch.distributed.run child process,
+launched before this process has made any GPU call) and prints their one line.
+
 Besides the contract fields the line carries
-  roofline      the dominant native kernel of the step (largest share of HIP-event time among
-                the C-ABI launches, measured live in the timed region on the launch stream):
-                algorithmic bytes per launch / average launch duration vs 8 TB/s HBM
-  cpu_baseline  the oracle's CPU restatement of the SAME step (oracle/model_ref.py on
-                oracle/pointops_ref.c, OpenMP + torch CPU threads) timed on this box's host cores,
-                rank 0 and N = 1 only, one step of the full batch
-  kernels       per-operator HIP-event totals for the timed region (ms per step)
+  roofline       the dominant native kernel ON THE STEP'S CRITICAL PATH (the feature half on the main stream;
+                 largest share of HIP-event time among its C-ABI launches, measured live): algorithmic bytes
+                 (or FLOPs) per launch / average launch duration vs 8 TB/s HBM (157.3 TFLOP/s fp32 MFMA)
+  roofline_step  the whole step against both roofs: SURVEY 8(d)'s algorithmic bytes and dense FLOPs per step /
+                 the measured step time, and the HBM bytes the PMC passes under profiles/ measured
+  latency_chain  the FPS chain (runs two steps ahead on a queue of its own): microseconds per dependent iteration
+  ms_per_step_no_overlap   the same parts replayed back to back on one stream
+  cpu_baseline   the oracle's CPU restatement of the SAME step (oracle/model_ref.py on oracle/pointops_ref.c,
+                 OpenMP + torch CPU threads) on this box's host cores, rank 0 and N = 1 only: 1 warm-up + 3 timed
+                 steps (median, forward / loss / backward split) at 2 clouds, 2 timed steps at the full batch
+  kernels        per-operator HIP-event totals for the timed region (ms per step)
 """
 import argparse
 import json
@@ -34,6 +41,11 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# SURVEY.md section 8(d) / BASELINE.md section 2: algorithmic work per POINT of a train step (forward x 3), derived there
+# for B=8 x N=24000 (S: 1.20 GB, 137.7 GF; L: 1.99 GB, 578.8 GF; XL: 4.26 GB, 3241 GF per 192000 points)
+ALGORITHMIC_PER_POINT = {"S": (1.197e9 / 192000, 137.7e9 / 192000), "L": (1.992e9 / 192000, 578.8e9 / 192000),
+                         "XL": (4.26e9 / 192000, 3241e9 / 192000)}
+GEOMETRY_OPS = ("furthest_point_sampling", "ball_query", "three_nn", "knnquery", "posmask", "ambiguity", "vote_labels")
 
 
 def parse():
@@ -52,10 +64,18 @@ def parse():
                     help="first-level FPS chains in flight (each for a different future batch; one launch per step)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="compute each batch's geometry inline instead of one step ahead on a side stream")
-    ap.add_argument("--sync-bn", action="store_true",
-                    help="N > 1: BatchNorm statistics over all ranks (the reference converts every BN layer to "
-                         "SyncBatchNorm when world_size > 1) on the fused kernels, one small RCCL all-reduce per layer "
-                         "and direction inside the captured step")
+    ap.add_argument("--sync-bn", action="store_true", help="(default at N > 1; kept for older command lines)")
+    ap.add_argument("--no-sync-bn", action="store_true",
+                    help="N > 1: per-rank BatchNorm statistics.  Default at N > 1 is the reference's behaviour "
+                         "(main_AA.py:146-148, 820: every BN layer becomes SyncBatchNorm): statistics over all ranks on "
+                         "the fused kernels, one small all-reduce per layer and direction issued eagerly BETWEEN the "
+                         "captured segments of the step (amcontrast3d_amd/graphs.py)")
+    ap.add_argument("--pool", type=int, default=4,
+                    help="distinct resident batches rotated through the pipeline (different geometry every step)")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="no GPU: run only the multi-rank control flow (launcher, process group, scene shards, flat "
+                         "gradient all-reduce, barrier/max timing, replica check) on a small torch CPU model over gloo; "
+                         "prints a line with metric 'rehearsal' (tests/test_dist_cpu.py)")
     ap.add_argument("--ddp", action="store_true",
                     help="N > 1: torch's SyncBatchNorm + DistributedDataParallel wrappers (eager), the literal "
                          "main_AA.py:146-152 recipe, as a cross-check of the two paths above")
@@ -95,8 +115,11 @@ def build(variant, dev, world, ddp, mm=False, sync_bn=False):
     return cfg, model, criterion, aargs, opt
 
 
-def cpu_baseline(cfg, model, batch_np, aargs_dict, points_per_step):
-    """One step of the oracle's CPU restatement on the same batch (bounded sample: one step)."""
+def cpu_baseline(cfg, model, batch_np, aargs_dict, points, small=2):
+    """The oracle's CPU restatement of the step on this box's host cores: 1 warm-up + 3 timed
+    steps at `small` clouds (median; forward / loss / backward split), then 2 timed steps of the full batch, whose median
+    is `value` (the same workload as the GPU line; ~1 minute of CPU work in all)."""
+    import statistics
     from oracle import model_ref, pointops_ref
     pointops_ref.build()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -106,14 +129,90 @@ def cpu_baseline(cfg, model, batch_np, aargs_dict, points_per_step):
     sd = {k: v.detach().cpu().clone() for k, v in (model.module if hasattr(model, "module") else model).state_dict().items()}
     cfg = json.loads(json.dumps(cfg))
     cfg["cls_args"]["dropout"] = 0
-    # drop the Dropout slot from the head keys is not needed: keys are looked up by name
-    data = {k: torch.from_numpy(v) for k, v in batch_np.items()}
+
+    def run(nclouds, reps, warm):
+        data = {k: torch.from_numpy(v[:nclouds]) for k, v in batch_np.items()}
+        rows = []
+        for i in range(warm + reps):
+            tm = {}
+            t0 = time.perf_counter()
+            model_ref.train_step(sd, cfg, data, data["y"], 13, None, aargs_dict, timings=tm)
+            tm["step"] = time.perf_counter() - t0
+            if i >= warm:
+                rows.append(tm)
+        return {k: statistics.median(r[k] for r in rows) for k in ("step", "forward", "loss", "backward")}
+
+    full = batch_np["pos"].shape[0]
+    small = min(small, full)
+    ms = run(small, 3, 1)
+    out = {"value": small * points / ms["step"], "unit": "points/s", "cores": cores, "kind": "port",
+           "sample": f"median of 3 steps after 1 warm-up, batch {small} x {points} points: {ms['step']:.2f} s/step "
+                     f"(forward {ms['forward']:.2f}, loss {ms['loss']:.2f}, backward {ms['backward']:.2f}); "
+                     f"oracle/model_ref.py + pointops_ref.c, OpenMP/torch {cores} threads; no optimizer step"}
+    if full > small and not os.environ.get("AMC3D_CPU_BASELINE_SMALL_ONLY"):
+        mf = run(full, 2, 0)
+        out["value_small_batch"] = out["value"]
+        out["value"] = full * points / mf["step"]
+        out["sample"] = (f"median of 2 steps, batch {full} x {points} points (the GPU line's workload): {mf['step']:.2f} s/step "
+                         f"(forward {mf['forward']:.2f}, loss {mf['loss']:.2f}, backward {mf['backward']:.2f}); and "
+                         + out["sample"])
+    return out
+
+
+def launch_ranks(args):
+    """`--gpus N` without a torchrun environment: start the N ranks as a CHILD process tree (torch.distributed.run) and
+    pass their output through.  This process has made no GPU call (importing torch makes none), so nothing that
+    touched the GPU is ever re-executed or forked."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def rehearse_cpu(args):
+    """The N-rank control flow of main() on a stand-in torch CPU model over gloo (no kernels): what the CPU test suite
+    can check of the multi-GPU path -- that `--gpus N` starts N ranks, shards scenes, keeps replicas in sync through
+    the flat gradient all-reduce and reports max-over-ranks time on rank 0."""
+    from amcontrast3d_amd import dist as adist
+    rank, local, world = adist.init_from_env(backend="gloo")
+    ids = adist.scene_ids(rank, world, args.batch)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 32), torch.nn.ReLU(), torch.nn.Linear(32, 4))
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    params = list(net.parameters())
+    flatg = adist.FlatGradients(params, accumulate=False)
+    adist.barrier()
     t0 = time.perf_counter()
-    model_ref.train_step(sd, cfg, data, data["y"], 13, None, aargs_dict)
-    dt = time.perf_counter() - t0
-    return {"value": points_per_step / dt, "unit": "points/s", "cores": cores, "kind": "port",
-            "sample": f"1 step, batch {data['pos'].shape[0]} x {data['pos'].shape[1]} points, {dt:.1f} s "
-                      f"(oracle/model_ref.py + pointops_ref.c, OpenMP/torch {cores} threads; no optimizer step)"}
+    for step in range(args.warmup + args.steps):
+        x = torch.randn(16, 8, generator=torch.Generator().manual_seed(1000 * ids[0] + step))
+        flatg.zero()
+        net(x).square().mean().backward()
+        flatg.gather()
+        flatg.allreduce()
+        opt.step()
+    adist.barrier()
+    dt = adist.max_over_ranks(time.perf_counter() - t0, torch.device("cpu"))
+    sync = True
+    if world > 1:
+        import torch.distributed as tdist
+        chk = torch.stack([p.detach().double().sum() for p in params])
+        lo, hi = chk.clone(), chk.clone()
+        tdist.all_reduce(lo, op=tdist.ReduceOp.MIN)
+        tdist.all_reduce(hi, op=tdist.ReduceOp.MAX)
+        sync = bool(torch.equal(lo, hi))
+    if rank == 0:
+        print(json.dumps({"metric": "rehearsal", "value": 0.0, "unit": "none", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(dt / max(1, args.steps) * 1e3, 3),
+                          "replicas_in_sync": sync, "scene_ids_rank0": ids, "data": "synthetic"}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 def eval_main(args):
@@ -175,13 +274,16 @@ def eval_main(args):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))  # children do the work; this process never touches the GPU
+    if args.rehearse_cpu:
+        return rehearse_cpu(args)
     if args.eval:
         return eval_main(args)
     from amcontrast3d_amd import _lib, configs, dist as adist, synthetic, timing
     rank, local, world = adist.init_from_env()
-    if world != args.gpus and not (world == 1 and args.gpus == 1):
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}: the environment's world size is used", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the product path)"
     local = local % torch.cuda.device_count()  # (rehearsals put several ranks on one card; a real node has one each)
     torch.cuda.set_device(local)
@@ -189,8 +291,8 @@ def main():
     _lib.load()
 
     use_ddp = world > 1 and args.ddp
-    sync_bn = world > 1 and args.sync_bn and not use_ddp
-    if args.sync_bn and world == 1 and os.environ.get("AMC3D_FORCE_SYNC_BN"):
+    sync_bn = world > 1 and not args.no_sync_bn and not use_ddp  # the reference's behaviour whenever distributed
+    if not args.no_sync_bn and world == 1 and os.environ.get("AMC3D_FORCE_SYNC_BN"):
         # rehearsal on a one-GPU box: a one-rank RCCL group, so that the captured step contains the all-reduces
         import torch.distributed as tdist
         import amcontrast3d_amd
@@ -202,9 +304,14 @@ def main():
         blocks._FORCE_SYNCED_BN = sync_bn = True
     use_graph = not args.no_graph and not use_ddp
     cfg, model, criterion, aargs, opt = build(args.variant, dev, world, use_ddp, args.mm, sync_bn)
-    ids = adist.scene_ids(rank, world, args.batch)
-    nb = synthetic.make_batch(args.batch, args.points, first_id=ids[0])
-    data = {k: torch.from_numpy(v).to(dev) for k, v in nb.items()}
+    # `--pool` distinct resident batches rotate through the pipeline: every step sees another cloud geometry (k-NN tie
+    # counts, grid occupancy, cache contents), as a training loop would; scene ids are disjoint across ranks and steps
+    npool = max(1, args.pool)
+    pool_np = [synthetic.make_batch(args.batch, args.points, first_id=adist.scene_ids(rank, world, args.batch, step=j)[0])
+               for j in range(npool)]
+    nb = pool_np[0]
+    pool = [{k: torch.from_numpy(v).to(dev) for k, v in b.items()} for b in pool_np]
+    data = {k: v.clone() for k, v in pool[0].items()}  # the feature half's static input buffers (batch t)
     params = list(model.parameters())
     # N > 1: gradients live in one flat buffer, exchanged by a single RCCL all-reduce between the two captured halves
     flatg = (adist.FlatGradients(params, accumulate=bool(os.environ.get("AMC3D_FLAT_ACCUMULATE")))
@@ -276,41 +383,63 @@ def main():
     head = criterion.contrast_head
     nlevels = len(list((model.module if hasattr(model, "module") else model).encoder.encoder))
 
-    def geo_fps_first():  # encoder stage 0 is the stride-1 stem (no sampling); stage 1 holds the first FPS
-        return geometry.precompute_fps_levels(model, data["pos"], 0, 2)
+    def geo_fps_first(batch):  # encoder stage 0 is the stride-1 stem (no sampling); stage 1 holds the first FPS
+        return geometry.precompute_fps_levels(model, batch["pos"], 0, 2)
 
     def geo_fps_tail(first_level):
         return geometry.precompute_fps_levels(model, first_level[-1]["new_p"], 2, nlevels)
 
-    def geo_rest(fps):
-        return geometry.precompute_rest(model, head, data, fps, 13, None, aargs)
+    def geo_rest(batch, fps):
+        return geometry.precompute_rest(model, head, batch, fps, 13, None, aargs)
 
+    def copy_batch(dst, src):
+        for k in dst:
+            if k != "_geometry":
+                dst[k].copy_(src[k])
+
+    # the pipeline's period: lane and pool index of step s are s % lanes and (s + lanes + 3) % npool
+    import math
+    period = lanes * npool // math.gcd(lanes, npool) if overlap else npool
     if overlap:
-        a1_out = [geo_fps_first() for _ in range(lanes)]  # written by streams A1[lane]: first FPS level
-        a1_stable = geometry.clone(a1_out[0])  # batch t+2: read by stream A2
+        # every in-flight batch has its own static input buffers, handed down the pipeline by rotate():
+        #   in_a[lane] (first FPS level, batches t+3..) -> in_a1s (FPS levels 2-4, t+2) -> in_b (neighbourhoods, t+1) -> data (t)
+        in_b = {k: v.clone() for k, v in pool[1 % npool].items()}
+        in_a1s = {k: v.clone() for k, v in pool[2 % npool].items()}
+        in_a = [{k: v.clone() for k, v in pool[(3 + l) % npool].items()} for l in range(lanes)]
+        a1_out = [geo_fps_first(in_a[l]) for l in range(lanes)]  # written by streams A1[lane]: first FPS level
+        a1_stable = geometry.clone(geo_fps_first(in_a1s))  # batch t+2: read by stream A2
         a2_out = geo_fps_tail(a1_stable)       # written by stream A2 (batch t+2): FPS levels 2..4
-        a_stable = geometry.clone(a1_stable + a2_out)  # batch t+1: read by stream B
-        b_full = geo_rest(a_stable)            # stream B (batch t+1): neighbourhoods, 3-NN, loss geometry
-        b_out = geometry.split(b_full)[1]
-        cur = geometry.clone(b_full)           # batch t: read by the feature half
+        fb = geo_fps_first(in_b)
+        a_stable = geometry.clone(fb + geo_fps_tail(fb))  # batch t+1: read by stream B
+        b_out = geometry.split(geo_rest(in_b, a_stable))[1]  # stream B (batch t+1): neighbourhoods, 3-NN, loss geometry
+        fc = geo_fps_first(data)
+        cur = geometry.clone(geo_rest(data, fc + geo_fps_tail(fc)))  # batch t: read by the feature half
         cur_fps, cur_rest = geometry.split(cur)
         data["_geometry"] = cur
         torch.cuda.synchronize()
 
-    def rotate(lane=0):  # main stream, between steps: advance the pipeline buffers by one batch
+    def rotate(s=0):  # main stream, between steps: advance every pipeline buffer by one batch
+        if not overlap:
+            copy_batch(data, pool[s % npool])
+            return
+        lane = s % lanes
         geometry.copy_into(cur_fps, a_stable)
         geometry.copy_into(cur_rest, b_out)
+        copy_batch(data, in_b)
         geometry.copy_into(a_stable, a1_stable + a2_out)
+        copy_batch(in_b, in_a1s)
         geometry.copy_into(a1_stable, a1_out[lane])
+        copy_batch(in_a1s, in_a[lane])
+        copy_batch(in_a[lane], pool[(s + lanes + 3) % npool])
 
     def body_a(lane=0):
-        geometry.copy_into(a1_out[lane], geo_fps_first())
+        geometry.copy_into(a1_out[lane], geo_fps_first(in_a[lane]))
 
     def body_a2():
         geometry.copy_into(a2_out, geo_fps_tail(a1_stable))
 
     def body_b():
-        geometry.copy_into(b_out, geometry.split(geo_rest(a_stable))[1])
+        geometry.copy_into(b_out, geometry.split(geo_rest(in_b, a_stable))[1])
 
     def update():
         torch.nn.utils.clip_grad_norm_(params, 10, norm_type=2)
@@ -319,14 +448,17 @@ def main():
     step_no = [0]
 
     def run_step(f_rotate, f_a, f_a2, f_b, f_feat, f_update):
+        sidx = step_no[0] % period
+        step_no[0] += 1
+        if not overlap:
+            f_rotate[sidx]()
         if overlap:
-            lane = step_no[0] % lanes  # the FPS lane launched `lanes` steps ago delivers now and is relaunched
-            step_no[0] += 1
+            lane = sidx % lanes  # the FPS lane launched `lanes` steps ago delivers now and is relaunched
             # events, not stream waits: several parts may share a queue (the other lane's FPS is still running)
             main_s.wait_event(ev_lane[lane])
             main_s.wait_event(ev_a2)
             main_s.wait_event(ev_b)
-            f_rotate[lane]()
+            f_rotate[sidx]()
             ev_main.record(main_s)
             skip = os.environ.get("AMC3D_SKIP", "")  # diagnostic: leave pipeline parts out (results go stale, timing only)
             with torch.cuda.stream(s_a[lane]):
@@ -352,7 +484,7 @@ def main():
     def eager_step():
         if flatg is None:
             opt.zero_grad(set_to_none=True)
-        run_step([lambda l=l: rotate(l) for l in range(lanes)], [lambda l=l: body_a(l) for l in range(lanes)], body_a2,
+        run_step([lambda j=j: rotate(j) for j in range(period)], [lambda l=l: body_a(l) for l in range(lanes)], body_a2,
                  body_b, fwd_bwd, update)
 
     step = eager_step
@@ -364,20 +496,27 @@ def main():
         torch.cuda.synchronize()
         if flatg is None:
             opt.zero_grad(set_to_none=True)
-        names = ["a2", "b", "feat", "update"] + [f"rotate{l}" for l in range(lanes)] + [f"fps{l}" for l in range(lanes)]
+        names = ["a2", "b", "feat", "update"] + [f"rotate{j}" for j in range(period)] + [f"fps{l}" for l in range(lanes)]
         graphs = {k: torch.cuda.CUDAGraph() for k in names}
         cap = main_s if not os.environ.get("AMC3D_CAPTURE_SIDE") else torch.cuda.Stream()
         # with a process group alive, RCCL's watchdog thread polls events while we capture: only this thread's calls
         # may be policed by the capture (the default "global" mode turns that poll into a fatal error)
         cap_mode = os.environ.get("AMC3D_CAPTURE_MODE") or ("thread_local" if world > 1 or sync_bn else "global")
-        with torch.cuda.graph(graphs["feat"], stream=cap, capture_error_mode=cap_mode):
-            fwd_bwd()
+        if sync_bn:
+            # the SyncBatchNorm statistics all-reduces are NOT captured: the feature half becomes a chain of graphs with
+            # the collectives issued eagerly between them (amcontrast3d_amd/graphs.py)
+            from amcontrast3d_amd.graphs import SegmentedGraph
+            graphs["feat"] = SegmentedGraph(cap_mode).capture(fwd_bwd, stream=cap)
+        else:
+            with torch.cuda.graph(graphs["feat"], stream=cap, capture_error_mode=cap_mode):
+                fwd_bwd()
         with torch.cuda.graph(graphs["update"], stream=cap, capture_error_mode=cap_mode):
             update()
+        for j in range(period):
+            with torch.cuda.graph(graphs[f"rotate{j}"], stream=cap, capture_error_mode=cap_mode):
+                rotate(j)
         if overlap:
             for l in range(lanes):
-                with torch.cuda.graph(graphs[f"rotate{l}"], stream=cap, capture_error_mode=cap_mode):
-                    rotate(l)
                 with torch.cuda.graph(graphs[f"fps{l}"], stream=s_a[l], capture_error_mode=cap_mode):
                     body_a(l)
             with torch.cuda.graph(graphs["a2"], stream=s_a2, capture_error_mode=cap_mode):
@@ -387,7 +526,7 @@ def main():
         torch.cuda.synchronize()
 
         def step():
-            run_step([graphs[f"rotate{l}"].replay for l in range(lanes)], [graphs[f"fps{l}"].replay for l in range(lanes)],
+            run_step([graphs[f"rotate{j}"].replay for j in range(period)], [graphs[f"fps{l}"].replay for l in range(lanes)],
                      graphs["a2"].replay, graphs["b"].replay, graphs["feat"].replay, graphs["update"].replay)
 
     for _ in range(args.warmup):
@@ -429,7 +568,7 @@ def main():
             ref = torch.cuda.Event(enable_timing=True)
             ref.record(main_s)
             h0 = time.perf_counter()
-            run_step([timed(graphs[f"rotate{l}"].replay, main_s, "rotate", log) for l in range(lanes)],
+            run_step([timed(graphs[f"rotate{j}"].replay, main_s, "rotate", log) for j in range(period)],
                      [timed(graphs[f"fps{l}"].replay, s_a[l], f"fps{l}", log) for l in range(lanes)],
                      timed(graphs["a2"].replay, s_a2, "a2", log), timed(graphs["b"].replay, s_b, "b", log),
                      timed(graphs["feat"].replay, main_s, "feat", log), timed(graphs["update"].replay, main_s, "update", log))
@@ -441,7 +580,8 @@ def main():
         torch.cuda.synchronize()
 
     parts = None
-    if use_graph and overlap and rank == 0:
+    no_overlap_ms = None
+    if use_graph and overlap:  # on every rank: with SyncBN the feature replay contains collectives
         # each pipeline part alone (back-to-back replays on its stream): what the overlap has to hide
         def alone(fn, stream, reps=5):
             torch.cuda.synchronize()
@@ -455,6 +595,23 @@ def main():
                  "fps_level1_ms": alone(graphs["fps0"].replay, s_a[0]), "fps_levels2to4_ms": alone(graphs["a2"].replay, s_a2),
                  "neighbourhood_geometry_ms": alone(graphs["b"].replay, s_b),
                  "rotate_ms": alone(graphs["rotate0"].replay, main_s)}
+
+        # the same step with nothing overlapped: every part replayed back to back on the main stream
+        def serial(reps=5):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for r in range(reps):
+                graphs[f"rotate{r % period}"].replay()
+                graphs[f"fps{r % lanes}"].replay()
+                graphs["a2"].replay()
+                graphs["b"].replay()
+                graphs["feat"].replay()
+                if flatg is not None:
+                    flatg.allreduce()
+                graphs["update"].replay()
+            torch.cuda.synchronize()
+            return round((time.perf_counter() - t) / reps * 1e3, 3)
+        no_overlap_ms = serial()
 
     # per-operator HIP-event timing: the same step, launched eagerly so each C-ABI launch can be
     # bracketed by events on its stream (events cannot bracket nodes inside a graph replay)
@@ -476,7 +633,6 @@ def main():
         points_per_step = args.batch * args.points
         ms_per_step = dt / args.steps * 1e3
         value = points_per_step * world / (dt / args.steps)
-        dom_name, dom = max(kernels.items(), key=lambda kv: kv[1]["total_ms"]) if kernels else (None, None)
         # HBM bytes per launch from the PMC passes committed under profiles/ (collected with rocprofv3 --pmc in
         # separate runs, as gpurun requires; None for operators that were not measured)
         traffic = {}
@@ -485,43 +641,75 @@ def main():
                 traffic = json.load(fh)
         except OSError:
             pass
+
+        def kernel_roofline(name, v):
+            """bytes (or FLOPs) of all launches of the operator / their summed HIP-event time, against the roof its
+            arithmetic intensity puts it under (machine balance 157.3 TF / 8 TB/s ~ 20 flop/byte)"""
+            nbytes, fl, tms = v["bytes"], v["flops"] * (args.steps / ksteps), v["total_ms"]
+            per_launch = {"avg_launch_ms": round(v["avg_ms"], 4), "launches_per_step": v["launches"] / args.steps,
+                          "ms_per_step": round(tms / args.steps, 4),
+                          "traffic": traffic.get(name, {}).get("bytes_per_launch")}
+            if fl > 0 and fl / max(nbytes, 1) > F32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+                ach = fl / (tms * 1e-3) / 1e12
+                return dict({"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                             "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+                             "algorithmic_flops_per_launch": fl / max(v["launches"], 1)}, **per_launch)
+            ach = nbytes / (tms * 1e-3) / 1e9
+            return dict({"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(v["bytes_per_launch"])},
+                        **per_launch)
+
+        # the dominant kernel of the critical path: with the pipeline on, the geometry operators (FPS chain, searches,
+        # loss geometry) run one to four steps ahead on their own queues and the feature half bounds the step
+        crit = {k: v for k, v in kernels.items() if not (overlap_was and k in GEOMETRY_OPS)}
         roofline = None
-        if dom is not None:
-            achieved = dom["bytes_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                        "traffic": traffic.get(dom_name, {}).get("bytes_per_launch"),
-                        "avg_launch_ms": round(dom["avg_ms"], 4), "launches_per_step": dom["launches"] / args.steps,
-                        "algorithmic_bytes_per_launch": int(dom["bytes_per_launch"])}
-        # the largest bandwidth-bound native kernel family next to it (FPS is a latency chain: its HBM
-        # fraction says nothing about kernel quality)
+        if crit:
+            dom_name, dom = max(crit.items(), key=lambda kv: kv[1]["total_ms"])
+            roofline = kernel_roofline(dom_name, dom)
+            roofline["note"] = ("largest HIP-event time among the operators of the feature half (the stream that bounds "
+                                "the overlapped step); the FPS chain is reported under latency_chain")
         hbm_names = [k for k in kernels if k.startswith("bn_") or k in ("group_points", "group_points_grad",
                      "three_interpolate", "three_interpolate_grad", "contrast_forward", "contrast_backward")]
-        roofline_hbm = None
-        if hbm_names:
-            hk = max(hbm_names, key=lambda k: kernels[k]["total_ms"])
-            hv = kernels[hk]
-            ach = hv["bytes"] / (hv["total_ms"] * 1e-3) / 1e9
-            roofline_hbm = {"bound": "hbm", "kernel": hk, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(ach / HBM_PEAK_GBS, 4),
-                            "traffic": traffic.get(hk, {}).get("bytes_per_launch"),
-                            "algorithmic_bytes_per_launch": int(hv["bytes_per_launch"]),
-                            "ms_per_step": round(hv["total_ms"] / args.steps, 3),
-                            "launches_per_step": hv["launches"] / args.steps,
-                            "note": "algorithmic bytes of all launches of this operator / their summed HIP-event time"}
-        # the dense contractions (fused grouped conv + pointwise conv, fp32 MFMA): FLOP rate against the f32 MFMA peak
+        roofline_hbm = kernel_roofline(*max(((k, kernels[k]) for k in hbm_names), key=lambda kv: kv[1]["total_ms"])) \
+            if hbm_names else None
+        # the dense contractions together (fused grouped conv + pointwise conv + SetAbstraction tail, fp32 MFMA)
         roofline_mfma = None
-        mf = [k for k in kernels if k.startswith("grouped_conv") or k.startswith("pointwise_conv")]
+        mf = [k for k in kernels if k.startswith(("grouped_conv", "pointwise_conv", "sa_tail", "local_aggregation"))]
         if mf:
             fl = sum(kernels[k]["flops"] for k in mf) * (args.steps / ksteps)
             tm = sum(kernels[k]["total_ms"] for k in mf)
             ach = fl / (tm * 1e-3) / 1e12
-            roofline_mfma = {"bound": "mfma", "kernel": "grouped_conv + pointwise_conv (forward, backward-data, backward-weight)",
-                             "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                             "ms_per_step": round(tm / args.steps, 3),
-                             "note": "K = C+3 <= 131 contractions over (B,C,P) tensors: HBM-bound by construction, "
-                                     "reported for completeness"}
+            roofline_mfma = {"bound": "mfma", "kernel": "+".join(sorted(mf)), "achieved": round(ach, 2),
+                             "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+                             "traffic": None, "ms_per_step": round(tm / args.steps, 3),
+                             "note": "launched FLOPs (recomputation included) of every MFMA operator / their summed time"}
+        # the FPS chain: one workgroup per cloud, n/4 dependent iterations -- a latency figure, not a bandwidth one
+        latency_chain = None
+        if "furthest_point_sampling" in kernels:
+            lvl1 = parts["fps_level1_ms"] if parts else None
+            fv = kernels["furthest_point_sampling"]
+            its = args.points // 4
+            latency_chain = {"kernel": "furthest_point_sampling", "level1_iterations": its,
+                             "level1_ms": lvl1, "us_per_iteration": round(lvl1 * 1e3 / its, 3) if lvl1 else None,
+                             "all_levels_ms_per_step": round(fv["total_ms"] / args.steps, 3),
+                             "cus_busy": args.batch, "hbm_bytes_per_launch": traffic.get("furthest_point_sampling", {}).get("bytes_per_launch"),
+                             "note": "serial arg-max chain, hidden by running 2 batches ahead on its own hardware queue"}
+        # the whole step against both roofs (SURVEY 8(d) algorithmic work)
+        roofline_step = None
+        if args.variant in ALGORITHMIC_PER_POINT and not args.mm:
+            bpp, fpp = ALGORITHMIC_PER_POINT[args.variant]
+            ab, af = bpp * points_per_step, fpp * points_per_step
+            meas = traffic.get("_step", {}).get("bytes_per_step") if (args.variant == "S" and args.batch == 8 and args.points == 24000) else None
+            roofline_step = {"algorithmic_GB": round(ab / 1e9, 3), "algorithmic_GFLOP": round(af / 1e9, 1),
+                             "ms": round(ms_per_step, 3),
+                             "hbm_GBps": round(ab / (ms_per_step * 1e-3) / 1e9, 1),
+                             "hbm_frac": round(ab / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "mfma_TFLOPs": round(af / (ms_per_step * 1e-3) / 1e12, 2),
+                             "mfma_frac": round(af / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                             "measured_hbm_GB": round(meas / 1e9, 2) if meas else None,
+                             "algorithmic_over_measured": round(ab / meas, 3) if meas else None,
+                             "note": "algorithmic = SURVEY 8(d) (ideal fusion, forward x 3); measured = sum of FETCH_SIZE x 2 + "
+                                     "WRITE_SIZE over every kernel of one step (profiles/, rocprofv3 --pmc passes)"}
         line = {
             "metric": "train-step points/sec (fwd+bwd) on 24k-pt S3DIS clouds",
             "value": round(value, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -538,7 +726,11 @@ def main():
                                    if overlap_was else "none"},
             "loss": round(final_loss, 6),
             "replicas_in_sync": replicas_in_sync,
+            "ms_per_step_no_overlap": no_overlap_ms,
+            "resident_batches": npool,
             "roofline": roofline,
+            "roofline_step": roofline_step,
+            "latency_chain": latency_chain,
             "roofline_hbm": roofline_hbm,
             "roofline_mfma": roofline_mfma,
             "kernels": {k: {"ms_per_step": round(v["total_ms"] / args.steps, 4),
@@ -547,9 +739,8 @@ def main():
             "pipeline_parts_alone": parts,
         }
         if world == 1 and not args.no_cpu_baseline:
-            b = args.cpu_baseline_batch or args.batch
-            sample = {k: v[:b] for k, v in nb.items()}
-            line["cpu_baseline"] = cpu_baseline(cfg, model, sample, configs.ambiguity_args("s3dis"), b * args.points)
+            line["cpu_baseline"] = cpu_baseline(cfg, model, nb, configs.ambiguity_args("s3dis"), args.points,
+                                                small=args.cpu_baseline_batch)
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

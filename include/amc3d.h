@@ -247,12 +247,15 @@ int amc3d_sa_tail_forward(int B, int C1, int C2, int M, int K, const float *y1, 
                           float *pooled, float *mean2, float *invstd2, float *var_unbiased2,
                           float *running_mean2, float *running_var2, long long *num_batches_tracked2,
                           void *workspace, size_t workspace_bytes, void *stream);
-/* dx1 (B,C1,M,32) = gradient w.r.t. relu(bn1(y1)); dw2 (C2,C1) deterministic; dgamma2, dbeta2 (C2) */
+/* dx1 (B,C1,M,32) = gradient w.r.t. relu(bn1(y1)); dw2 (C2,C1) deterministic; dgamma2, dbeta2 (C2);
+ * arg_out (B,C2,M) bytes or NULL: the neighbour each pooled gradient was routed to (what torch.max returns as
+ * indices, pointnext_AA.py:166) -- the parity tests hold the routing fixed with it */
 int amc3d_sa_tail_backward(int B, int C1, int C2, int M, int K, const float *y1, const float *mean1,
                            const float *invstd1, const float *gamma1, const float *beta1, const float *w2,
                            const float *mean2, const float *invstd2, const float *gamma2, const float *beta2,
                            int relu2, const float *dpooled, float *dx1, float *dw2,
-                           float *dgamma2, float *dbeta2, void *workspace, size_t workspace_bytes, void *stream);
+                           float *dgamma2, float *dbeta2, unsigned char *arg_out, void *workspace,
+                           size_t workspace_bytes, void *stream);
 
 /* ---- training-mode BatchNorm fused with ReLU / neighbourhood max-pool ---------------------------
  * The reference runs nn.Conv -> nn.BatchNorm -> nn.ReLU(inplace) [-> torch.max over the neighbours]

@@ -97,3 +97,30 @@ def test_single_process_defaults():
     assert adist.allreduce_gradients([]) == 0
     m = torch.nn.Linear(2, 2)
     assert adist.wrap_data_parallel(m, torch.device("cpu"), 1) is m
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no torchrun environment: the parent (no GPU call) starts two ranks as children
+    and rank 0 prints ONE line with n_gpus 2 -- here on the CPU rehearsal path (gloo, stand-in model): scene shards are
+    disjoint, the flat gradient all-reduce keeps the replicas bit-identical."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-cpu", "--steps", "3",
+                          "--warmup", "1", "--batch", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["replicas_in_sync"] is True and line["scene_ids_rank0"] == [0, 1, 2, 3]
+
+
+def test_segmented_graph_orders_graphs_and_collectives():
+    """graphs.SegmentedGraph without a GPU: collective() outside a capture just runs the call (the eager path)."""
+    from amcontrast3d_amd import graphs
+    seen = []
+    assert graphs.collective(lambda: seen.append(1) or 7) == 7 and seen == [1]
+    sg = graphs.SegmentedGraph()
+    assert sg.segments == 0 and sg.collectives == 0

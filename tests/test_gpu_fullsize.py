@@ -1,0 +1,183 @@
+"""Parity at the sizes the bench times: the product on the MI355X against the oracle's CPU
+restatement of the same train step (forward + CrossEntropyAce / CrossEntropyAcePre + backward) on the same seeded
+batch, at BASELINE.json's configurations:
+
+    cfg 2   PointNeXt-S,  8 x 24000 points (and 2 x 24000, the bench's cpu_baseline sample)
+    cfg 3   PointNeXt-L (width 32, blocks [1,3,5,3,3]), 2 x 24000 points per step of the oracle (the per-GPU batch of 8 is
+            the same kernels on 4x the positions; 2 clouds keep the CPU side at ~10 s)
+    cfg 4   PointNeXt-XL + AMContrast3D++ (MM), 1 x 64000 points (ScanNet-sized cloud, voxel 0.02)
+
+Kernel dispatch is size dependent (blocks._pw_pays, amc3d_sa_tail_pays, grid vs all-pairs searches, library GEMMs
+below 65536 positions), so every case also asserts WHICH operators ran (timing.count_calls): the fused paths the
+bench's numbers come from are the ones compared here.
+
+Tolerances: sampled coordinates (FPS picks) bit-exact; logits, loss, decoder embeddings within 1e-4 (north star).
+
+Gradients.  Two things limit how closely two correct fp32 evaluations of this step agree, and the test removes both
+instead of widening the tolerance (tests/test_gpu_model.py's 3e-2):
+  * the 32-neighbour max-pools route each gradient to ONE element and near-ties flip under any reassociation: the
+    oracle's pools gather at the arg-max the GPU kernels used (ops.pool_log -> model_ref.PoolRouting), so the routing
+    is the same in every run compared here;
+  * with the routing fixed, the CPU oracle in fp32 still differs from the same oracle in fp64 by up to 1e-2 per
+    parameter (the gradient passes through 17-58 batch-statistics BatchNorms; measured, see the printed table): the
+    step is ill-conditioned in fp32, whoever evaluates it.  So the yardstick is the fp64 run ("truth", features and
+    weights in double, coordinate-derived inputs as the fp32 values the reference computes): per parameter the GPU's
+    distance to truth must not exceed NOISE_FACTOR x the CPU-fp32 run's distance to truth (+ 2e-4 of the norm).  A
+    wrong term in any backward kernel moves its parameters by O(1), orders above that band.
+No fixture covers these sizes (the reference cannot run here at all: CUDA-only natives); the oracle itself is pinned
+at small sizes by tests/test_oracle_model.py -- parity at these sizes is unpinned by the reference in that sense.
+"""
+import numpy as np
+import pytest
+import torch
+
+from amcontrast3d_amd import configs
+
+pytestmark = pytest.mark.gpu
+
+NOISE_FACTOR = 6.0
+
+
+def _easy(d):
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from openpoints.utils import EasyConfig
+    c = EasyConfig()
+    c.update(d)
+    return c
+
+
+def _build(cfg, mm, dev):
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from openpoints.loss import build_criterion_from_cfg
+    from openpoints.models import build_model_from_cfg
+    torch.manual_seed(0)
+    model = build_model_from_cfg(_easy(cfg)).to(dev).train()
+    crit = build_criterion_from_cfg(_easy(configs.criterion_cfg_mm() if mm else configs.criterion_cfg())).to(dev)
+    return model, crit
+
+
+def _step(variant, B, N, mm, voxel):
+    """-> (gpu results, oracle results, dispatch counter)"""
+    from amcontrast3d_amd import ops, synthetic, timing
+    from oracle import model_ref, pointops_ref
+    import os
+    dev = torch.device("cuda:0")
+    cfg = configs.model_cfg_mm(variant, dropout=0) if mm else configs.model_cfg(variant, dropout=0)
+    model, crit = _build(cfg, mm, dev)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    nb = synthetic.make_batch(B, N, first_id=300, voxel_size=voxel)
+    cpu = {k: torch.from_numpy(v) for k, v in nb.items()}
+    gpu = {k: v.to(dev) for k, v in cpu.items()}
+    aa = configs.ambiguity_args_mm("s3dis") if mm else configs.ambiguity_args("s3dis")
+    log = {}
+    ops.pool_log(log)
+    try:
+        with timing.count_calls() as calls:
+            if mm:
+                logits, stage, _ = model(gpu)
+                seg, ce, contrast, reg = crit(logits, gpu["y"], stage, 13, None, _easy(aa))
+                loss = seg + reg
+            else:
+                logits, stage = model(gpu)
+                loss = crit(logits, gpu["y"], stage, 13, None, _easy(aa))
+            loss.backward()
+            torch.cuda.synchronize()
+            calls = dict(calls)
+    finally:
+        ops.pool_log(None)
+    got = {"logits": logits.detach().cpu(), "loss": float(loss), "p_out": [s["p_out"].cpu() for s in stage["up"]],
+           "f_out": [s["f_out"].detach().cpu() for s in stage["up"]],
+           "grads": {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None}}
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    pointops_ref.set_threads(threads)
+    torch.set_num_threads(threads)
+    pool = model_ref.PoolRouting({i: a.cpu() for i, a in log.items()})
+    step = model_ref.train_step_mm if mm else model_ref.train_step
+    want = step(sd, cfg, cpu, cpu["y"], 13, None, aa, pool=pool)
+    assert len(log) == pool.seq, "every max-pool of the model reported its arg-max"
+    sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    cpu64 = dict(cpu)
+    cpu64["x"] = cpu["x"].double()
+    truth = step(sd64, cfg, cpu64, cpu["y"], 13, None, aa, pool=model_ref.PoolRouting(pool.override))
+    want["grads64"] = truth["grads"]
+    want["logits64"], want["loss64"] = truth["logits"], float(truth["loss"])
+    flips = sum(int((pool.record[i] != pool.override[i].long()).sum()) for i in log)
+    total = sum(a.numel() for a in log.values())
+    print(f"[{variant} {B}x{N}{' MM' if mm else ''}] max-pool picks differing from the CPU run's own: {flips} of {total}")
+    return got, want, calls
+
+
+def _compare(got, want, mm):
+    for i in range(4):  # FPS picks -> sampled clouds: exact
+        np.testing.assert_array_equal(got["p_out"][i].numpy(), want["stage"]["up"][i]["p_out"].numpy())
+    # logits: 1e-4 (north star) wherever fp32 can deliver it; on the deep variants the CPU oracle's own fp32 run is
+    # further than that from its fp64 run, and the band widens to NOISE_FACTOR x that distance
+    scale = max(1.0, float(want["logits"].abs().max()))
+    dg = (got["logits"] - want["logits"]).abs()
+    dc = (want["logits"].double() - want["logits64"]).abs()
+    dg64 = (got["logits"].double() - want["logits64"]).abs()
+    q = lambda t, f: float(torch.quantile(t.flatten()[:: max(1, t.numel() // 4000000)].double(), f))
+    print(f"logits |GPU-CPU32| max {float(dg.max()):.2e} p99.99 {q(dg, 0.9999):.2e} | |CPU32-CPU64| max {float(dc.max()):.2e} "
+          f"p99.99 {q(dc, 0.9999):.2e} | |GPU-CPU64| max {float(dg64.max()):.2e}; elements over 1e-4*scale: "
+          f"{int((dg > 1e-4 * scale).sum())} of {dg.numel()}; loss {got['loss']:.6f} / {float(want['loss']):.6f} / {want['loss64']:.6f}")
+    band = max(1e-4 * scale, NOISE_FACTOR * float(dc.max()))
+    if mm:
+        # the masked refinement replaces a point's features when its PREDICTED ambiguity crosses a threshold
+        # (MaskedRefine.py:60-98): a point within rounding of the threshold switches in one run and not in the other and its
+        # logits move by O(1) -- a property of the model, present between the CPU's fp32 and fp64 runs too.  Such points are
+        # counted, not bounded: at most 1e-4 of all points may leave the band
+        pts_g = int((dg.amax(1) > band).sum())
+        print(f"points outside the band of {band:.2e}: {pts_g} of {dg.shape[0] * dg.shape[2]}")
+        assert pts_g <= 1e-4 * dg.shape[0] * dg.shape[2], ("logits", pts_g)
+    else:
+        assert float(dg.max()) <= band, ("logits", float(dg.max()), band)
+    assert abs(got["loss"] - float(want["loss"])) <= max(1e-4, NOISE_FACTOR * abs(float(want["loss"]) - want["loss64"])) * max(1.0, abs(float(want["loss"])))
+    for i in range(4):
+        ref = want["stage"]["up"][i]["f_out"].detach()
+        e = float((got["f_out"][i] - ref).abs().max())
+        print(f"f_out/{i}: max |GPU-CPU32| {e:.2e} (range {float(ref.abs().max()):.2f})")
+        if not mm:
+            assert e <= max(1e-4 * max(1.0, float(ref.abs().max())), band), (f"f_out/{i}", e)
+    gmax = max(float(g.norm()) for g in want["grads64"].values())
+    rows = []
+    for k, g64 in want["grads64"].items():
+        scale = max(float(g64.norm()), 1e-3 * gmax)  # a ~zero gradient (a conv bias in front of a BN) is judged on the scale of the rest
+        dev_gpu = float((got["grads"][k].double() - g64).norm()) / scale
+        dev_cpu = float((want["grads"][k].double() - g64).norm()) / scale
+        rows.append((dev_gpu / max(dev_cpu, 5e-5), dev_gpu, dev_cpu, k))
+    rows.sort(reverse=True)
+    print("gradient distance to the fp64 run, relative (GPU fp32 | CPU fp32), worst ratios:")
+    for ratio, dg, dc, k in rows[:4]:
+        print(f"   {dg:.2e} | {dc:.2e}   x{ratio:.2f}  {k}")
+    print(f"   largest CPU-fp32 distance: {max(r[2] for r in rows):.2e}; largest GPU distance: {max(r[1] for r in rows):.2e}")
+    for ratio, dg, dc, k in rows:
+        assert dg <= NOISE_FACTOR * dc + 2e-4, (k, dg, dc)
+
+
+@pytest.mark.parametrize("B", [2, 8])
+def test_cfg2_pointnext_s_24000(B):
+    from amcontrast3d_amd import _lib
+    got, want, calls = _step("S", B, 24000, False, 0.04)
+    _compare(got, want, False)
+    # the paths bench.py times at this size
+    assert calls.get("sa_tail_forward", 0) == 1 and calls.get("sa_tail_backward", 0) == 1, calls
+    assert calls.get("grouped_conv_forward", 0) >= 2 and calls.get("pointwise_conv_forward", 0) >= 5, calls
+    assert calls.get("contrast_forward", 0) == 4 and calls.get("cross_entropy_forward", 0) == 1, calls
+    lib = _lib.load()
+    assert lib.amc3d_knnquery_uses_grid(B * 24000, 24, B * 24000, 1) == 1  # the loss's stage-0 k-NN runs on the cell grid
+
+
+def test_cfg3_pointnext_l_24000():
+    got, want, calls = _step("L", 2, 24000, False, 0.04)
+    _compare(got, want, False)
+    # every LocalAggregation / SetAbstraction layer of L runs the fused gather+conv kernel (no group_points + library conv)
+    assert calls.get("group_points", 0) == 0, calls
+    assert calls.get("grouped_conv_forward", 0) == 4 + (2 + 4 + 2 + 2), calls
+
+
+def test_cfg4_pointnext_xl_mm_64000():
+    got, want, calls = _step("XL", 1, 64000, True, 0.02)
+    _compare(got, want, True)
+    assert calls.get("group_points", 0) == 0, calls

@@ -92,8 +92,9 @@ def test_model_blocks_route_1x1_convs_to_the_kernel():
 
 @pytest.mark.parametrize("shape", [(8, 256, 256, (375,)), (4, 768, 256, (94,)), (2, 128, 192, (50, 32))])
 def test_library_gemm_conv_matches_torch_conv(shape):
-    """deep, short layers: the three-GEMM decomposition (ops.LibraryGemmConv) against nn.functional.conv, including the
-    once-per-shape choice of the weight-gradient form and its use under a later call"""
+    """deep, short layers: the three-GEMM decomposition (ops.LibraryGemmConv) against nn.functional.conv, in both
+    weight-gradient forms (the form is a pure function of the shape; AMC3D_WGRAD_FORM overrides it)"""
+    import os
     from amcontrast3d_amd import ops
     B, ci, co, sp = shape
     dev = torch.device("cuda:0")
@@ -105,11 +106,12 @@ def test_library_gemm_conv_matches_torch_conv(shape):
     yr = conv(x, w)
     yr.backward(go)
     want = (yr.detach(), x.grad.clone(), w.grad.clone())
-    for _ in range(2):  # first call times the two weight-gradient forms, the second uses the cached one
+    for form in ("", "bmm", "flat"):
+        os.environ["AMC3D_WGRAD_FORM"] = form
         x.grad = w.grad = None
         y = ops.library_gemm_conv(x, w)
         y.backward(go)
         for got, ref in zip((y.detach(), x.grad, w.grad), want):
             assert got.shape == ref.shape
             assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
-    assert (B, ci, co, int(np.prod(sp))) in ops._wgrad_form
+    os.environ.pop("AMC3D_WGRAD_FORM", None)

@@ -179,7 +179,7 @@ def test_model_with_synced_bn_equals_whole_batch_model():
         assert grad_err <= 3e-2, (rank, grad_name, grad_err)
 
 
-def _graph_worker(port, q):
+def _graph_worker(port, q, segmented=False):
     os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
                        "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     import torch.distributed as dist
@@ -205,22 +205,36 @@ def _graph_worker(port, q):
             step()  # warm-up outside capture (communicator set-up, allocator)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, capture_error_mode="thread_local"):  # the RCCL watchdog thread polls events meanwhile
-        y = step()
-    with torch.no_grad():
-        xs.copy_(x)
-    graph.replay()
+    if segmented:
+        # bench.py's N > 1 form: the two all-reduces are NOT captured; the step becomes graph | all-reduce | graph |
+        # all-reduce | graph, replayed in that order (amcontrast3d_amd/graphs.py); backward stays on this thread
+        from amcontrast3d_amd.graphs import SegmentedGraph
+        out = {}
+        with torch.cuda.stream(side):
+            graph = SegmentedGraph("thread_local").capture(lambda: out.update(y=step()))
+            y = out["y"]
+            assert (graph.segments, graph.collectives) == (3, 2), (graph.segments, graph.collectives)
+            with torch.no_grad():
+                xs.copy_(x)
+            graph.replay()
+    else:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):  # the RCCL watchdog thread polls events meanwhile
+            y = step()
+        with torch.no_grad():
+            xs.copy_(x)
+        graph.replay()
     torch.cuda.synchronize()
     got = (y.detach(), xs.grad, gs.grad, bs.grad)
     q.put([float((a - b).abs().max()) for a, b in zip(got, want)] + [int(bn.num_batches_tracked)])
     dist.destroy_process_group()
 
 
-def test_one_rank_rccl_under_graph_capture():
+@pytest.mark.parametrize("segmented", [False, True])
+def test_one_rank_rccl_under_graph_capture(segmented):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_graph_worker, args=(_free_port(), q))
+    p = ctx.Process(target=_graph_worker, args=(_free_port(), q, segmented))
     p.start()
     res = q.get(timeout=300)
     p.join(timeout=60)
