@@ -1,0 +1,574 @@
+// Neighbourhood aggregation with ONE grouped convolution -- every LocalAggregation of the InvResMLP blocks and every
+// single-layer SetAbstraction of PointNeXt-B/L/XL -- as "convolve first, gather after" (gfx950).
+//
+// Reference (pointnext_AA.py:57-63, 139-170; group.py:244-255, 323-325): ball query -> grouping_operation gathers the
+// neighbours' features into (B,C,M,32) -> cat with the relative positions dp (B,3,M,32) -> Conv2d 1x1 (C+3 -> C') ->
+// BatchNorm2d (batch statistics) -> ReLU -> max over the 32 neighbours.  Every one of those tensors is 32x the size
+// of the layer's input and output; the conv runs on M*32 positions.
+//
+// The conv is linear and the gather only selects columns, so  W . [dp ; f[idx]] = (W_f . f)[idx] + W_dp . dp :
+//   G (B,C',N) = W_f . f                       one pointwise conv on the N source points (32x fewer positions)
+//   y[b,c,m,k] = G[b,c,idx[b,m,k]] + W_dp[c] . dp[b,:,m,k]
+// and the BatchNorm statistics of y over all B*M*32 positions follow from N-sized sums and three geometry moments
+//   cnt[n] = #{(m,k): idx[m,k] = n},   D[n] = sum of dp over those positions,   S1 = sum_p dp_p,  S2 = sum_p dp_p dp_p^T :
+//   sum_p y_p   = sum_n cnt[n] G[n] + W_dp . S1
+//   sum_p y_p^2 = sum_n cnt[n] G[n]^2 + 2 sum_n G[n] (W_dp . D[n]) + W_dp^T S2 W_dp
+// (accumulated in fp64).  The only pass over M*32 positions is the max-pool itself: gather 32 rows of G per centroid,
+// add the 3-term dp product, normalise, keep the first maximum (torch.max's rule).  Nothing of size (B,C,M,32) exists.
+//
+// Backward.  The gradient of the pooled output reaches ONE neighbour per (b,c,m); BatchNorm's backward then makes
+// it dense again, dz_p = g*is*(dq_p - mean(dq) - xhat_p*mean(dq*xhat)), but what the layer needs is only
+//   dG[n] = sum_{p -> n} dz_p = g*is*( Q[n] - cnt[n]*ma - mb*is*( cnt[n]*(G[n] - mu) + W_dp . D[n] ) ),
+// with Q[n] the scattered sparse gradients (M*C' atomics instead of M*32*C'), and dW_dp, dgamma, dbeta from the same
+// M-sized and N-sized sums.  df = W_f^T dG and dW_f = dG f^T are the pointwise conv's backward on N points.
+// The geometry moments depend on coordinates only and are part of the geometry plan (computed ahead, shared by all
+// blocks of a stage).
+#include "common.h"
+
+namespace amc {
+
+constexpr double LAGG_FX_D = 68719476736.0;   // 2^36: fixed point of the per-point dp sums (|dp| <= radius or 1)
+constexpr double LAGG_FX_M = 1073741824.0;    // 2^30: fixed point of the global moments (block partials in double)
+constexpr int LAGG_MT = 32;                   // centroids per workgroup tile (8 per wave)
+constexpr int LAGG_CT = 128;                  // channels per workgroup (pool / scatter kernels)
+constexpr int LAGG_NT = 64;                   // points per tile (statistics / apply kernels)
+constexpr int LAGG_TILES = 4;                 // tiles per workgroup in the partial-sum kernels
+
+struct LaggMoments {  // views into the opaque moments buffer of amc3d_group_moments
+    const long long *mom;   // [9 (+7 pad)] S1[3], S2[(0,0),(0,1),(0,2),(1,1),(1,2),(2,2)]
+    const int *cnt;         // (b, n)
+    const long long *dfx;   // (b, n, 3)
+};
+
+static size_t lagg_moments_bytes(int b, int n) { return 16 * 8 + (size_t)b * n * 4 + (((size_t)b * n) & 1) * 4 + (size_t)b * n * 24; }
+
+static LaggMoments lagg_views(const void *buf, int b, int n)
+{
+    LaggMoments v;
+    const char *p = (const char *)buf;
+    v.mom = (const long long *)p;
+    v.cnt = (const int *)(p + 16 * 8);
+    v.dfx = (const long long *)(p + 16 * 8 + (size_t)b * n * 4 + (((size_t)b * n) & 1) * 4);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// geometry moments: integer / fixed-point atomics, so the result does not depend on the order of arrival
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lagg_geom_kernel(int n, long P, const int *__restrict__ idx, const float *__restrict__ dp,
+                                                        int *__restrict__ cnt, unsigned long long *__restrict__ dfx,
+                                                        unsigned long long *__restrict__ mom)
+{
+    __shared__ double red[4][9];
+    const int b = blockIdx.y;
+    const int *ib = idx + (size_t)b * P;
+    const float *d0 = dp + (size_t)b * 3 * P, *d1 = d0 + P, *d2 = d1 + P;
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+        const int id = ib[p];
+        const float x = d0[p], y = d1[p], z = d2[p];
+        if (id >= 0 && id < n) {
+            atomicAdd(cnt + (size_t)b * n + id, 1);
+            unsigned long long *t = dfx + ((size_t)b * n + id) * 3;
+            atomicAdd(t + 0, (unsigned long long)__double2ll_rn((double)x * LAGG_FX_D));
+            atomicAdd(t + 1, (unsigned long long)__double2ll_rn((double)y * LAGG_FX_D));
+            atomicAdd(t + 2, (unsigned long long)__double2ll_rn((double)z * LAGG_FX_D));
+        }
+        const double dx = x, dy = y, dz = z;
+        s[0] += dx; s[1] += dy; s[2] += dz;
+        s[3] += dx * dx; s[4] += dx * dy; s[5] += dx * dz; s[6] += dy * dy; s[7] += dy * dz; s[8] += dz * dz;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        double v = s[j];
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wave][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        const double v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        atomicAdd(mom + threadIdx.x, (unsigned long long)__double2ll_rn(v * LAGG_FX_M));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward statistics: per channel  sum_n cnt G,  sum_n cnt G^2,  sum_n G D_j  (j = 0..2)  + the point-major copy of G
+// grid (n-tile groups, channel chunks of 64, b)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lagg_stats_kernel(int C, int n, const float *__restrict__ g_cm, float *__restrict__ g_pm,
+                                                         LaggMoments gm, double *__restrict__ partial, int nparts_per_b)
+{
+    __shared__ float tile[64][LAGG_NT + 1];
+    __shared__ double red[4][64][5];
+    const int b = blockIdx.z, c0 = blockIdx.y * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = c0 + lane;
+    double a[5] = {0, 0, 0, 0, 0};
+    for (int tt = 0; tt < LAGG_TILES; ++tt) {
+        const int n0 = (blockIdx.x * LAGG_TILES + tt) * LAGG_NT;
+        if (n0 >= n) break;
+        __syncthreads();
+        for (int r = wave; r < 64; r += 4) {  // r: channel of the chunk, lane: point
+            const int ch = c0 + r, nn = n0 + lane;
+            tile[r][lane] = (ch < C && nn < n) ? g_cm[((size_t)b * C + ch) * n + nn] : 0.f;
+        }
+        __syncthreads();
+        for (int i = 0; i < 16; ++i) {
+            const int nl = wave * 16 + i, nn = n0 + nl;
+            if (nn >= n) break;  // wave-uniform
+            const float g = tile[lane][nl];
+            if (c < C) g_pm[((size_t)b * n + nn) * C + c] = g;
+            const double cn = (double)gm.cnt[(size_t)b * n + nn];
+            const long long *df = gm.dfx + ((size_t)b * n + nn) * 3;
+            const double dx = (double)df[0] * (1.0 / LAGG_FX_D), dy = (double)df[1] * (1.0 / LAGG_FX_D),
+                         dz = (double)df[2] * (1.0 / LAGG_FX_D);
+            const double gd = g;
+            a[0] += cn * gd; a[1] += cn * gd * gd; a[2] += gd * dx; a[3] += gd * dy; a[4] += gd * dz;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) red[wave][lane][j] = a[j];
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        double *out = partial + (((size_t)b * nparts_per_b + blockIdx.x) * C + c) * 5;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) out[j] = (red[0][lane][j] + red[1][lane][j]) + (red[2][lane][j] + red[3][lane][j]);
+    }
+}
+
+// mean / invstd / unbiased variance of y from the partials and the geometry moments; gd[c][3] = sum_n G D (kept for backward)
+__global__ __launch_bounds__(256) void lagg_stats_finalize_kernel(int C, int nparts, double count, float eps, float momentum,
+                                                                  const double *__restrict__ partial, const long long *__restrict__ mom,
+                                                                  const float *__restrict__ w_dp, float *__restrict__ mean,
+                                                                  float *__restrict__ invstd, float *__restrict__ var_unbiased,
+                                                                  double *__restrict__ gd, float *__restrict__ running_mean,
+                                                                  float *__restrict__ running_var, long long *__restrict__ tracked)
+{
+    __shared__ double red[4][5];
+    const int c = blockIdx.x;
+    double a[5] = {0, 0, 0, 0, 0};
+    for (int k = threadIdx.x; k < nparts; k += 256) {
+        const double *p = partial + ((size_t)k * C + c) * 5;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) a[j] += p[j];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        double v = a[j];
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wave][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) a[j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+    double m[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) m[j] = (double)mom[j] * (1.0 / LAGG_FX_M);
+    const double w0 = w_dp[c * 3 + 0], w1 = w_dp[c * 3 + 1], w2 = w_dp[c * 3 + 2];
+    const double sy = a[0] + w0 * m[0] + w1 * m[1] + w2 * m[2];
+    const double quad = w0 * w0 * m[3] + w1 * w1 * m[6] + w2 * w2 * m[8] + 2.0 * (w0 * w1 * m[4] + w0 * w2 * m[5] + w1 * w2 * m[7]);
+    const double sy2 = a[1] + 2.0 * (w0 * a[2] + w1 * a[3] + w2 * a[4]) + quad;
+    const double mu = sy / count;
+    double var = sy2 / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)mu, vu = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+    mean[c] = mf;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    var_unbiased[c] = vu;
+    gd[c * 3 + 0] = a[2]; gd[c * 3 + 1] = a[3]; gd[c * 3 + 2] = a[4];
+    if (running_mean && momentum >= 0.f) {
+        running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * mf;
+        running_var[c] = running_var[c] * (1.f - momentum) + momentum * vu;
+        if (c == 0 && tracked) *tracked += 1;
+    }
+}
+
+__device__ __forceinline__ float lagg_bn(float x, float mean, float invstd, float gamma, float beta)
+{
+    return __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(x, mean), invstd), gamma), beta);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward max-pool: pooled[b,c,m] = max_k [relu](bn(G[b, idx[b,m,k], c] + W_dp[c] . dp[b,:,m,k])), arg = first k, ystar = raw y there
+// grid (m tiles of 32, channel chunks of <= 128, b); a wave owns 8 centroids; LPR lanes share one gathered row
+// (16 bytes each), 64/LPR rows per load instruction
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lagg_pool_kernel(int C, int n, int M, int K, int lpr, int relu,
+                                                        const float *__restrict__ g_pm, const int *__restrict__ idx,
+                                                        const float *__restrict__ dp, const float *__restrict__ w_dp,
+                                                        const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                        float *__restrict__ pooled, unsigned char *__restrict__ arg,
+                                                        float *__restrict__ ystar)
+{
+    extern __shared__ float lagg_smem[];
+    const int ct = min(LAGG_CT, C - (int)blockIdx.y * LAGG_CT);  // channels of this chunk (a multiple of 4)
+    float *sp = lagg_smem;                        // [ct][LAGG_MT + 1] pooled
+    float *sy = sp + ct * (LAGG_MT + 1);          // ystar
+    float *sa = sy + ct * (LAGG_MT + 1);          // arg (as float bits of an int)
+    const int b = blockIdx.z, c0 = blockIdx.y * LAGG_CT, m0 = blockIdx.x * LAGG_MT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane % lpr, r = lane / lpr, rpi = 64 / lpr;
+    const bool chan_ok = 4 * q < ct;
+    const int cq = c0 + 4 * q;
+    float w[4][3], mu[4], is[4], ga[4], be[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = chan_ok ? cq + j : c0;
+        w[j][0] = w_dp[c * 3 + 0]; w[j][1] = w_dp[c * 3 + 1]; w[j][2] = w_dp[c * 3 + 2];
+        mu[j] = mean[c]; is[j] = invstd[c]; ga[j] = gamma[c]; be[j] = beta[c];
+    }
+    const long P = (long)M * K;
+    for (int i = 0; i < LAGG_MT / 4; ++i) {
+        const int ml = wave * (LAGG_MT / 4) + i, m = m0 + ml;
+        if (m >= M) break;  // wave-uniform
+        int id_l = 0;
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+        if (lane < K) {
+            const size_t p = (size_t)m * K + lane;
+            id_l = idx[(size_t)b * P + p];
+            d0 = dp[((size_t)b * 3 + 0) * P + p]; d1 = dp[((size_t)b * 3 + 1) * P + p]; d2 = dp[((size_t)b * 3 + 2) * P + p];
+        }
+        float best[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        float by[4] = {0.f, 0.f, 0.f, 0.f};
+        int bk[4] = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < K; k0 += rpi) {
+            const int k = k0 + r;
+            const int ks = k < K ? k : K - 1;
+            const int id = __shfl(id_l, ks, 64);
+            const float e0 = __shfl(d0, ks, 64), e1 = __shfl(d1, ks, 64), e2 = __shfl(d2, ks, 64);
+            if (k < K && chan_ok) {
+                const float4 g = *reinterpret_cast<const float4 *>(g_pm + ((size_t)b * n + id) * C + cq);
+                const float gs[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float y = __fmaf_rn(w[j][0], e0, __fmaf_rn(w[j][1], e1, __fmaf_rn(w[j][2], e2, gs[j])));
+                    float v = lagg_bn(y, mu[j], is[j], ga[j], be[j]);
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (v > best[j]) { best[j] = v; bk[j] = k; by[j] = y; }
+                }
+            }
+        }
+        for (int s = lpr; s < 64; s <<= 1) {  // combine the row slots, first index wins among equal values
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float ov = __shfl_xor(best[j], s, 64), oy = __shfl_xor(by[j], s, 64);
+                const int ok = __shfl_xor(bk[j], s, 64);
+                if (ov > best[j] || (ov == best[j] && ok < bk[j])) { best[j] = ov; bk[j] = ok; by[j] = oy; }
+            }
+        }
+        if (r == 0 && chan_ok) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cl = 4 * q + j;
+                sp[cl * (LAGG_MT + 1) + ml] = best[j];
+                sy[cl * (LAGG_MT + 1) + ml] = by[j];
+                sa[cl * (LAGG_MT + 1) + ml] = __int_as_float(bk[j]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < ct * LAGG_MT; t += 256) {
+        const int cl = t / LAGG_MT, ml = t - cl * LAGG_MT, m = m0 + ml;
+        if (m < M) {
+            const size_t o = ((size_t)b * C + c0 + cl) * M + m;
+            pooled[o] = sp[cl * (LAGG_MT + 1) + ml];
+            ystar[o] = sy[cl * (LAGG_MT + 1) + ml];
+            arg[o] = (unsigned char)__float_as_int(sa[cl * (LAGG_MT + 1) + ml]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward 1: per (b,c,m): dq = dpooled * [relu: bn(ystar) > 0], scatter into Q[b, idx[b,m,arg], c]; per-channel partial sums
+//   {sum dq, sum dq xhat, sum dq dp_j}.  grid (m-tile groups, channel chunks of 128, b)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lagg_bwd_scatter_kernel(int C, int n, int M, int K, int relu,
+                                                               const float *__restrict__ dpooled, const float *__restrict__ ystar,
+                                                               const unsigned char *__restrict__ arg, const int *__restrict__ idx,
+                                                               const float *__restrict__ dp, const float *__restrict__ mean,
+                                                               const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta, float *__restrict__ Q,
+                                                               double *__restrict__ partial, int nparts_per_b)
+{
+    extern __shared__ float lagg_smem[];
+    const int ct = min(LAGG_CT, C - (int)blockIdx.y * LAGG_CT);
+    float *sd = lagg_smem;                        // [ct][LAGG_MT + 1] dpooled
+    float *sy = sd + ct * (LAGG_MT + 1);          // ystar
+    float *sa = sy + ct * (LAGG_MT + 1);          // arg
+    const int b = blockIdx.z, c0 = blockIdx.y * LAGG_CT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long P = (long)M * K;
+    double acc[2][5];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[h][j] = 0.0;
+    float mu[2], is[2], ga[2], be[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int cl = lane + 64 * h, c = cl < ct ? c0 + cl : c0;
+        mu[h] = mean[c]; is[h] = invstd[c]; ga[h] = gamma[c]; be[h] = beta[c];
+    }
+    for (int tt = 0; tt < LAGG_TILES; ++tt) {
+        const int m0 = (blockIdx.x * LAGG_TILES + tt) * LAGG_MT;
+        if (m0 >= M) break;
+        __syncthreads();
+        for (int t = threadIdx.x; t < ct * LAGG_MT; t += 256) {
+            const int cl = t / LAGG_MT, ml = t - cl * LAGG_MT, m = m0 + ml;
+            float d = 0.f, y = 0.f;
+            int a = 0;
+            if (m < M) {
+                const size_t o = ((size_t)b * C + c0 + cl) * M + m;
+                d = dpooled[o]; y = ystar[o]; a = arg[o];
+            }
+            sd[cl * (LAGG_MT + 1) + ml] = d; sy[cl * (LAGG_MT + 1) + ml] = y; sa[cl * (LAGG_MT + 1) + ml] = __int_as_float(a);
+        }
+        __syncthreads();
+        for (int i = 0; i < LAGG_MT / 4; ++i) {
+            const int ml = wave * (LAGG_MT / 4) + i, m = m0 + ml;
+            if (m >= M) break;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int cl = lane + 64 * h;
+                if (cl >= ct) continue;
+                float dq = sd[cl * (LAGG_MT + 1) + ml];
+                const float y = sy[cl * (LAGG_MT + 1) + ml];
+                const int k = __float_as_int(sa[cl * (LAGG_MT + 1) + ml]);
+                const float xh = __fmul_rn(__fsub_rn(y, mu[h]), is[h]);
+                if (relu && !(__fadd_rn(__fmul_rn(xh, ga[h]), be[h]) > 0.f)) dq = 0.f;
+                if (dq != 0.f) {
+                    const size_t p = (size_t)b * P + (size_t)m * K + k;
+                    const int id = idx[p];
+                    const size_t pd = (size_t)b * 3 * P + (size_t)m * K + k;
+                    const double dd = dq;
+                    acc[h][0] += dd; acc[h][1] += dd * (double)xh;
+                    acc[h][2] += dd * (double)dp[pd]; acc[h][3] += dd * (double)dp[pd + P]; acc[h][4] += dd * (double)dp[pd + 2 * P];
+                    atomicAdd(Q + ((size_t)b * n + id) * C + c0 + cl, dq);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    double *red = reinterpret_cast<double *>(lagg_smem);  // [4][ct][5] doubles
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        if (lane + 64 * h < ct) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) red[((size_t)wave * ct + lane + 64 * h) * 5 + j] = acc[h][j];
+        }
+    __syncthreads();
+    for (int t = threadIdx.x; t < ct * 5; t += 256) {
+        const int cl = t / 5, j = t - cl * 5;
+        const double v = (red[((size_t)0 * ct + cl) * 5 + j] + red[((size_t)1 * ct + cl) * 5 + j]) +
+                         (red[((size_t)2 * ct + cl) * 5 + j] + red[((size_t)3 * ct + cl) * 5 + j]);
+        partial[(((size_t)b * nparts_per_b + blockIdx.x) * C + c0 + cl) * 5 + j] = v;
+    }
+}
+
+// dgamma, dbeta, dW_dp and the per-channel coefficients of dG: coef[c] = {g*is, ma, mb*is, mu}
+__global__ __launch_bounds__(256) void lagg_bwd_finalize_kernel(int C, int nparts, double count, const double *__restrict__ partial,
+                                                                const long long *__restrict__ mom, const double *__restrict__ gd,
+                                                                const float *__restrict__ w_dp, const float *__restrict__ mean,
+                                                                const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                                float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                                float *__restrict__ dw_dp, float *__restrict__ coef)
+{
+    __shared__ double red[4][5];
+    const int c = blockIdx.x;
+    double a[5] = {0, 0, 0, 0, 0};
+    for (int k = threadIdx.x; k < nparts; k += 256) {
+        const double *p = partial + ((size_t)k * C + c) * 5;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) a[j] += p[j];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        double v = a[j];
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wave][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) a[j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+    double m[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) m[j] = (double)mom[j] * (1.0 / LAGG_FX_M);
+    const double S2[3][3] = {{m[3], m[4], m[5]}, {m[4], m[6], m[7]}, {m[5], m[7], m[8]}};
+    const double mu = mean[c], is = invstd[c], g = gamma[c];
+    const double ma = a[0] / count, mb = a[1] / count, gi = g * is;
+    dbeta[c] = (float)a[0];
+    dgamma[c] = (float)a[1];
+    const double w[3] = {w_dp[c * 3 + 0], w_dp[c * 3 + 1], w_dp[c * 3 + 2]};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        // sum_p xhat_p dp_p[j] = is * ( sum_n G D_j + sum_j' w_j' S2[j'][j] - mu S1[j] )
+        const double sxd = is * (gd[c * 3 + j] + w[0] * S2[0][j] + w[1] * S2[1][j] + w[2] * S2[2][j] - mu * m[j]);
+        dw_dp[c * 3 + j] = (float)(gi * (a[2 + j] - ma * m[j] - mb * sxd));
+    }
+    coef[c * 4 + 0] = (float)gi; coef[c * 4 + 1] = (float)ma; coef[c * 4 + 2] = (float)(mb * is); coef[c * 4 + 3] = (float)mu;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward 2: dG[b,c,n] = gi * ( Q - cnt*ma - mbis * ( cnt*(G - mu) + W_dp . D ) ), written channel-major
+// grid (n tiles of 64, channel chunks of 64, b)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lagg_bwd_apply_kernel(int C, int n, const float *__restrict__ Q, const float *__restrict__ g_pm,
+                                                             LaggMoments gm, const float *__restrict__ w_dp,
+                                                             const float *__restrict__ coef, float *__restrict__ dg_cm)
+{
+    __shared__ float tile[64][LAGG_NT + 1];
+    const int b = blockIdx.z, c0 = blockIdx.y * 64, n0 = blockIdx.x * LAGG_NT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = c0 + lane;
+    float gi = 0.f, ma = 0.f, mbis = 0.f, mu = 0.f, w0 = 0.f, w1 = 0.f, w2 = 0.f;
+    if (c < C) {
+        gi = coef[c * 4 + 0]; ma = coef[c * 4 + 1]; mbis = coef[c * 4 + 2]; mu = coef[c * 4 + 3];
+        w0 = w_dp[c * 3 + 0]; w1 = w_dp[c * 3 + 1]; w2 = w_dp[c * 3 + 2];
+    }
+    for (int i = 0; i < 16; ++i) {
+        const int nl = wave * 16 + i, nn = n0 + nl;
+        float v = 0.f;
+        if (nn < n && c < C) {
+            const size_t o = ((size_t)b * n + nn) * C + c;
+            const float cn = (float)gm.cnt[(size_t)b * n + nn];
+            const long long *df = gm.dfx + ((size_t)b * n + nn) * 3;
+            const float dx = (float)((double)df[0] * (1.0 / LAGG_FX_D)), dy = (float)((double)df[1] * (1.0 / LAGG_FX_D)),
+                        dz = (float)((double)df[2] * (1.0 / LAGG_FX_D));
+            const float wd = w0 * dx + w1 * dy + w2 * dz;
+            v = gi * (Q[o] - cn * ma - mbis * (cn * (g_pm[o] - mu) + wd));
+        }
+        tile[lane][nl] = v;
+    }
+    __syncthreads();
+    for (int r = wave; r < 64; r += 4) {
+        const int ch = c0 + r, nn = n0 + lane;
+        if (ch < C && nn < n) dg_cm[((size_t)b * C + ch) * n + nn] = tile[r][lane];
+    }
+}
+
+static bool lagg_supported(int C, int K)
+{
+    if (C < 8 || C % 4 || K < 1 || K > 64) return false;
+    const int ct = C < LAGG_CT ? C : LAGG_CT;
+    const int lpr = ct / 4;
+    return (lpr & (lpr - 1)) == 0 && C % ct == 0;  // 8,16,32,64,128 and multiples of 128
+}
+
+static size_t lagg_partial_bytes(int b, int C, int n, int M)
+{
+    const size_t pf = (size_t)b * div_up(div_up(n, LAGG_NT), LAGG_TILES), pb = (size_t)b * div_up(div_up(M, LAGG_MT), LAGG_TILES);
+    return (pf > pb ? pf : pb) * C * 5 * sizeof(double);
+}
+
+}  // namespace amc
+
+using namespace amc;
+
+AMC_API int amc3d_local_aggregation_supported(int cout, int nsample) { return lagg_supported(cout, nsample) ? 1 : 0; }
+
+AMC_API size_t amc3d_group_moments_bytes(int b, int n) { return (b <= 0 || n <= 0) ? 0 : lagg_moments_bytes(b, n); }
+
+// moments (opaque, amc3d_group_moments_bytes): in-degree and dp sum of every support point, global dp moments
+AMC_API int amc3d_group_moments(int b, int n, int npoints, int nsample, const int *idx, const float *dp, void *moments,
+                                size_t moments_bytes, void *stream_)
+{
+    if (b <= 0 || n <= 0) return 0;
+    if (!idx || !dp || !moments || moments_bytes < lagg_moments_bytes(b, n) || npoints <= 0 || nsample <= 0)
+        return bad_arg("amc3d_group_moments: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int st = fill_i32((int *)moments, 0, lagg_moments_bytes(b, n) / 4, stream)) return st;
+    const LaggMoments v = lagg_views(moments, b, n);
+    const long P = (long)npoints * nsample;
+    const int blocks = (int)(div_up(P, 256 * 4) < 1024 ? div_up(P, 256 * 4) : 1024);
+    hipLaunchKernelGGL(lagg_geom_kernel, dim3(blocks, b), dim3(256), 0, stream, n, P, idx, dp, (int *)v.cnt,
+                       (unsigned long long *)v.dfx, (unsigned long long *)v.mom);
+    return launch_status("amc3d_group_moments");
+}
+
+AMC_API size_t amc3d_local_aggregation_workspace_bytes(int b, int cout, int n, int npoints)
+{
+    if (b <= 0 || cout <= 0 || n <= 0 || npoints <= 0) return 0;
+    // partial sums | Q (b, n, cout) | coef (cout, 4)
+    return lagg_partial_bytes(b, cout, n, npoints) + (size_t)b * n * cout * sizeof(float) + (size_t)cout * 4 * sizeof(float) + 64;
+}
+
+// g_cm (b,cout,n) = W_f . f, computed by the caller (amc3d_pointwise_conv_forward).  Outputs: g_pm (b,n,cout) the
+// point-major copy (kept for backward), pooled / ystar (b,cout,npoints) fp32, arg (b,cout,npoints) bytes, mean / invstd /
+// var_unbiased (cout), gd (cout,3) doubles.  training == 0: mean / invstd are INPUTS (running statistics), no statistics pass.
+AMC_API int amc3d_local_aggregation_forward(int b, int cout, int n, int npoints, int nsample, int training, int relu, float eps,
+                                            float momentum, const float *g_cm, const int *idx, const float *dp,
+                                            const float *w_dp, const void *moments, const float *gamma, const float *beta,
+                                            float *g_pm, float *pooled, unsigned char *arg, float *ystar, float *mean,
+                                            float *invstd, float *var_unbiased, double *gd, float *running_mean,
+                                            float *running_var, long long *num_batches_tracked, void *workspace,
+                                            size_t workspace_bytes, void *stream_)
+{
+    if (b <= 0 || npoints <= 0) return 0;
+    if (!lagg_supported(cout, nsample) || n <= 0 || !g_cm || !idx || !dp || !w_dp || !gamma || !beta || !g_pm || !pooled || !arg ||
+        !ystar || !mean || !invstd || (training && (!moments || !var_unbiased || !gd || !workspace ||
+        workspace_bytes < amc3d_local_aggregation_workspace_bytes(b, cout, n, npoints))) ||
+        (running_mean && (!running_var || !num_batches_tracked)))
+        return bad_arg("amc3d_local_aggregation_forward: unsupported shape, null pointer or workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    LaggMoments gm{};
+    if (moments) gm = lagg_views(moments, b, n);
+    const int nparts_b = div_up(div_up(n, LAGG_NT), LAGG_TILES);
+    double *partial = (double *)workspace;
+    if (training) {
+        hipLaunchKernelGGL(lagg_stats_kernel, dim3(nparts_b, div_up(cout, 64), b), dim3(256), 0, stream, cout, n, g_cm, g_pm, gm,
+                           partial, nparts_b);
+        hipLaunchKernelGGL(lagg_stats_finalize_kernel, dim3(cout), dim3(256), 0, stream, cout, nparts_b * b,
+                           (double)b * (double)npoints * (double)nsample, eps, momentum, (const double *)partial, gm.mom, w_dp,
+                           mean, invstd, var_unbiased, gd, running_mean, running_var, num_batches_tracked);
+    } else {
+        // eval mode: only the point-major copy is needed
+        if (int st = amc3d_transpose_cn(b, cout, n, g_cm, g_pm, stream_)) return st;
+    }
+    const int ct = cout < LAGG_CT ? cout : LAGG_CT;
+    const size_t lds = (size_t)3 * ct * (LAGG_MT + 1) * sizeof(float);
+    hipLaunchKernelGGL(lagg_pool_kernel, dim3(div_up(npoints, LAGG_MT), cout / ct, b), dim3(256), lds, stream, cout, n, npoints,
+                       nsample, ct / 4, relu, (const float *)g_pm, idx, dp, w_dp, (const float *)mean, (const float *)invstd, gamma,
+                       beta, pooled, arg, ystar);
+    return launch_status("amc3d_local_aggregation_forward");
+}
+
+// dg_cm (b,cout,n): gradient w.r.t. G = W_f . f (the caller runs the pointwise conv's backward on it);
+// dw_dp (cout,3), dgamma, dbeta (cout)
+AMC_API int amc3d_local_aggregation_backward(int b, int cout, int n, int npoints, int nsample, int relu, const float *dpooled,
+                                             const float *ystar, const unsigned char *arg, const float *g_pm, const int *idx,
+                                             const float *dp, const float *w_dp, const void *moments, const double *gd,
+                                             const float *mean, const float *invstd, const float *gamma, const float *beta,
+                                             float *dg_cm, float *dw_dp, float *dgamma, float *dbeta, void *workspace,
+                                             size_t workspace_bytes, void *stream_)
+{
+    if (b <= 0 || npoints <= 0) return 0;
+    if (!lagg_supported(cout, nsample) || n <= 0 || !dpooled || !ystar || !arg || !g_pm || !idx || !dp || !w_dp || !moments || !gd ||
+        !mean || !invstd || !gamma || !beta || !dg_cm || !dw_dp || !dgamma || !dbeta || !workspace ||
+        workspace_bytes < amc3d_local_aggregation_workspace_bytes(b, cout, n, npoints))
+        return bad_arg("amc3d_local_aggregation_backward: unsupported shape, null pointer or workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    const LaggMoments gm = lagg_views(moments, b, n);
+    double *partial = (double *)workspace;
+    float *Q = (float *)((char *)workspace + lagg_partial_bytes(b, cout, n, npoints));
+    float *coef = Q + (size_t)b * n * cout;
+    if (int st = fill_i32((int *)Q, 0, (size_t)b * n * cout, stream)) return st;
+    const int ct = cout < LAGG_CT ? cout : LAGG_CT;
+    const int nparts_b = div_up(div_up(npoints, LAGG_MT), LAGG_TILES);
+    size_t lds = (size_t)3 * ct * (LAGG_MT + 1) * sizeof(float);
+    const size_t red = (size_t)4 * ct * 5 * sizeof(double);
+    if (lds < red) lds = red;
+    hipLaunchKernelGGL(lagg_bwd_scatter_kernel, dim3(nparts_b, cout / ct, b), dim3(256), lds, stream, cout, n, npoints, nsample,
+                       relu, dpooled, ystar, arg, idx, dp, mean, invstd, gamma, beta, Q, partial, nparts_b);
+    hipLaunchKernelGGL(lagg_bwd_finalize_kernel, dim3(cout), dim3(256), 0, stream, cout, nparts_b * b,
+                       (double)b * (double)npoints * (double)nsample, (const double *)partial, gm.mom, gd, w_dp, mean, invstd,
+                       gamma, dgamma, dbeta, dw_dp, coef);
+    hipLaunchKernelGGL(lagg_bwd_apply_kernel, dim3(div_up(n, LAGG_NT), div_up(cout, 64), b), dim3(256), 0, stream, cout, n,
+                       (const float *)Q, g_pm, gm, w_dp, (const float *)coef, dg_cm);
+    return launch_status("amc3d_local_aggregation_backward");
+}

@@ -20,9 +20,17 @@ import torch
 import torch.nn as nn
 
 from ..layers import (CHANNEL_MAP, create_act, create_convblock1d, create_convblock2d, create_grouper,
-                      furthest_point_sample, fused_first_conv, get_aggregation_feautres, random_sample,
-                      run_convblocks,
+                      furthest_point_sample, fused_first_conv, fused_local_aggregation, get_aggregation_feautres,
+                      random_sample, run_convblocks,
                       three_interpolate, three_nn)
+
+
+def _moments(convs, feature_type, idx, dp, n_support):
+    """geometry moments for a single-conv neighbourhood layer (the convolve-before-gather kernels need them), else None"""
+    if len(convs) != 1 or feature_type != 'dp_fj' or not idx.is_cuda:
+        return None
+    from amcontrast3d_amd import ops
+    return ops.group_moments(idx, dp, n_support)
 
 
 def get_reduction_fn(reduction):
@@ -61,12 +69,17 @@ class LocalAggregation(nn.Module):
         if not hasattr(self.grouper, 'query'):
             return None
         idx = self.grouper.query(p, p)
-        return {'idx': idx, 'dp': self.grouper.relative_positions(idx, p, p)}
+        dp = self.grouper.relative_positions(idx, p, p)
+        return {'idx': idx, 'dp': dp, 'mom': _moments(self.convs, self.feature_type, idx, dp, p.shape[1])}
 
     def forward(self, pf, geom=None):
         p, f = pf
         if geom is None:
             geom = self.plan(p)
+        if self.reduction == 'max':
+            y = fused_local_aggregation(self.convs, f, geom, self.feature_type)
+            if y is not None:  # conv on the source points, then gather + BN + ReLU + max in one pass
+                return y
         pre = fused_first_conv(self.convs, f, geom, self.feature_type)
         if pre is not None:  # gather + concat + first conv in one MFMA kernel
             y = run_convblocks(self.convs, None, pool_max=self.reduction == 'max', pre=pre)
@@ -135,6 +148,7 @@ class SetAbstraction(nn.Module):
         if not self.is_head and hasattr(self.grouper, 'query'):
             g['idx'] = self.grouper.query(g['new_p'], p)
             g['dp'] = self.grouper.relative_positions(g['idx'], g['new_p'], p)
+            g['mom'] = _moments(self.convs, self.feature_type, g['idx'], g['dp'], p.shape[1])
         return g
 
     def plan(self, p):
@@ -153,8 +167,11 @@ class SetAbstraction(nn.Module):
             fi = torch.gather(f, -1, idx.unsqueeze(1).expand(-1, f.shape[1], -1))
             if self.use_res:
                 identity = run_convblocks((self.skipconv,), fi)
-        pre = fused_first_conv(self.convs, f, geom, self.feature_type)
-        if pre is not None:  # gather + concat + first conv in one MFMA kernel
+        fused = fused_local_aggregation(self.convs, f, geom, self.feature_type)
+        pre = fused_first_conv(self.convs, f, geom, self.feature_type) if fused is None else None
+        if fused is not None:  # single conv layer: conv on the source points, then gather + BN + ReLU + max in one pass
+            f = fused
+        elif pre is not None:  # gather + concat + first conv in one MFMA kernel
             f = run_convblocks(self.convs, None, pool_max=True, pre=pre)
         else:
             dp, fj = self.grouper(new_p, p, f, geom=geom if 'idx' in geom else None)

@@ -248,6 +248,34 @@ def _sa_tail(mods, pool_max, pre):
                             len(s1) == 3, bn1, bn2)
 
 
+def fused_local_aggregation(blocks, f, geom, feature_type):
+    """A stack of ONE conv block -- Conv2d 1x1 -> BatchNorm2d [-> ReLU] -- followed by the max over the neighbours (every
+    LocalAggregation of InvResMLP, the single-layer SetAbstraction of PointNeXt-B/L/XL) as convolve-before-gather
+    (amcontrast3d_amd/csrc/lagg.hip): the pooled (B,C,M) output, or None when the layer is not of that form."""
+    from amcontrast3d_amd import ops
+    import os
+    if (feature_type != 'dp_fj' or geom is None or 'idx' not in geom or geom.get('mom') is None or f is None or not f.is_cuda
+            or f.dtype != torch.float32 or torch.is_autocast_enabled() or len(blocks) != 1
+            or os.environ.get("AMC3D_NO_LOCAL_AGGREGATION")):
+        return None
+    blk = blocks[0]
+    if (not isinstance(blk, nn.Sequential) or len(blk) not in (2, 3) or not isinstance(blk[0], nn.Conv2d)
+            or not isinstance(blk[1], nn.modules.batchnorm._BatchNorm) or (len(blk) == 3 and type(blk[2]) is not nn.ReLU)):
+        return None
+    conv, bn = blk[0], blk[1]
+    idx = geom['idx']
+    if (conv.bias is not None or conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.groups != 1
+            or any(v != 0 for v in conv.padding) or conv.in_channels != f.shape[1] + 3
+            or not ops.local_aggregation_supported(conv.out_channels, idx.shape[-1])):
+        return None
+    relu = len(blk) == 3
+    if _eval_bn(bn, f):
+        return ops.local_aggregation_eval(f, geom['dp'], idx, conv.weight, bn, relu)
+    if not _fusable_bn(bn, f):
+        return None
+    return ops.LocalAggregationFused.apply(f, geom['dp'], idx, geom['mom'], conv.weight, bn.weight, bn.bias, bn.eps, relu, bn)
+
+
 def fused_first_conv(blocks, f, geom, feature_type):
     """Output of the first block's 1x1 conv on [dp ; f[idx]] from the fused gather+conv MFMA kernel, or None
     when the layer is not of that form (then the caller groups, concatenates and convolves as usual)."""

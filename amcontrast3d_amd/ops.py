@@ -750,6 +750,143 @@ class GroupedConv(Function):
 grouped_conv = GroupedConv.apply
 
 
+# ----------------------------------------------------------------------------------------------
+# single grouped conv + BatchNorm [+ReLU] + max over the neighbours, convolved before the gather (csrc/lagg.hip)
+# ----------------------------------------------------------------------------------------------
+def local_aggregation_supported(cout, nsample):
+    return bool(_lib.load().amc3d_local_aggregation_supported(int(cout), int(nsample)))
+
+
+@torch.no_grad()
+def group_moments(idx, dp, n_support):
+    """Geometry moments of a neighbourhood query -- idx (B,M,K) int32 into n_support points, dp (B,3,M,K) -- that the
+    convolve-before-gather layers need for their BatchNorm statistics and backward (in-degree and dp sum per support point,
+    global dp moments): coordinates only, so part of the geometry plan.  -> opaque uint8 buffer."""
+    _need_gpu(idx, dp)
+    _need_dtype(torch.int32, idx=idx)
+    _need_dtype(torch.float32, dp=dp)
+    idx, dp = idx.contiguous(), dp.contiguous()
+    B, M, K = idx.shape
+    lib = _lib.load()
+    nb = int(lib.amc3d_group_moments_bytes(B, int(n_support)))
+    out = torch.empty(nb, dtype=torch.uint8, device=idx.device)
+    with torch.cuda.device(idx.device), timing.span("group_moments", idx.numel() * 16 + nb):
+        _lib.check(lib.amc3d_group_moments(B, int(n_support), M, K, _ptr(idx), _ptr(dp), _ptr(out), nb, _stream(idx)),
+                   "group_moments")
+    return out
+
+
+class LocalAggregationFused(Function):
+    """pooled (B,C,M) = max_k [relu](bn(conv1x1([dp ; f[idx]]))) -- grouping_operation + cat + Conv2d + BatchNorm2d (batch
+    statistics) [+ ReLU] + max of LocalAggregation / single-layer SetAbstraction (pointnext_AA.py:57-63, 139-170) -- with
+    the conv applied to the N source points BEFORE the gather:  W.[dp ; f[idx]] = (W_f.f)[idx] + W_dp.dp.
+    f (B,Cin,N) fp32, dp (B,3,M,K), idx (B,M,K) int32, moments = group_moments(idx, dp, N), weight (C,Cin+3,1,1),
+    `bn`: the nn.BatchNorm2d whose running buffers are updated (None: no update)."""
+
+    @staticmethod
+    def forward(ctx, f, dp, idx, moments, weight, gamma, beta, eps, relu, bn=None):
+        _need_gpu(f, dp, idx, moments, weight, gamma, beta)
+        _need_dtype(torch.float32, f=f, dp=dp, weight=weight)
+        _need_dtype(torch.int32, idx=idx)
+        f, dp, idx = f.contiguous(), dp.contiguous(), idx.contiguous()
+        B, Cin, N = f.shape
+        _, M, K = idx.shape
+        C = weight.shape[0]
+        assert weight.numel() == C * (Cin + 3)
+        dev = f.device
+        lib = _lib.load()
+        w2 = weight.reshape(C, Cin + 3)
+        w_dp, w_f = w2[:, :3].contiguous(), w2[:, 3:].contiguous()
+        g_cm = torch.empty(B, C, N, dtype=torch.float32, device=dev)
+        g_pm = torch.empty(B, N, C, dtype=torch.float32, device=dev)
+        pooled = torch.empty(B, C, M, dtype=torch.float32, device=dev)
+        ystar = torch.empty_like(pooled)
+        arg = torch.empty(B, C, M, dtype=torch.uint8, device=dev)
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd, var_u = torch.empty_like(mean), torch.empty_like(mean)
+        gd = torch.empty(C, 3, dtype=torch.float64, device=dev)
+        wb = int(lib.amc3d_local_aggregation_workspace_bytes(B, C, N, M))
+        work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
+        mom, rm, rv, nbt = _bn_running_args(bn)
+        with torch.cuda.device(dev):
+            with timing.span("pointwise_conv_forward", 4 * B * N * (Cin + C), 2.0 * B * N * Cin * C):
+                _lib.check(lib.amc3d_pointwise_conv_forward(B, Cin, C, N, _ptr(f), _ptr(w_f), None, _ptr(g_cm), _stream(f)),
+                           "pointwise_conv_forward")
+            # algorithmic bytes: G read (statistics) + the gathered rows, idx, dp + the pooled outputs
+            with timing.span("local_aggregation_forward", 8 * B * N * C + B * M * K * (4 * C + 16) + 9 * B * M * C):
+                _lib.check(lib.amc3d_local_aggregation_forward(
+                    B, C, N, M, K, 1, int(bool(relu)), float(eps), mom, _ptr(g_cm), _ptr(idx), _ptr(dp), _ptr(w_dp),
+                    _ptr(moments), _ptr(gamma), _ptr(beta), _ptr(g_pm), _ptr(pooled), _ptr(arg), _ptr(ystar), _ptr(mean),
+                    _ptr(invstd), _ptr(var_u), _ptr(gd), rm, rv, nbt, _ptr(work), wb, _stream(f)), "local_aggregation_forward")
+        if bn is not None and bn.track_running_stats and bn.running_mean is not None and bn.momentum is None:
+            bn_update_running(bn, mean, var_u)  # cumulative average: its own launch
+        ctx.save_for_backward(f, w_f, w_dp, g_pm, idx, dp, moments, gamma, beta, mean, invstd, gd, ystar, arg)
+        ctx.relu, ctx.wshape = bool(relu), tuple(weight.shape)
+        if _pool_log is not None:
+            _pool_log[_next_pool_seq()] = arg
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        f, w_f, w_dp, g_pm, idx, dp, moments, gamma, beta, mean, invstd, gd, ystar, arg = ctx.saved_tensors
+        B, Cin, N = f.shape
+        _, M, K = idx.shape
+        C = w_f.shape[0]
+        dev = f.device
+        lib = _lib.load()
+        dpooled = dpooled.contiguous()
+        dg_cm = torch.empty(B, C, N, dtype=torch.float32, device=dev)
+        dw_dp = torch.empty(C, 3, dtype=torch.float32, device=dev)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        wb = int(lib.amc3d_local_aggregation_workspace_bytes(B, C, N, M))
+        work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
+        need_f = ctx.needs_input_grad[0]
+        df = torch.empty_like(f) if need_f else None
+        dw_f = torch.empty(C, Cin, dtype=torch.float32, device=dev)
+        wb2 = int(lib.amc3d_pointwise_conv_workspace_bytes(B, Cin, C, N))
+        work2 = torch.empty(max(wb2, 4), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            with timing.span("local_aggregation_backward", 17 * B * M * C + 12 * B * N * C):
+                _lib.check(lib.amc3d_local_aggregation_backward(
+                    B, C, N, M, K, int(ctx.relu), _ptr(dpooled), _ptr(ystar), _ptr(arg), _ptr(g_pm), _ptr(idx), _ptr(dp),
+                    _ptr(w_dp), _ptr(moments), _ptr(gd), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dg_cm),
+                    _ptr(dw_dp), _ptr(dgamma), _ptr(dbeta), _ptr(work), wb, _stream(f)), "local_aggregation_backward")
+            with timing.span("pointwise_conv_backward", 4 * B * N * (Cin + C) * (1 + int(need_f)),
+                             2.0 * B * N * Cin * C * (1 + int(need_f))):
+                _lib.check(lib.amc3d_pointwise_conv_backward(B, Cin, C, N, _ptr(f), _ptr(w_f), _ptr(dg_cm),
+                                                             _ptr(df) if need_f else None, _ptr(dw_f), _ptr(work2), wb2,
+                                                             _stream(f)), "pointwise_conv_backward")
+        dw = torch.cat((dw_dp, dw_f), dim=1).view(ctx.wshape)
+        return df, None, None, None, dw, dgamma, dbeta, None, None, None
+
+
+@torch.no_grad()
+def local_aggregation_eval(f, dp, idx, weight, bn, relu):
+    """the same layer in inference mode (running statistics), no gradient"""
+    f, dp, idx = f.contiguous(), dp.contiguous(), idx.contiguous()
+    B, Cin, N = f.shape
+    _, M, K = idx.shape
+    C = weight.shape[0]
+    dev = f.device
+    lib = _lib.load()
+    w2 = weight.reshape(C, Cin + 3)
+    w_dp, w_f = w2[:, :3].contiguous(), w2[:, 3:].contiguous()
+    g_cm = torch.empty(B, C, N, dtype=torch.float32, device=dev)
+    g_pm = torch.empty(B, N, C, dtype=torch.float32, device=dev)
+    pooled = torch.empty(B, C, M, dtype=torch.float32, device=dev)
+    ystar = torch.empty_like(pooled)
+    arg = torch.empty(B, C, M, dtype=torch.uint8, device=dev)
+    invstd = torch.rsqrt(bn.running_var + bn.eps)
+    with torch.cuda.device(dev):
+        _lib.check(lib.amc3d_pointwise_conv_forward(B, Cin, C, N, _ptr(f), _ptr(w_f), None, _ptr(g_cm), _stream(f)),
+                   "pointwise_conv_forward")
+        _lib.check(lib.amc3d_local_aggregation_forward(
+            B, C, N, M, K, 0, int(bool(relu)), float(bn.eps), 0.0, _ptr(g_cm), _ptr(idx), _ptr(dp), _ptr(w_dp), None,
+            _ptr(bn.weight), _ptr(bn.bias), _ptr(g_pm), _ptr(pooled), _ptr(arg), _ptr(ystar), _ptr(bn.running_mean),
+            _ptr(invstd), None, None, None, None, None, None, 0, _stream(f)), "local_aggregation_forward")
+    return pooled
+
+
 class PointwiseConv(Function):
     """y = conv1x1(x, weight, bias): nn.Conv1d / nn.Conv2d with kernel size 1 (models/layers/conv.py:8-21) on the
     fp32 MFMA kernels of csrc/pwconv.hip.  x (B,Cin,*spatial) fp32, weight (Cout,Cin,1[,1]), bias (Cout) or None."""

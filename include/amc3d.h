@@ -228,6 +228,41 @@ int amc3d_pointwise_conv_backward(int b, int cin, int cout, long P, const float 
                                   const float *dy, float *dx, float *dweight, void *workspace,
                                   size_t workspace_bytes, void *stream);
 
+/* ---- neighbourhood aggregation with one grouped conv: "convolve first, gather after" ---------------------------------
+ * LocalAggregation.forward / single-layer SetAbstraction.forward (openpoints/models/backbone/pointnext_AA.py:57-63,
+ * 139-170; layers/group.py:244-255, 323-325): grouping_operation -> cat([dp, fj]) -> Conv2d 1x1 -> BatchNorm2d (batch
+ * statistics) [-> ReLU] -> max over the nsample neighbours.  W . [dp ; f[idx]] = (W_f . f)[idx] + W_dp . dp, so the conv
+ * runs on the n source points (amc3d_pointwise_conv_forward), BatchNorm's statistics follow from n-sized sums and the
+ * geometry moments below, and the only pass over npoints * nsample positions is the gather + max itself (csrc/lagg.hip).
+ * Supported: cout in {8,16,32,64,128} or a multiple of 128; nsample <= 64. */
+int amc3d_local_aggregation_supported(int cout, int nsample);
+/* geometry moments of a neighbourhood query (coordinates only; part of the geometry plan): idx (b,npoints,nsample) into
+ * the n support points, dp (b,3,npoints,nsample) -> opaque buffer holding each support point's in-degree and the sum of
+ * the dp that reference it (fixed point: independent of the order of the atomics) and the global sums of dp and dp dp^T */
+size_t amc3d_group_moments_bytes(int b, int n);
+int amc3d_group_moments(int b, int n, int npoints, int nsample, const int *idx, const float *dp, void *moments,
+                        size_t moments_bytes, void *stream);
+size_t amc3d_local_aggregation_workspace_bytes(int b, int cout, int n, int npoints);
+/* g_cm (b,cout,n) = W_f . f from amc3d_pointwise_conv_forward; w_dp (cout,3) = the conv weight's dp columns.
+ * Outputs: pooled (b,cout,npoints), arg (b,cout,npoints) bytes = torch.max's indices, ystar = the pre-BatchNorm value at
+ * arg, g_pm (b,n,cout) point-major copy of g_cm, gd (cout,3) doubles (all kept for backward), mean / invstd /
+ * var_unbiased (cout) + nn.BatchNorm's running update when running_mean != NULL (momentum < 0: left to the caller).
+ * training == 0 (eval): mean / invstd are inputs (running statistics); moments, gd, var_unbiased, workspace may be NULL */
+int amc3d_local_aggregation_forward(int b, int cout, int n, int npoints, int nsample, int training, int relu, float eps,
+                                    float momentum, const float *g_cm, const int *idx, const float *dp, const float *w_dp,
+                                    const void *moments, const float *gamma, const float *beta, float *g_pm, float *pooled,
+                                    unsigned char *arg, float *ystar, float *mean, float *invstd, float *var_unbiased,
+                                    double *gd, float *running_mean, float *running_var, long long *num_batches_tracked,
+                                    void *workspace, size_t workspace_bytes, void *stream);
+/* dg_cm (b,cout,n) = gradient w.r.t. g_cm (feed it to amc3d_pointwise_conv_backward for df and dW_f); dw_dp (cout,3),
+ * dgamma, dbeta (cout).  The pooled gradient is scattered with cout * npoints float atomics (not x nsample). */
+int amc3d_local_aggregation_backward(int b, int cout, int n, int npoints, int nsample, int relu, const float *dpooled,
+                                     const float *ystar, const unsigned char *arg, const float *g_pm, const int *idx,
+                                     const float *dp, const float *w_dp, const void *moments, const double *gd,
+                                     const float *mean, const float *invstd, const float *gamma, const float *beta,
+                                     float *dg_cm, float *dw_dp, float *dgamma, float *dbeta, void *workspace,
+                                     size_t workspace_bytes, void *stream);
+
 /* ---- tail of a two-layer SetAbstraction block, recomputed instead of materialised -----------------------------
  * BN1 -> ReLU -> Conv2d 1x1 (C1 -> C2) -> BN2 [-> ReLU] -> max over the K = 32 neighbours
  * (openpoints/models/backbone/pointnext_AA.py:104-127, 164-166) from the first conv's raw output y1 (B,C1,M,32),

@@ -1,0 +1,118 @@
+"""Convolve-before-gather neighbourhood aggregation (csrc/lagg.hip, ops.LocalAggregationFused) against the layer as the
+reference writes it -- grouping_operation + cat([dp, fj]) + Conv2d 1x1 + BatchNorm2d (batch statistics) [+ ReLU] + max
+over the neighbours (pointnext_AA.py:57-63, 139-170) -- evaluated by torch in fp64 on the same inputs: forward values,
+arg-max picks, batch statistics / running buffers, and every gradient (routing = the kernel's own picks)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(B, Cin, C, N, M, K, seed, relu, radius=0.35):
+    from amcontrast3d_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    dev = torch.device("cuda:0")
+    p = torch.rand(B, N, 3, generator=g).to(dev)
+    q = p[:, :M].contiguous()
+    idx = ops.ball_query(radius, K, p, q)
+    dp = (ops.grouping_operation(p.transpose(1, 2).contiguous(), idx) - q.transpose(1, 2).unsqueeze(-1)) / radius
+    f = torch.randn(B, Cin, N, generator=g).to(dev)
+    w = (torch.randn(C, Cin + 3, 1, 1, generator=g) * 0.3).to(dev)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    gamma[::5] *= -1  # negative scale factors too
+    beta = (torch.randn(C, generator=g) * 0.2).to(dev)
+    go = torch.randn(B, C, M, generator=g).to(dev)
+    return p, idx, dp.contiguous(), f, w, gamma, beta, go
+
+
+def _reference(idx, dp, f, w, gamma, beta, go, relu, arg, eps=1e-5):
+    """fp64 torch evaluation; the max-pool gathers at `arg` (the kernel's picks) so that the gradients are comparable"""
+    B, Cin, N = f.shape
+    f = f.double().requires_grad_(True)
+    w = w.double().requires_grad_(True)
+    gamma = gamma.double().requires_grad_(True)
+    beta = beta.double().requires_grad_(True)
+    fj = f.gather(2, idx.reshape(B, 1, -1).expand(-1, Cin, -1).long()).reshape(B, Cin, idx.shape[1], idx.shape[2])
+    x = torch.cat([dp.double(), fj], 1)
+    y = torch.nn.functional.conv2d(x, w)
+    mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
+    z = (y - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + eps) * gamma[None, :, None, None] + beta[None, :, None, None]
+    if relu:
+        z = torch.relu(z)
+    own = z.max(-1)
+    pooled = z.gather(-1, arg.long().unsqueeze(-1)).squeeze(-1)
+    pooled.backward(go.double())
+    cnt = y.numel() / y.shape[1]
+    return {"pooled": pooled.detach(), "own_max": own.values.detach(), "own_arg": own.indices, "mean": mean.detach(),
+            "var_u": (var * cnt / (cnt - 1)).detach(), "df": f.grad, "dw": w.grad, "dgamma": gamma.grad, "dbeta": beta.grad}
+
+
+@pytest.mark.parametrize("B,Cin,C,N,M,K,relu", [
+    (2, 8, 8, 700, 700, 32, True),        # test-width LocalAggregation (M = N)
+    (2, 16, 32, 900, 225, 32, True),      # strided SetAbstraction
+    (3, 32, 64, 1500, 375, 32, False),    # no ReLU behind the BatchNorm
+    (2, 64, 64, 1200, 1200, 32, True),
+    (1, 128, 128, 800, 800, 32, True),
+    (2, 64, 256, 640, 160, 32, True),     # two channel chunks of 128
+    (1, 24, 512, 300, 75, 16, True),      # 16 neighbours, four chunks
+])
+def test_local_aggregation_matches_the_unfused_layer(B, Cin, C, N, M, K, relu):
+    from amcontrast3d_amd import ops
+    p, idx, dp, f, w, gamma, beta, go = _case(B, Cin, C, N, M, K, 11 + C, relu)
+    bn = torch.nn.BatchNorm2d(C).to(f.device)
+    mom = ops.group_moments(idx, dp, N)
+    fr, wr, gr, br = (t.clone().requires_grad_(True) for t in (f, w, gamma, beta))
+    log = {}
+    ops.pool_log(log)
+    try:
+        pooled = ops.LocalAggregationFused.apply(fr, dp, idx, mom, wr, gr, br, 1e-5, relu, bn)
+    finally:
+        ops.pool_log(None)
+    pooled.backward(go)
+    arg = log[0]
+    ref = _reference(idx, dp, f, w, gamma, beta, go, relu, arg)
+    tol = lambda r: 2e-5 * max(1.0, float(r.abs().max()))
+    assert float((pooled.double() - ref["pooled"]).abs().max()) <= tol(ref["pooled"])
+    # the kernel's pick attains the true maximum (first index among equals, up to fp32 rounding of the values)
+    assert float((ref["pooled"] - ref["own_max"]).abs().max()) <= tol(ref["own_max"])
+    assert float((arg.long() != ref["own_arg"]).double().mean()) <= 2e-3
+    assert float((bn.running_mean.double() - 0.1 * ref["mean"]).abs().max()) <= 1e-5
+    assert float((bn.running_var.double() - (0.9 + 0.1 * ref["var_u"])).abs().max()) <= 1e-5 * max(1.0, float(ref["var_u"].max()))
+    assert int(bn.num_batches_tracked) == 1
+    for name, got, want in (("df", fr.grad, ref["df"]), ("dw", wr.grad, ref["dw"]), ("dgamma", gr.grad, ref["dgamma"]),
+                            ("dbeta", br.grad, ref["dbeta"])):
+        err = float((got.double() - want).abs().max())
+        assert err <= 5e-5 * max(1.0, float(want.abs().max())), (name, err, float(want.abs().max()))
+
+
+def test_local_aggregation_eval_mode_and_moments():
+    from amcontrast3d_amd import ops
+    B, Cin, C, N, M, K = 2, 16, 32, 900, 225, 32
+    p, idx, dp, f, w, gamma, beta, go = _case(B, Cin, C, N, M, K, 5, True)
+    # moments against torch: in-degree, dp sums, global sums
+    mom = ops.group_moments(idx, dp, N)
+    raw = mom.cpu().numpy()
+    glob = raw[:72].view(np.int64).astype(np.float64) / 2.0 ** 30
+    cnt = raw[128:128 + 4 * B * N].view(np.int32).reshape(B, N)
+    off = 128 + 4 * B * N + 4 * ((B * N) & 1)
+    dsum = raw[off:off + 24 * B * N].view(np.int64).reshape(B, N, 3).astype(np.float64) / 2.0 ** 36
+    flat = idx.reshape(B, -1).long().cpu()
+    want_cnt = torch.stack([torch.bincount(flat[b], minlength=N) for b in range(B)]).numpy()
+    np.testing.assert_array_equal(cnt, want_cnt)
+    d = dp.reshape(B, 3, -1).double().cpu()
+    want_d = torch.zeros(B, N, 3, dtype=torch.float64)
+    for b in range(B):
+        want_d[b].index_add_(0, flat[b], d[b].t())
+    np.testing.assert_allclose(dsum, want_d.numpy(), atol=1e-7)
+    np.testing.assert_allclose(glob[:3], d.sum((0, 2)).numpy(), atol=1e-5)
+    np.testing.assert_allclose(glob[3], float((d[:, 0] * d[:, 0]).sum()), rtol=1e-8, atol=1e-5)
+    # eval mode: running statistics, no gradient
+    bn = torch.nn.BatchNorm2d(C).to(f.device)
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5); bn.weight.copy_(gamma); bn.bias.copy_(beta)
+    bn.eval()
+    got = ops.local_aggregation_eval(f, dp, idx, w, bn, True)
+    fj = ops.grouping_operation(f, idx)
+    want = torch.relu(bn(torch.nn.functional.conv2d(torch.cat([dp, fj], 1), w))).max(-1).values
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
