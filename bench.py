@@ -72,6 +72,9 @@ def parse():
                          "captured segments of the step (amcontrast3d_amd/graphs.py)")
     ap.add_argument("--pool", type=int, default=4,
                     help="distinct resident batches rotated through the pipeline (different geometry every step)")
+    ap.add_argument("--lean", action="store_true",
+                    help="profiling runs: stop after the timed loop (no parts-alone / serial / per-operator passes, no CPU "
+                         "baseline), so that the tail of a rocprofv3 trace is the steady state")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="no GPU: run only the multi-rank control flow (launcher, process group, scene shards, flat "
                          "gradient all-reduce, barrier/max timing, replica check) on a small torch CPU model over gloo; "
@@ -579,6 +582,12 @@ def main():
                     f"{tag} {ref.elapsed_time(e0):.2f}-{ref.elapsed_time(e1):.2f}" for tag, e0, e1 in log), file=sys.stderr)
         torch.cuda.synchronize()
 
+    if args.lean:
+        if rank == 0:
+            print(json.dumps({"ms_per_step": round(dt / args.steps * 1e3, 3), "loss": final_loss, "lean": True}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     parts = None
     no_overlap_ms = None
     if use_graph and overlap:  # on every rank: with SyncBN the feature replay contains collectives

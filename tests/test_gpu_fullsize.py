@@ -172,12 +172,15 @@ def test_cfg2_pointnext_s_24000(B):
 def test_cfg3_pointnext_l_24000():
     got, want, calls = _step("L", 2, 24000, False, 0.04)
     _compare(got, want, False)
-    # every LocalAggregation / SetAbstraction layer of L runs the fused gather+conv kernel (no group_points + library conv)
-    assert calls.get("group_points", 0) == 0, calls
-    assert calls.get("grouped_conv_forward", 0) == 4 + (2 + 4 + 2 + 2), calls
+    # every SetAbstraction (4) / LocalAggregation (2 + 4 + 2 + 2) layer of L runs convolve-before-gather (csrc/lagg.hip);
+    # grouping_operation is left with the relative positions of the geometry plan only (one per ball query)
+    assert calls.get("local_aggregation_forward", 0) == 4 + (2 + 4 + 2 + 2), calls
+    assert calls.get("local_aggregation_backward", 0) == 14 and calls.get("grouped_conv_forward", 0) == 0, calls
+    assert calls.get("group_points", 0) == calls.get("ball_query", 0) and calls.get("group_points_grad", 0) == 0, calls
 
 
 def test_cfg4_pointnext_xl_mm_64000():
     got, want, calls = _step("XL", 1, 64000, True, 0.02)
     _compare(got, want, True)
-    assert calls.get("group_points", 0) == 0, calls
+    assert calls.get("local_aggregation_forward", 0) == 4 + (3 + 6 + 3 + 3), calls  # XL: blocks [1,4,7,4,4]
+    assert calls.get("group_points", 0) == calls.get("ball_query", 0) and calls.get("group_points_grad", 0) == 0, calls
