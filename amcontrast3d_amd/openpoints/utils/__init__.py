@@ -8,10 +8,8 @@ from . import registry
 from .config import EasyConfig
 from .metrics import AverageMeter, ConfusionMatrix, get_mious
 from .registry import Registry, build_from_cfg
-
-
-def cal_model_parm_nums(model):
-    return sum(p.numel() for p in model.parameters())
+from .ckpt_util import (cal_model_parm_nums, get_missing_parameters_message, get_unexpected_parameters_message,  # noqa: F401
+                        load_checkpoint, resume_checkpoint, resume_model, resume_optimizer, save_checkpoint)
 
 
 def _overlay_optional():
@@ -22,8 +20,6 @@ def _overlay_optional():
         'random': ['set_random_seed'],
         'logger': ['setup_logger_dist', 'generate_exp_directory', 'resume_exp_directory'],
         'wandb': ['Wandb'],
-        'ckpt_util': ['resume_model', 'resume_optimizer', 'resume_checkpoint', 'save_checkpoint', 'load_checkpoint',
-                      'get_missing_parameters_message', 'get_unexpected_parameters_message'],
         'dist_utils': ['reduce_tensor', 'gather_tensor', 'find_free_port'],
     }
     for mod, names in table.items():

@@ -109,12 +109,9 @@ def build(variant, dev, world, ddp, mm=False, sync_bn=False):
     cc = EasyConfig(); cc.update(configs.criterion_cfg_mm() if mm else configs.criterion_cfg())
     criterion = build_criterion_from_cfg(cc).to(dev)
     aargs = EasyConfig(); aargs.update(configs.ambiguity_args_mm("s3dis") if mm else configs.ambiguity_args("s3dis"))
-    # cfgs/s3dis/default.yaml:64-72: AdamW lr 0.01 wd 1e-4, clip 10
-    decay, no_decay = [], []
-    for p in model.parameters():
-        (no_decay if p.ndim <= 1 else decay).append(p)
-    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 1e-4}, {"params": no_decay, "weight_decay": 0.0}],
-                            lr=0.01, capturable=True, fused=True)
+    # cfgs/s3dis/default.yaml:64-72: AdamW lr 0.01 wd 1e-4 (1-d parameters and biases undecayed), clip 10
+    from openpoints.optim import build_optimizer_from_cfg
+    opt = build_optimizer_from_cfg(model, NAME="adamw", lr=0.01, weight_decay=1e-4)  # fused + capturable on the GPU
     return cfg, model, criterion, aargs, opt
 
 
