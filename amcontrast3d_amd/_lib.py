@@ -51,6 +51,11 @@ SIGNATURES = {
     "amc3d_pointwise_conv_forward": (_i, [_i, _i, _i, _l, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_pointwise_conv_workspace_bytes": (_sz, [_i, _i, _i, _l]),
     "amc3d_pointwise_conv_backward": (_i, [_i, _i, _i, _l, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "amc3d_voxelize_workspace_bytes": (_sz, [_i]),
+    "amc3d_voxelize": (_i, [_i, _vp, ctypes.c_double] + [_vp] * 7 + [_sz, _vp]),
+    "amc3d_voxel_select": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_crop_nearest_workspace_bytes": (_sz, [_i]),
+    "amc3d_crop_nearest": (_i, [_i, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_local_aggregation_supported": (_i, [_i, _i]),
     "amc3d_group_moments_bytes": (_sz, [_i, _i]),
     "amc3d_group_moments": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),

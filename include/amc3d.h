@@ -228,6 +228,25 @@ int amc3d_pointwise_conv_backward(int b, int cin, int cout, long P, const float 
                                   const float *dy, float *dx, float *dweight, void *workspace,
                                   size_t workspace_bytes, void *stream);
 
+/* ---- input pipeline on the device (openpoints/dataset/data_util.py:92-174; dataset/s3dis/s3dis.py:122-144) -----------
+ * voxelize: floor(coord / voxel_size) in float64 -> FNV-1a 64-bit hash of the three cell coordinates (fnv_hash_vec) ->
+ * stable sort by key -> voxel ids / starts / counts.  coord (n,3) fp32 must be shifted to its min corner (crop_pc does
+ * that first).  numpy's argsort is not stable, so the reference leaves the order of the points inside one voxel
+ * unspecified; idx_sort here is the stable order.  key (n) = hash per point; idx_sort (n); voxel_idx (n) = voxel id of
+ * sorted position i (np.unique's inverse); start (n+1); count (n, zero beyond nvox); nvox (1) -- all device memory. */
+size_t amc3d_voxelize_workspace_bytes(int n);
+int amc3d_voxelize(int n, const float *coord, double voxel_size, unsigned long long *key, int *idx_sort, int *voxel_idx,
+                   int *start, int *count, int *nvox, void *workspace, size_t workspace_bytes, void *stream);
+/* train mode (data_util.py:136-140): idx_unique[v] = idx_sort[start[v] + rnd[v] % count[v]], rnd = the caller's
+ * np.random.randint(0, count.max(), nvox) draw */
+int amc3d_voxel_select(int nvox, const int *start, const int *count, const int *idx_sort, const int *rnd, int *idx_unique,
+                       void *stream);
+/* crop_pc's crop (data_util.py:157-160): d2 (n) fp32 = squared distances to coord[init_idx] (((dx^2+dy^2)+dz^2), no
+ * contraction), crop_idx (keep) = indices of the keep nearest points in ascending distance */
+size_t amc3d_crop_nearest_workspace_bytes(int n);
+int amc3d_crop_nearest(int n, const float *coord, int init_idx, int keep, float *d2, int *crop_idx, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
 /* ---- neighbourhood aggregation with one grouped conv: "convolve first, gather after" ---------------------------------
  * LocalAggregation.forward / single-layer SetAbstraction.forward (openpoints/models/backbone/pointnext_AA.py:57-63,
  * 139-170; layers/group.py:244-255, 323-325): grouping_operation -> cat([dp, fj]) -> Conv2d 1x1 -> BatchNorm2d (batch

@@ -334,6 +334,46 @@ def run_eval_case(name="eval_w8_room", n_room=5000, voxel=0.06, width=8, nsample
           f"inner pts={int(cm_i.value.sum())} ({os.path.getsize(os.path.join(OUT, name + '.npz')) / 1e6:.2f} MB)")
 
 
+def run_input_case(name="input_room", n_base=12000, copies=3, voxel=0.04, voxel_max=1000):
+    """Input pipeline of the S3DIS loader (dataset/s3dis/s3dis.py:122-144 -> dataset/data_util.py:92-174): the reference's
+    own fnv_hash_vec / voxelize / crop_pc run on a raw (several points per voxel) synthetic room.  numpy's argsort is
+    not stable, so the order of points INSIDE a voxel (idx_sort) is whatever numpy's sort made of it; recorded as is,
+    compared as sets per voxel."""
+    from openpoints.dataset.data_util import crop_pc, fnv_hash_vec, voxelize
+    room = synthetic.make_batch(1, n_base, first_id=700, voxel_size=0.02)
+    rng = np.random.default_rng(11)
+    base = room["pos"][0].astype(np.float32)
+    coord = np.concatenate([base + rng.uniform(-0.015, 0.015, base.shape).astype(np.float32) for _ in range(copies)], 0)
+    feat = np.concatenate([room["x"][0, :3].T] * copies, 0).astype(np.float32)
+    label = np.concatenate([room["y"][0]] * copies, 0).astype(np.int64)
+    perm = rng.permutation(len(coord))
+    coord, feat, label = coord[perm], feat[perm], label[perm]
+    coord = coord - coord.min(0)
+    key = fnv_hash_vec(np.floor(coord / np.array(voxel)))
+    idx_sort, voxel_idx, count = voxelize(coord, voxel, mode=1)
+    np.random.seed(3)
+    rnd = np.random.randint(0, count.max(), count.size)   # the draw voxelize(mode=0) makes (data_util.py:138-139)
+    np.random.seed(3)
+    idx_unique = voxelize(coord, voxel, mode=0)
+    assert np.array_equal(idx_unique, idx_sort[np.cumsum(np.insert(count, 0, 0)[0:-1]) + rnd % count])
+    # the crop stage alone on the voxelised cloud (validation split: centre point N // 2, no shuffle)
+    cv, fv, lv = coord[idx_unique].copy(), feat[idx_unique].copy(), label[idx_unique].copy()
+    d2 = np.sum(np.square(cv - cv[len(lv) // 2]), 1)
+    crop_idx = np.argsort(d2)[:voxel_max]
+    c_out, f_out, l_out = crop_pc(cv.copy(), fv.copy(), lv.copy(), "val", voxel, voxel_max, downsample=False, variable=True,
+                                  shuffle=False)
+    assert np.array_equal(c_out, (cv[crop_idx] - cv[crop_idx].min(0)).astype(np.float32))
+    out = {"coord": coord, "feat": feat, "label": label, "voxel": np.float64(voxel), "voxel_max": np.int64(voxel_max),
+           "key": key, "idx_sort": idx_sort.astype(np.int64), "voxel_idx": voxel_idx.astype(np.int64),
+           "count": count.astype(np.int64), "rnd": rnd.astype(np.int64), "idx_unique": idx_unique.astype(np.int64),
+           "d2": d2.astype(np.float32), "crop_idx": crop_idx.astype(np.int64), "crop_coord": c_out, "crop_feat": f_out,
+           "crop_label": l_out.astype(np.int64),
+           "meta": json.dumps({"numpy": np.__version__, "note": "coord / np.array(voxel) is a float64 division under numpy 2 "
+                               "(NEP 50: a 0-d array is not a weak scalar)"})}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "raw points", len(coord), "voxels", len(count), "max per voxel", int(count.max()), "crop", len(crop_idx))
+
+
 def run_mm_cases():
     # AMContrast3D++ with a narrow S-shaped backbone and stored weights: APM towers, masked refinement (DualMasks,
     # threshold lowered so that a good share of the points is refined at seed-0 init), three-term loss
@@ -349,6 +389,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "eval":
         run_eval_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "input":
+        run_input_case()
         sys.exit(0)
     run_state_keys()
     run_ops_case()
@@ -366,3 +409,4 @@ if __name__ == "__main__":
                    ignore_index=-100, ignore_frac=0.05, voxel_size=0.02, global_feat="max", grad_keys=G[:1])
     run_mm_cases()
     run_eval_case()
+    run_input_case()
