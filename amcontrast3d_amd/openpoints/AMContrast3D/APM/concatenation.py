@@ -48,12 +48,12 @@ class APM_pf_ConCate(nn.Module):
         (rows = points, BatchNorm1d over the rows) without flatten / permute copies and without handing
         (B*n) x 35 -> 32 -> ... -> 1 products to a GEMM library (hipBLASLt spends ~4 ms per step on them at
         B*n = 192000).  -> (B*n, 1)"""
-        from amcontrast3d_amd.ops import BatchNormAct, pointwise_conv
+        from amcontrast3d_amd.ops import BatchNormAct, mixed_precision, pointwise_conv
         from openpoints.models.layers.blocks import _fusable_bn
         x = torch.cat((p.transpose(1, 2), f), dim=1).contiguous()
         for mod in tower:
             if isinstance(mod, nn.Linear):
-                x = pointwise_conv(x, mod.weight.unsqueeze(-1), mod.bias)
+                x = pointwise_conv(x, mod.weight.unsqueeze(-1), mod.bias, mixed_precision())
             elif isinstance(mod, nn.BatchNorm1d):
                 x = BatchNormAct.apply(x, mod.weight, mod.bias, mod.eps, False, mod)[0] if _fusable_bn(mod, x) else mod(x)
             else:  # Dropout (p = 0 in the shipped configs), Sigmoid
@@ -63,7 +63,7 @@ class APM_pf_ConCate(nn.Module):
     def forward(self, p, f):
         """p (B,n,3) with f (B,D,n), or already flattened p (m,3) with f (m,D) -> a (m,1) [, a_map (m,D)]"""
         if (p.dim() == 3 and f.dim() == 3 and f.is_cuda and f.dtype == torch.float32 and not self.map
-                and not torch.is_autocast_enabled() and f.shape[1] in self.dim):
+                and f.shape[1] in self.dim):
             return self._tower_channel_major(getattr(self, f'layer_{self.dim.index(f.shape[1])}'), p, f)
         if not (p.dim() == 2 and f.dim() == 2):
             p = torch.flatten(p, start_dim=0, end_dim=1)

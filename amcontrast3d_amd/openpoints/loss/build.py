@@ -19,8 +19,7 @@ def _cross_entropy(crit, logit, target):
     """(CE value, flattened target): nn.CrossEntropyLoss on the (B*N, ncls) view of the logits, through the fused
     kernel when the module is the plain default"""
     if (type(crit) is CrossEntropyLoss and crit.weight is None and crit.label_smoothing == 0.0
-            and crit.reduction == 'mean' and logit.is_cuda and logit.dtype == torch.float32 and logit.dim() == 3
-            and not torch.is_autocast_enabled()):
+            and crit.reduction == 'mean' and logit.is_cuda and logit.dtype == torch.float32 and logit.dim() == 3):
         # same value without the (B*N, ncls) transposed copy: one fused pass over the (B,ncls,N) logits
         from amcontrast3d_amd.ops import cross_entropy_mean
         return cross_entropy_mean(logit, target, crit.ignore_index), target.flatten()

@@ -112,7 +112,7 @@ def _fusable_bn(bn, x):
     """plain training-mode BatchNorm1d/2d on a contiguous fp32 GPU tensor (SyncBatchNorm, eval mode and
     other norms take the ordinary torch modules)"""
     return (type(bn) in (nn.BatchNorm1d, nn.BatchNorm2d) and bn.training and bn.affine and bn.track_running_stats
-            and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled())
+            and x.is_cuda and x.dtype == torch.float32)
 
 
 def _eval_bn(bn, x):
@@ -120,7 +120,7 @@ def _eval_bn(bn, x):
     the fused kernels with the running statistics (ops.bn_eval)"""
     return (isinstance(bn, nn.modules.batchnorm._BatchNorm) and not bn.training and bn.affine
             and bn.track_running_stats and bn.running_mean is not None and x.is_cuda and x.dtype == torch.float32
-            and not torch.is_grad_enabled() and not torch.is_autocast_enabled())
+            and not torch.is_grad_enabled())
 
 
 def _synced_bn_group(bn, x):
@@ -128,8 +128,7 @@ def _synced_bn_group(bn, x):
     kernels exchange their per-channel sums: ops.SyncBatchNormFused), else None"""
     import torch.distributed as dist
     if not (type(bn) is nn.SyncBatchNorm and bn.training and bn.affine and bn.track_running_stats and x.is_cuda
-            and x.dtype == torch.float32 and not torch.is_autocast_enabled() and dist.is_available()
-            and dist.is_initialized()):
+            and x.dtype == torch.float32 and dist.is_available() and dist.is_initialized()):
         return None
     group = bn.process_group if bn.process_group is not None else dist.group.WORLD
     return group if dist.get_world_size(group) > 1 or _FORCE_SYNCED_BN else None
@@ -142,9 +141,15 @@ def conv1x1(conv, x):
     """conv(x); a plain 1x1 convolution on a contiguous fp32 GPU tensor runs on the MFMA kernels of
     csrc/pwconv.hip (same parameters, same autograd contract), anything else on the stored torch module."""
     if (type(conv) in (nn.Conv1d, nn.Conv2d, Conv1d, Conv2d) and x.is_cuda and x.dtype == torch.float32
-            and not torch.is_autocast_enabled() and conv.groups == 1 and conv.padding_mode == 'zeros'
+            and conv.groups == 1 and conv.padding_mode == 'zeros'
             and all(k == 1 for k in conv.kernel_size) and all(v == 1 for v in conv.stride)
             and all(v == 0 for v in conv.padding) and x.dim() == conv.weight.dim()):
+        from amcontrast3d_amd.ops import mixed_precision
+        if mixed_precision():
+            # use_amp (main_AA.py:389-394): bf16 operands, fp32 accumulation on the bf16 MFMA; activations, BatchNorm,
+            # searches and the loss stay fp32 (tensors are never stored in bf16)
+            from amcontrast3d_amd.ops import pointwise_conv
+            return pointwise_conv(x, conv.weight, conv.bias, True)
         if _pw_pays(conv, x):
             from amcontrast3d_amd.ops import pointwise_conv
             return pointwise_conv(x, conv.weight, conv.bias)
@@ -255,7 +260,7 @@ def fused_local_aggregation(blocks, f, geom, feature_type):
     from amcontrast3d_amd import ops
     import os
     if (feature_type != 'dp_fj' or geom is None or 'idx' not in geom or geom.get('mom') is None or f is None or not f.is_cuda
-            or f.dtype != torch.float32 or torch.is_autocast_enabled() or len(blocks) != 1
+            or f.dtype != torch.float32 or len(blocks) != 1
             or os.environ.get("AMC3D_NO_LOCAL_AGGREGATION")):
         return None
     blk = blocks[0]
@@ -282,7 +287,7 @@ def fused_first_conv(blocks, f, geom, feature_type):
     from amcontrast3d_amd import ops
     blk = blocks[0]
     if (feature_type != 'dp_fj' or geom is None or 'idx' not in geom or f is None or not f.is_cuda
-            or f.dtype != torch.float32 or torch.is_autocast_enabled() or not isinstance(blk, nn.Sequential)
+            or f.dtype != torch.float32 or not isinstance(blk, nn.Sequential)
             or len(blk) < 2 or not isinstance(blk[0], nn.Conv2d)
             or not isinstance(blk[1], nn.modules.batchnorm._BatchNorm)):
         return None

@@ -64,6 +64,20 @@ def _need_gpu(*ts):
                                "there is no CPU fallback" % t.device)
 
 
+def mixed_precision():
+    """True inside torch.autocast('cuda', dtype=torch.bfloat16): the pointwise convolutions then run in bf16 compute /
+    fp32 accumulate (csrc/gemm_bf16.hip) while every tensor stays fp32 in memory (main_AA.py:389-394 use_amp)"""
+    return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+
+
+def _pw(lib, bf16):
+    """(forward, workspace_bytes, backward) entry points of the pointwise conv in the requested arithmetic"""
+    if bf16:
+        return (lib.amc3d_pointwise_conv_forward_bf16, lib.amc3d_pointwise_conv_workspace_bytes_bf16,
+                lib.amc3d_pointwise_conv_backward_bf16)
+    return lib.amc3d_pointwise_conv_forward, lib.amc3d_pointwise_conv_workspace_bytes, lib.amc3d_pointwise_conv_backward
+
+
 def _need_dtype(dtype, **named):
     """The C-ABI takes raw pointers: a float64 / bf16 coordinate or an int64 index would be reinterpreted silently.
     The reference's pybind layer throws on data_ptr<float>() / data_ptr<int>() of another dtype (ball_query.cpp:29-38);
@@ -808,9 +822,10 @@ class LocalAggregationFused(Function):
         wb = int(lib.amc3d_local_aggregation_workspace_bytes(B, C, N, M))
         work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
         mom, rm, rv, nbt = _bn_running_args(bn)
+        ctx.bf16 = mixed_precision()  # the conv on the source points in bf16 compute under autocast; the rest is fp32
         with torch.cuda.device(dev):
             with timing.span("pointwise_conv_forward", 4 * B * N * (Cin + C), 2.0 * B * N * Cin * C):
-                _lib.check(lib.amc3d_pointwise_conv_forward(B, Cin, C, N, _ptr(f), _ptr(w_f), None, _ptr(g_cm), _stream(f)),
+                _lib.check(_pw(lib, ctx.bf16)[0](B, Cin, C, N, _ptr(f), _ptr(w_f), None, _ptr(g_cm), _stream(f)),
                            "pointwise_conv_forward")
             # algorithmic bytes: G read (statistics) + the gathered rows, idx, dp + the pooled outputs
             with timing.span("local_aggregation_forward", 8 * B * N * C + B * M * K * (4 * C + 16) + 9 * B * M * C):
@@ -843,7 +858,8 @@ class LocalAggregationFused(Function):
         need_f = ctx.needs_input_grad[0]
         df = torch.empty_like(f) if need_f else None
         dw_f = torch.empty(C, Cin, dtype=torch.float32, device=dev)
-        wb2 = int(lib.amc3d_pointwise_conv_workspace_bytes(B, Cin, C, N))
+        _, pw_wbytes, pw_bwd = _pw(lib, ctx.bf16)
+        wb2 = int(pw_wbytes(B, Cin, C, N))
         work2 = torch.empty(max(wb2, 4), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             with timing.span("local_aggregation_backward", 17 * B * M * C + 12 * B * N * C):
@@ -853,9 +869,8 @@ class LocalAggregationFused(Function):
                     _ptr(dw_dp), _ptr(dgamma), _ptr(dbeta), _ptr(work), wb, _stream(f)), "local_aggregation_backward")
             with timing.span("pointwise_conv_backward", 4 * B * N * (Cin + C) * (1 + int(need_f)),
                              2.0 * B * N * Cin * C * (1 + int(need_f))):
-                _lib.check(lib.amc3d_pointwise_conv_backward(B, Cin, C, N, _ptr(f), _ptr(w_f), _ptr(dg_cm),
-                                                             _ptr(df) if need_f else None, _ptr(dw_f), _ptr(work2), wb2,
-                                                             _stream(f)), "pointwise_conv_backward")
+                _lib.check(pw_bwd(B, Cin, C, N, _ptr(f), _ptr(w_f), _ptr(dg_cm), _ptr(df) if need_f else None, _ptr(dw_f),
+                                  _ptr(work2), wb2, _stream(f)), "pointwise_conv_backward")
         dw = torch.cat((dw_dp, dw_f), dim=1).view(ctx.wshape)
         return df, None, None, None, dw, dgamma, dbeta, None, None, None
 
@@ -892,8 +907,9 @@ class PointwiseConv(Function):
     fp32 MFMA kernels of csrc/pwconv.hip.  x (B,Cin,*spatial) fp32, weight (Cout,Cin,1[,1]), bias (Cout) or None."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, bf16=False):
         _need_gpu(x, weight)
+        _need_dtype(torch.float32, x=x, weight=weight, bias=bias)
         x = x.contiguous()
         B, Cin = x.shape[0], x.shape[1]
         P = x[0, 0].numel()
@@ -901,15 +917,15 @@ class PointwiseConv(Function):
         assert weight.numel() == Cout * Cin, "pointwise_conv needs a 1x1 kernel"
         w2 = weight.reshape(Cout, Cin).contiguous()
         y = torch.empty((B, Cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
-        lib = _lib.load()
+        fwd = _pw(_lib.load(), bf16)[0]
         with torch.cuda.device(x.device), timing.span("pointwise_conv_forward", 4 * B * P * (Cin + Cout),
                                                       2.0 * B * P * Cin * Cout):
-            _lib.check(lib.amc3d_pointwise_conv_forward(B, Cin, Cout, P, _ptr(x), _ptr(w2),
-                                                        _ptr(bias.contiguous()) if bias is not None else None,
-                                                        _ptr(y), _stream(x)), "pointwise_conv_forward")
+            _lib.check(fwd(B, Cin, Cout, P, _ptr(x), _ptr(w2), _ptr(bias.contiguous()) if bias is not None else None,
+                           _ptr(y), _stream(x)), "pointwise_conv_forward")
         ctx.save_for_backward(x, w2)
         ctx.wshape = tuple(weight.shape)
         ctx.has_bias = bias is not None
+        ctx.bf16 = bool(bf16)
         return y
 
     @staticmethod
@@ -923,21 +939,20 @@ class PointwiseConv(Function):
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dx = torch.empty_like(x) if need_x else None
         dw = torch.empty(Cout, Cin, dtype=torch.float32, device=dev) if need_w else None
-        lib = _lib.load()
-        wb = int(lib.amc3d_pointwise_conv_workspace_bytes(B, Cin, Cout, P)) if need_w else 0
+        _, wbytes, bwd = _pw(_lib.load(), ctx.bf16)
+        wb = int(wbytes(B, Cin, Cout, P)) if need_w else 0
         work = torch.empty(max(wb, 4), dtype=torch.uint8, device=dev)
         flops = 2.0 * B * P * Cin * Cout * (int(need_x) + int(need_w))
         with torch.cuda.device(dev), timing.span("pointwise_conv_backward",
                                                  4 * B * P * ((Cin + Cout) * int(need_x) + (Cin + Cout) * int(need_w)), flops):
-            _lib.check(lib.amc3d_pointwise_conv_backward(B, Cin, Cout, P, _ptr(x), _ptr(w2), _ptr(dy),
-                                                         _ptr(dx) if need_x else None, _ptr(dw) if need_w else None,
-                                                         _ptr(work), wb, _stream(dy)), "pointwise_conv_backward")
-        db = dy.reshape(B, Cout, -1).sum(dim=(0, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return dx, (dw.view(ctx.wshape) if need_w else None), db
+            _lib.check(bwd(B, Cin, Cout, P, _ptr(x), _ptr(w2), _ptr(dy), _ptr(dx) if need_x else None,
+                           _ptr(dw) if need_w else None, _ptr(work), wb, _stream(dy)), "pointwise_conv_backward")
+        db = dy.reshape(B, Cout, -1).float().sum(dim=(0, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, (dw.view(ctx.wshape) if need_w else None), db, None
 
 
-def pointwise_conv(x, weight, bias=None):
-    return PointwiseConv.apply(x, weight, bias)
+def pointwise_conv(x, weight, bias=None, bf16=False):
+    return PointwiseConv.apply(x, weight, bias, bf16)
 
 
 def _library_wgrad(dy3, x3):

@@ -72,6 +72,9 @@ def parse():
                          "captured segments of the step (amcontrast3d_amd/graphs.py)")
     ap.add_argument("--pool", type=int, default=4,
                     help="distinct resident batches rotated through the pipeline (different geometry every step)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16: the reference's use_amp (main_AA.py:389-394): model and criterion under autocast; here the 1x1 "
+                         "convolutions then run on the bf16 MFMA with fp32 accumulation, tensors stay fp32")
     ap.add_argument("--lean", action="store_true",
                     help="profiling runs: stop after the timed loop (no parts-alone / serial / per-operator passes, no CPU "
                          "baseline), so that the tail of a rocprofv3 trace is the steady state")
@@ -322,13 +325,14 @@ def main():
     def fwd_bwd():
         if flatg is not None:
             flatg.zero()  # part of the captured half (a fill in accumulate mode; .grad = None in copy mode)
-        if args.mm:  # examples/segmentation/main_MM.py:404-410: segmentation + regression objective
-            logits, stage, _ = model(data)
-            seg, _, _, reg = criterion(logits, data["y"], stage, 13, None, aargs)
-            out["loss"] = seg + reg
-        else:
-            logits, stage = model(data)
-            out["loss"] = criterion(logits, data["y"], stage, 13, None, aargs)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
+            if args.mm:  # examples/segmentation/main_MM.py:404-410: segmentation + regression objective
+                logits, stage, _ = model(data)
+                seg, _, _, reg = criterion(logits, data["y"], stage, 13, None, aargs)
+                out["loss"] = seg + reg
+            else:
+                logits, stage = model(data)
+                out["loss"] = criterion(logits, data["y"], stage, 13, None, aargs)
         out["loss"].backward()
         if flatg is not None:
             flatg.gather()  # copy mode: one multi-tensor copy into the all-reduce buffer, .grad -> its views
@@ -720,7 +724,8 @@ def main():
             "metric": "train-step points/sec (fwd+bwd) on 24k-pt S3DIS clouds",
             "value": round(value, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.dtype == "f32" else "bf16 (1x1 convs on the bf16 MFMA, fp32 accumulate; tensors fp32)",
+            "data": "synthetic",
             "config": {"workload": f"PointNeXt-{args.variant} + AMContrast3D-{'MM (++)' if args.mm else 'AA'}, S3DIS-shaped {args.points}-pt "
                                    f"voxelised (0.04 m) clouds, batch {args.batch}/GPU, fwd + CE/contrast loss + bwd + "
                                    f"clip + AdamW",

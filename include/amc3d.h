@@ -282,6 +282,16 @@ int amc3d_local_aggregation_backward(int b, int cout, int n, int npoints, int ns
                                      float *dg_cm, float *dw_dp, float *dgamma, float *dbeta, void *workspace,
                                      size_t workspace_bytes, void *stream);
 
+/* ---- the same three products in bf16 compute / fp32 accumulate (mixed precision: main_AA.py:389-394 wraps model and
+ * criterion in autocast; BASELINE config 5).  Tensors stay fp32 in memory; operands are rounded to bf16 as they are
+ * staged, multiplied on v_mfma_f32_32x32x16_bf16 and accumulated in fp32 (csrc/gemm_bf16.hip). */
+int amc3d_pointwise_conv_forward_bf16(int b, int cin, int cout, long P, const float *x, const float *weight,
+                                      const float *bias, float *y, void *stream);
+size_t amc3d_pointwise_conv_workspace_bytes_bf16(int b, int cin, int cout, long P);
+int amc3d_pointwise_conv_backward_bf16(int b, int cin, int cout, long P, const float *x, const float *weight,
+                                       const float *dy, float *dx, float *dweight, void *workspace,
+                                       size_t workspace_bytes, void *stream);
+
 /* ---- tail of a two-layer SetAbstraction block, recomputed instead of materialised -----------------------------
  * BN1 -> ReLU -> Conv2d 1x1 (C1 -> C2) -> BN2 [-> ReLU] -> max over the K = 32 neighbours
  * (openpoints/models/backbone/pointnext_AA.py:104-127, 164-166) from the first conv's raw output y1 (B,C1,M,32),

@@ -184,3 +184,39 @@ def test_cfg4_pointnext_xl_mm_64000():
     _compare(got, want, True)
     assert calls.get("local_aggregation_forward", 0) == 4 + (3 + 6 + 3 + 3), calls  # XL: blocks [1,4,7,4,4]
     assert calls.get("group_points", 0) == calls.get("ball_query", 0) and calls.get("group_points_grad", 0) == 0, calls
+
+
+def test_cfg5_pointnext_xl_mm_120000_bf16():
+    """BASELINE config 5: PointNeXt-XL + AMContrast3D++ on a 120000-point whole room (voxel 0.02), one cloud per GPU, bf16
+    mixed precision.  The CPU oracle needs minutes at this size, so the comparison is between two runs of the product: the
+    fp32 step (the kernels test_cfg4 checks against the oracle at 64000 points) and the same step under
+    torch.autocast(bfloat16), where every 1x1 convolution (all of XL's dense work, with the grouped convs convolved before
+    the gather) runs on the bf16 MFMA.  Bounds: sampled coordinates identical (the searches stay fp32), loss within 2e-2,
+    logits within 25 % relative L2 (the oracle under autocast moves them by ~20 % at 4096 points, tests/test_gpu_model.py)."""
+    from amcontrast3d_amd import synthetic, timing
+    dev = torch.device("cuda:0")
+    cfg = configs.model_cfg_mm("XL", dropout=0)
+    model, crit = _build(cfg, True, dev)
+    aa = _easy(configs.ambiguity_args_mm("s3dis"))
+    data = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.make_batch(1, 120000, first_id=400, voxel_size=0.02).items()}
+    logits32, stage32, _ = model(data)
+    seg32, _, _, reg32 = crit(logits32, data["y"], stage32, 13, None, aa)
+    p32 = [s["p_out"].clone() for s in stage32["up"]]
+    logits32, loss32 = logits32.detach(), float(seg32 + reg32)
+    del stage32, seg32, reg32
+    model.zero_grad()
+    with timing.count_calls() as calls:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits, stage, _ = model(data)
+            seg, _, _, reg = crit(logits, data["y"], stage, 13, None, aa)
+        (seg + reg).backward()
+        torch.cuda.synchronize()
+    assert logits.dtype == torch.float32 and calls.get("library_gemm_conv", 0) == 0 and calls.get("group_points_grad", 0) == 0
+    assert calls["local_aggregation_forward"] == 4 + (3 + 6 + 3 + 3) and calls["pointwise_conv_forward"] >= 60, dict(calls)
+    for a, b in zip(p32, stage["up"]):
+        assert torch.equal(a, b["p_out"])
+    rel = float((logits.detach() - logits32).norm() / logits32.norm())
+    print(f"[XL-MM 1x120000 bf16] logits relative L2 to the fp32 step {rel:.3e}; loss {float(seg + reg):.5f} vs {loss32:.5f}; "
+          f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    assert rel <= 0.25 and abs(float(seg + reg) - loss32) <= 2e-2 * abs(loss32)
+    assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in model.parameters())

@@ -230,21 +230,44 @@ def test_mm_precomputed_geometry_is_the_same_computation():
     assert torch.equal(logits0, logits1) and float(seg0) == float(seg1) and abs(r0 - r1) < 1e-9
 
 
-def test_bf16_autocast_step_runs():
-    """use_amp in the reference wraps model and criterion in autocast (examples/segmentation/main_AA.py:389-394;
-    BASELINE config 5 asks for bf16): the fused fp32 kernels step aside for the autocast-aware torch modules, the
-    searches and the loss stay fp32.  A smoke test of that fallback: finite, and close to the fp32 step."""
+def test_bf16_mixed_precision_step_on_the_hip_path():
+    """use_amp in the reference wraps model and criterion in autocast (examples/segmentation/main_AA.py:389-394; BASELINE
+    config 5 asks for bf16).  Here every 1x1 convolution then runs on the bf16 MFMA with fp32 accumulation
+    (csrc/gemm_bf16.hip) while activations, BatchNorm statistics, searches and the loss stay fp32 -- no fallback to the
+    torch modules: the dispatch is asserted.  Tolerance: the bf16 step against the fp32 step of the same product on the same
+    batch.  The yardstick for "close enough" is the reference's own mixed-precision arithmetic: the oracle evaluated under
+    torch.autocast(bfloat16) (bf16 convolutions AND bf16 activations, what use_amp gives the reference) moves the logits by
+    ~20 % (relative L2, random initialisation, ~20 batch-normalised layers); this path keeps fp32 activations and must stay
+    closer to the fp32 step than that, and within 20 % outright; loss within 2e-2."""
+    from oracle import model_ref
+    from amcontrast3d_amd import synthetic, timing
     dev = torch.device("cuda:0")
-    model, criterion = build(configs.model_cfg("S", dropout=0), dev)
-    from amcontrast3d_amd import synthetic
-    aargs = easy(configs.ambiguity_args("s3dis"))
-    data = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.make_batch(2, 4096, first_id=5).items()}
-    logits32, stage = model(data)
-    loss32 = criterion(logits32, data["y"], stage, 13, None, aargs)
-    with torch.autocast("cuda", dtype=torch.bfloat16):
-        logits, stage = model(data)
-        loss = criterion(logits.float(), data["y"], stage, 13, None, aargs)
-    loss.backward()
-    assert logits.dtype == torch.bfloat16
-    assert abs(float(loss) - float(loss32)) <= 2e-2 * abs(float(loss32))
-    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+    for variant, kw in (("S", {}), ("L", {"width": 16, "blocks": [1, 2, 2, 1, 1]})):
+        model, criterion = build(configs.model_cfg(variant, dropout=0, **kw), dev)
+        aargs = easy(configs.ambiguity_args("s3dis"))
+        data = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.make_batch(2, 4096, first_id=5).items()}
+        logits32, stage = model(data)
+        loss32 = criterion(logits32, data["y"], stage, 13, None, aargs)
+        model.zero_grad()
+        with timing.count_calls() as calls:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                logits, stage = model(data)
+                loss = criterion(logits, data["y"], stage, 13, None, aargs)
+            loss.backward()
+        assert logits.dtype == torch.float32  # tensors stay fp32; only the multiplications are bf16
+        assert calls["pointwise_conv_forward"] >= 9 and calls.get("library_gemm_conv", 0) == 0, dict(calls)
+        assert calls["bn_act_forward"] >= 9 and calls["cross_entropy_forward"] == 1 and calls["contrast_forward"] == 4
+        rel = float((logits - logits32).norm() / logits32.norm())
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        cpu = {k: v.cpu() for k, v in data.items()}
+        cfg_d = configs.model_cfg(variant, dropout=0, **kw)
+        with torch.no_grad():
+            ref32, _ = model_ref.model_forward(sd, cfg_d, cpu, training=True)
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                ref_amp, _ = model_ref.model_forward(sd, cfg_d, cpu, training=True)
+        rel_ref = float((ref_amp.float() - ref32).norm() / ref32.norm())
+        print(f"{variant}: logits relative L2 to the fp32 step: this path {rel:.3e}, oracle under autocast {rel_ref:.3e}; "
+              f"loss {float(loss):.5f} vs {float(loss32):.5f}")
+        assert rel <= min(rel_ref, 0.2), (variant, rel, rel_ref)
+        assert abs(float(loss) - float(loss32)) <= 2e-2 * abs(float(loss32))
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())

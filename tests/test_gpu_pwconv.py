@@ -115,3 +115,29 @@ def test_library_gemm_conv_matches_torch_conv(shape):
             assert got.shape == ref.shape
             assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
     os.environ.pop("AMC3D_WGRAD_FORM", None)
+
+
+@pytest.mark.parametrize("B,ci,co,P", [(2, 64, 256, 3000), (1, 35, 32, 5003), (3, 256, 64, 777), (2, 512, 512, 186),
+                                      (1, 1024, 256, 93), (4, 4, 32, 4096)])
+def test_pointwise_conv_bf16_compute(B, ci, co, P):
+    """csrc/gemm_bf16.hip: operands rounded to bf16 (round-to-nearest-even), exact products, fp32 accumulation.  Checked
+    against torch in fp64 ON THE SAME bf16-ROUNDED OPERANDS (then only the fp32 summation order differs: 1e-5), and
+    against the unrounded fp32 product at the bf16 bound (2^-8 per operand, sqrt(K) growth)."""
+    from amcontrast3d_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, ci, P, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(co, ci, 1, generator=g) * 0.1).to(dev).requires_grad_(True)
+    bias = torch.randn(co, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(B, co, P, generator=g).to(dev)
+    y = ops.pointwise_conv(x, w, bias, True)
+    y.backward(go)
+    r = lambda t: t.detach().to(torch.bfloat16).double()
+    yr = torch.einsum("oc,bcp->bop", r(w)[..., 0], r(x)) + bias.detach().double()[None, :, None]
+    dxr = torch.einsum("oc,bop->bcp", r(w)[..., 0], r(go))
+    dwr = torch.einsum("bop,bcp->oc", r(go), r(x))
+    for name, got, ref in (("y", y, yr), ("dx", x.grad, dxr), ("dw", w.grad[..., 0], dwr), ("db", bias.grad, go.double().sum((0, 2)))):
+        err = float((got.double() - ref).abs().max())
+        assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (name, err)
+    y32 = torch.einsum("oc,bcp->bop", w.detach().double()[..., 0], x.detach().double()) + bias.detach().double()[None, :, None]
+    assert float((y.double() - y32).abs().max()) <= 2 ** -7 * float(y32.abs().max()) + 1e-3
