@@ -46,21 +46,25 @@ __device__ __forceinline__ unsigned gb_pack(float lo, float hi)
     return (unsigned)(*reinterpret_cast<const unsigned short *>(&a)) | ((unsigned)(*reinterpret_cast<const unsigned short *>(&b)) << 16);
 }
 
-// registers of one chunk of one operand: 128 rows x 32 k floats = 1024 float4, four per thread
+// registers of one chunk of one operand: 128 rows x 32 k floats, sixteen per thread
 struct GbRegs {
-    float4 v[4];
+    float f[16];
 };
 
-// KCONT: contiguous along k in memory: thread t -> row = t / 8 + 32 j, k = (t % 8) * 4 .. + 3
-// else (contiguous along the row index): thread t -> rows (t % 32) * 4 .. + 3, k rows 2 (t / 32) + {0, 1} + 16 j'
+// KCONT (contiguous along k in memory): thread t -> row = t / 8 + 32 j, k = (t % 8) * 4 .. + 3  (one float4 per j)
+// else (contiguous along the row index): item j of a thread is ONE row and one k pair (2 kp, 2 kp + 1):
+//   half-wave hw = t / 32 (0..7), r8 = t % 8, q4 = (t / 8) % 4;  row = 8 (hw + 8 (j & 1)) + r8,  kp = 4 (j >> 1) + q4
+// so that a half-wave's packed 32-bit LDS stores cover 8 consecutive rows x 4 consecutive words: with the 80-byte row
+// stride those are 32 different banks (rows r and r + 8 would collide), and the two halves of a wave read 16
+// consecutive rows = one 64-byte segment per k row from memory.
 template <bool KCONT>
 __device__ __forceinline__ void gb_load(GbRegs &r, const GbView &g, int row0, int nrows, long k0, long kend, bool vec)
 {
     const int t = threadIdx.x;
+    if (KCONT) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (KCONT) {
+        for (int j = 0; j < 4; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int row = t / 8 + 32 * j;
             const long k = k0 + (t % 8) * 4;
             if (row < nrows && k < kend) {
@@ -68,16 +72,22 @@ __device__ __forceinline__ void gb_load(GbRegs &r, const GbView &g, int row0, in
                 if (vec && k + 3 < kend) v = *reinterpret_cast<const float4 *>(p);
                 else { v.x = p[0]; if (k + 1 < kend) v.y = p[1]; if (k + 2 < kend) v.z = p[2]; if (k + 3 < kend) v.w = p[3]; }
             }
-        } else {
-            const int krow = 2 * (t / 32) + (j & 1) + 16 * (j >> 1), row = (t % 32) * 4;
-            const long k = k0 + krow;
-            if (k < kend && row < nrows) {
-                const float *p = g.base + k * g.sk + (row0 + row);
-                if (vec && row + 3 < nrows) v = *reinterpret_cast<const float4 *>(p);
-                else { v.x = p[0]; if (row + 1 < nrows) v.y = p[1]; if (row + 2 < nrows) v.z = p[2]; if (row + 3 < nrows) v.w = p[3]; }
-            }
+            r.f[4 * j] = v.x; r.f[4 * j + 1] = v.y; r.f[4 * j + 2] = v.z; r.f[4 * j + 3] = v.w;
         }
-        r.v[j] = v;
+    } else {
+        const int hw = t >> 5, r8 = t & 7, q4 = (t >> 3) & 3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = 8 * (hw + 8 * (j & 1)) + r8;
+            const long k = k0 + 2 * (4 * (j >> 1) + q4);
+            float a = 0.f, b = 0.f;
+            if (row < nrows) {
+                const float *p = g.base + k * g.sk + (row0 + row);
+                if (k < kend) a = p[0];
+                if (k + 1 < kend) b = p[g.sk];
+            }
+            r.f[2 * j] = a; r.f[2 * j + 1] = b;
+        }
     }
 }
 
@@ -90,19 +100,16 @@ __device__ __forceinline__ void gb_store(const GbRegs &r, unsigned short *lds)
         for (int j = 0; j < 4; ++j) {
             const int row = t / 8 + 32 * j, kk = (t % 8) * 4;
             uint2 w;
-            w.x = gb_pack(r.v[j].x, r.v[j].y);
-            w.y = gb_pack(r.v[j].z, r.v[j].w);
+            w.x = gb_pack(r.f[4 * j], r.f[4 * j + 1]);
+            w.y = gb_pack(r.f[4 * j + 2], r.f[4 * j + 3]);
             *reinterpret_cast<uint2 *>(lds + row * GB_S + kk) = w;
         }
     } else {
+        const int hw = t >> 5, r8 = t & 7, q4 = (t >> 3) & 3;
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {  // k rows (2q, 2q + 1) + 16 jj of rows row .. row + 3
-            const int kk = 2 * (t / 32) + 16 * jj, row = (t % 32) * 4;
-            const float4 a = r.v[2 * jj], b = r.v[2 * jj + 1];
-            *reinterpret_cast<unsigned *>(lds + (row + 0) * GB_S + kk) = gb_pack(a.x, b.x);
-            *reinterpret_cast<unsigned *>(lds + (row + 1) * GB_S + kk) = gb_pack(a.y, b.y);
-            *reinterpret_cast<unsigned *>(lds + (row + 2) * GB_S + kk) = gb_pack(a.z, b.z);
-            *reinterpret_cast<unsigned *>(lds + (row + 3) * GB_S + kk) = gb_pack(a.w, b.w);
+        for (int j = 0; j < 8; ++j) {
+            const int row = 8 * (hw + 8 * (j & 1)) + r8, kk = 2 * (4 * (j >> 1) + q4);
+            *reinterpret_cast<unsigned *>(lds + row * GB_S + kk) = gb_pack(r.f[2 * j], r.f[2 * j + 1]);
         }
     }
 }

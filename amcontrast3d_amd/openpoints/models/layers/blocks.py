@@ -145,7 +145,7 @@ def conv1x1(conv, x):
             and all(k == 1 for k in conv.kernel_size) and all(v == 1 for v in conv.stride)
             and all(v == 0 for v in conv.padding) and x.dim() == conv.weight.dim()):
         from amcontrast3d_amd.ops import mixed_precision
-        if mixed_precision():
+        if mixed_precision() and _bf16_pays(conv, x):
             # use_amp (main_AA.py:389-394): bf16 operands, fp32 accumulation on the bf16 MFMA; activations, BatchNorm,
             # searches and the loss stay fp32 (tensors are never stored in bf16)
             from amcontrast3d_amd.ops import pointwise_conv
@@ -160,6 +160,13 @@ def conv1x1(conv, x):
             from amcontrast3d_amd.ops import library_gemm_conv
             return library_gemm_conv(x, conv.weight)
     return conv(x)
+
+
+def _bf16_pays(conv, x):
+    """Under autocast the 1x1 convs with >= 64 channels on both sides over >= 4096 positions run on the bf16 MFMA
+    (scratch/gemm_bench.py: 1.2-2x the fp32 kernels there).  Narrower layers are HBM-bound and shorter ones fill a fraction
+    of the chip with 128 x 128 tiles: both keep their fp32 route, which is at least as accurate as what autocast asks for."""
+    return min(conv.in_channels, conv.out_channels) >= 64 and x.numel() // x.shape[1] >= 4096
 
 
 def _pw_pays(conv, x):

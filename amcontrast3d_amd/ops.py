@@ -822,7 +822,7 @@ class LocalAggregationFused(Function):
         wb = int(lib.amc3d_local_aggregation_workspace_bytes(B, C, N, M))
         work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
         mom, rm, rv, nbt = _bn_running_args(bn)
-        ctx.bf16 = mixed_precision()  # the conv on the source points in bf16 compute under autocast; the rest is fp32
+        ctx.bf16 = mixed_precision() and min(Cin, C) >= 64 and B * N >= 4096  # the conv on the source points on the bf16 MFMA
         with torch.cuda.device(dev):
             with timing.span("pointwise_conv_forward", 4 * B * N * (Cin + C), 2.0 * B * N * Cin * C):
                 _lib.check(_pw(lib, ctx.bf16)[0](B, Cin, C, N, _ptr(f), _ptr(w_f), None, _ptr(g_cm), _stream(f)),

@@ -60,8 +60,11 @@ def parse():
                     help="AMContrast3D++ (BaseSeg_M_AMContrast3D + CrossEntropyAcePre) instead of AMContrast3D")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--fps-lanes", type=int, default=2,
-                    help="first-level FPS chains in flight (each for a different future batch; one launch per step)")
+    ap.add_argument("--fps-lanes", type=int, default=0,
+                    help="first-level FPS chains in flight (each for a different future batch; one launch per step).  0 = "
+                         "choose: 2 where the chain is shorter than the feature half (24k-point clouds), else enough lanes, "
+                         "each on a hardware queue of its own, that chains / lanes stays below it (64k / 120k-point clouds "
+                         "in small batches: a chain of 16000-30000 dependent iterations on ONE workgroup per cloud)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="compute each batch's geometry inline instead of one step ahead on a side stream")
     ap.add_argument("--sync-bn", action="store_true", help="(default at N > 1; kept for older command lines)")
@@ -359,7 +362,27 @@ def main():
     main_s = torch.cuda.Stream(priority=prio[0])  # all work of this process runs on non-default streams (capture recipe)
     main_s.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(main_s)
-    lanes = max(1, args.fps_lanes)
+    lanes = args.fps_lanes
+    if lanes <= 0:  # measure one first-level FPS and one eager feature step
+        def _ms(fn, reps):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / reps
+        t_fps = _ms(lambda: geometry.precompute_fps_levels(model, data["pos"], 0, 2), 1)
+        plan0 = geometry.precompute(model, criterion.contrast_head, data, 13, None, aargs)
+        data["_geometry"] = plan0
+        t_feat = _ms(fwd_bwd, 2)  # eager: an upper bound of the captured feature half
+        data.pop("_geometry")
+        del plan0
+        if flatg is None:
+            opt.zero_grad(set_to_none=True)
+        lanes = 2 if t_fps <= 1.2 * t_feat else int(min(6, max(2, -(-t_fps // max(0.6 * t_feat, 1e-3)))))
+    lanes = max(1, lanes)
     # Hardware queues.  Ordinary HIP streams of a process share GPU_MAX_HW_QUEUES (default 4) queues round-robin, and
     # whatever shares a queue with a running FPS kernel (8 ms on 8 workgroups) waits for it; which stream that is
     # changes with every stream anybody creates (graph-internal branches, RCCL).  So the two long-latency chains get
@@ -367,7 +390,8 @@ def main():
     #   Q_fps : the first-level FPS of both lanes (one launch per step, 8 ms each)
     #   Q_geo : FPS levels 2-4, then the neighbourhood / loss geometry of the same batch
     from amcontrast3d_amd import ops as _ops
-    qplan = os.environ.get("AMC3D_QUEUES", "fps,geo")  # others, for scratch/queue_sweep.sh: "pooled", "fps,a2,b", ...
+    # others, for scratch/queue_sweep.sh: "pooled", "fps,a2,b", ...; more than two lanes: a queue per lane (they must overlap)
+    qplan = os.environ.get("AMC3D_QUEUES", "fps,geo" if lanes <= 2 else ",".join([f"fps{l}" for l in range(lanes)] + ["geo"]))
     if (not use_graph and "AMC3D_QUEUES" not in os.environ) or qplan == "probed":
         # launched kernel by kernel, dedicated queues lose the overlap (pipeline.py): two pooled streams probed to sit
         # on hardware queues of their own, as the eager GeometryPrefetcher uses them
