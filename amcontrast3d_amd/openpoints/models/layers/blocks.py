@@ -159,6 +159,8 @@ def conv1x1(conv, x):
             # whose weight gradient is wrapped in layout transposes (scratch/pw_bench3.py: 30-50 us per layer)
             from amcontrast3d_amd.ops import library_gemm_conv
             return library_gemm_conv(x, conv.weight)
+        with torch.autocast("cuda", enabled=False):  # small leftovers: the torch module in fp32 (tensors stay fp32)
+            return conv(x)
     return conv(x)
 
 

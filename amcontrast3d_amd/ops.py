@@ -985,8 +985,10 @@ class LibraryGemmConv(Function):
         w2 = weight.reshape(Cout, Cin)
         timing.note("library_gemm_conv")
         # bmm with the weight expanded along the batch (stride 0): torch.matmul(2-d, 3-d) would fold the batch into one
-        # GEMM by way of a transposed copy of x
-        y = torch.bmm(w2.unsqueeze(0).expand(B, Cout, Cin), x.view(B, Cin, -1))
+        # GEMM by way of a transposed copy of x.  (Under autocast this fp32 route is chosen for layers where bf16 does
+        # not pay: keep the library GEMM in fp32, tensors stay fp32.)
+        with torch.autocast("cuda", enabled=False):
+            y = torch.bmm(w2.unsqueeze(0).expand(B, Cout, Cin), x.view(B, Cin, -1))
         ctx.save_for_backward(x, w2)
         ctx.wshape = tuple(weight.shape)
         return y.view((B, Cout) + tuple(x.shape[2:]))
@@ -996,9 +998,10 @@ class LibraryGemmConv(Function):
         x, w2 = ctx.saved_tensors
         B, Cin = x.shape[0], x.shape[1]
         dy3 = dy.contiguous().view(B, w2.shape[0], -1)
-        dx = (torch.bmm(w2.t().unsqueeze(0).expand(B, Cin, w2.shape[0]), dy3).view(x.shape)
-              if ctx.needs_input_grad[0] else None)
-        dw = _library_wgrad(dy3, x.view(B, Cin, -1)).view(ctx.wshape) if ctx.needs_input_grad[1] else None
+        with torch.autocast("cuda", enabled=False):
+            dx = (torch.bmm(w2.t().unsqueeze(0).expand(B, Cin, w2.shape[0]), dy3).view(x.shape)
+                  if ctx.needs_input_grad[0] else None)
+            dw = _library_wgrad(dy3, x.view(B, Cin, -1)).view(ctx.wshape) if ctx.needs_input_grad[1] else None
         return dx, dw
 
 
