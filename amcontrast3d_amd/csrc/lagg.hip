@@ -452,6 +452,173 @@ __global__ __launch_bounds__(256) void lagg_bwd_apply_kernel(int C, int n, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// First layer of a multi-layer SetAbstraction MLP (PointNeXt-S: sa_layers = 2): the same convolve-before-gather
+// conv + BatchNorm + ReLU, but the activation x1 (B,C,M,K) is materialised for the layers that follow
+//   expand    x1[b,c,m,k] = [relu](bn(G[b, idx[b,m,k], c] + W_dp[c] . dp[b,:,m,k]))       one gather pass, one write
+//   collapse  from dx1 (B,C,M,K): d = dx1 * [relu mask], scattered into Q[b, idx, c] (row-contiguous float atomics, zeros
+//             skipped) + the per-channel sums {sum d, sum d xhat, sum d dp_j}: BatchNorm's backward then needs nothing
+//             else of size M*K (lagg_bwd_finalize / lagg_bwd_apply turn Q into dG on the N source points).
+// One pass over dx1 replaces BN-backward statistics, BN-backward apply, the conv's backward-data product + scatter and
+// its backward-weight product.  grid (position-tile groups, channel chunks of 64, b); a tile = 128 positions.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int LAGG_PT = 128;  // positions per tile
+constexpr int LAGG_XC = 64;   // channels per workgroup
+
+template <int LPR>
+__global__ __launch_bounds__(256) void lagg_expand_kernel(int C, int n, long P, int relu, const float *__restrict__ g_pm,
+                                                          const int *__restrict__ idx, const float *__restrict__ dp,
+                                                          const float *__restrict__ w_dp, const float *__restrict__ mean,
+                                                          const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float *__restrict__ x1)
+{
+    __shared__ float tile[LAGG_XC][LAGG_PT + 1];  // odd stride: the (channel quad, position) writes are at most 2-way
+    const int b = blockIdx.z, c0 = blockIdx.y * LAGG_XC;
+    const int ct = min(LAGG_XC, C - c0);
+    const long p0 = (long)blockIdx.x * LAGG_PT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int rpi = 64 / LPR;
+    const int q = lane % LPR, r = lane / LPR;
+    const int cq = c0 + 4 * q;
+    float w[4][3], mu[4], is[4], ga[4], be[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = cq + j;
+        w[j][0] = w_dp[c * 3 + 0]; w[j][1] = w_dp[c * 3 + 1]; w[j][2] = w_dp[c * 3 + 2];
+        mu[j] = mean[c]; is[j] = invstd[c]; ga[j] = gamma[c]; be[j] = beta[c];
+    }
+    // this wave's 32 positions: lane l < 32 fetches index and dp of position wave*32 + l
+    const long pw = p0 + wave * 32;
+    int id_l = 0;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    if (lane < 32 && pw + lane < P) {
+        id_l = idx[(size_t)b * P + pw + lane];
+        d0 = dp[((size_t)b * 3 + 0) * P + pw + lane]; d1 = dp[((size_t)b * 3 + 1) * P + pw + lane]; d2 = dp[((size_t)b * 3 + 2) * P + pw + lane];
+    }
+#pragma unroll
+    for (int k0 = 0; k0 < 32; k0 += rpi) {
+        const int k = k0 + r;
+        const int id = __shfl(id_l, k, 64);
+        const float e0 = __shfl(d0, k, 64), e1 = __shfl(d1, k, 64), e2 = __shfl(d2, k, 64);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pw + k < P) g = *reinterpret_cast<const float4 *>(g_pm + ((size_t)b * n + id) * C + cq);
+        const float gs[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float y = __fmaf_rn(w[j][0], e0, __fmaf_rn(w[j][1], e1, __fmaf_rn(w[j][2], e2, gs[j])));
+            float v = lagg_bn(y, mu[j], is[j], ga[j], be[j]);
+            if (relu) v = fmaxf(v, 0.f);
+            tile[4 * q + j][wave * 32 + k] = v;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < ct * LAGG_PT; t += 256) {  // a wave stores 256 contiguous bytes of one channel row
+        const int cl = t / LAGG_PT, pp = t - cl * LAGG_PT;
+        if (p0 + pp < P) x1[((size_t)b * C + c0 + cl) * P + p0 + pp] = tile[cl][pp];
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void lagg_collapse_kernel(int C, int n, long P, int relu, const float *__restrict__ dx1,
+                                                            const float *__restrict__ g_pm, const int *__restrict__ idx,
+                                                            const float *__restrict__ dp, const float *__restrict__ w_dp,
+                                                            const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            float *__restrict__ Q, double *__restrict__ partial, int nparts_per_b)
+{
+    __shared__ float tile[LAGG_XC][LAGG_PT + 1];
+    __shared__ double red[4][LAGG_XC][5];
+    constexpr int rpi = 64 / LPR, CT = 4 * LPR;  // channels of this workgroup's chunk
+    const int b = blockIdx.z, c0 = blockIdx.y * LAGG_XC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane % LPR, r = lane / LPR;
+    const int cq = c0 + 4 * q;
+    float w[4][3], mu[4], is[4], ga[4], be[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = cq + j;
+        w[j][0] = w_dp[c * 3 + 0]; w[j][1] = w_dp[c * 3 + 1]; w[j][2] = w_dp[c * 3 + 2];
+        mu[j] = mean[c]; is[j] = invstd[c]; ga[j] = gamma[c]; be[j] = beta[c];
+    }
+    double acc[4][5];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int v = 0; v < 5; ++v) acc[j][v] = 0.0;
+    for (int tt = 0; tt < LAGG_TILES; ++tt) {
+        const long p0 = ((long)blockIdx.x * LAGG_TILES + tt) * LAGG_PT;
+        if (p0 >= P) break;
+        __syncthreads();
+        for (int t = threadIdx.x; t < CT * LAGG_PT; t += 256) {
+            const int cl = t / LAGG_PT, pp = t - cl * LAGG_PT;
+            tile[cl][pp] = (p0 + pp < P) ? dx1[((size_t)b * C + c0 + cl) * P + p0 + pp] : 0.f;
+        }
+        __syncthreads();
+        const long pw = p0 + wave * 32;
+        int id_l = 0;
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+        if (lane < 32 && pw + lane < P) {
+            id_l = idx[(size_t)b * P + pw + lane];
+            d0 = dp[((size_t)b * 3 + 0) * P + pw + lane]; d1 = dp[((size_t)b * 3 + 1) * P + pw + lane]; d2 = dp[((size_t)b * 3 + 2) * P + pw + lane];
+        }
+        // phase A: 16-byte gathers of the G rows; mask the ReLU, accumulate the sums, leave the masked gradient in the tile
+#pragma unroll
+        for (int k0 = 0; k0 < 32; k0 += rpi) {
+            const int k = k0 + r;
+            const int id = __shfl(id_l, k, 64);
+            const float e0 = __shfl(d0, k, 64), e1 = __shfl(d1, k, 64), e2 = __shfl(d2, k, 64);
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pw + k < P) g = *reinterpret_cast<const float4 *>(g_pm + ((size_t)b * n + id) * C + cq);
+            const float gs[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float y = __fmaf_rn(w[j][0], e0, __fmaf_rn(w[j][1], e1, __fmaf_rn(w[j][2], e2, gs[j])));
+                const float xh = __fmul_rn(__fsub_rn(y, mu[j]), is[j]);
+                float d = tile[4 * q + j][wave * 32 + k];
+                if (relu && !(__fadd_rn(__fmul_rn(xh, ga[j]), be[j]) > 0.f)) d = 0.f;
+                tile[4 * q + j][wave * 32 + k] = d;  // (this lane is the only reader and writer of the element)
+                const double dd = d;
+                acc[j][0] += dd; acc[j][1] += dd * (double)xh;
+                acc[j][2] += dd * (double)e0; acc[j][3] += dd * (double)e1; acc[j][4] += dd * (double)e2;
+            }
+        }
+        // phase B: scatter with one lane per channel: a wave-instruction adds 64 / CT whole rows of CT contiguous floats
+        // (each wave reads back only what it wrote itself: its own 32 positions)
+        constexpr int ppi = 64 / CT > 0 ? 64 / CT : 1;  // positions per instruction
+        const int cl = lane % CT, sub = lane / CT;
+        for (int k0 = 0; k0 < 32; k0 += ppi) {
+            const int k = k0 + sub;
+            const int id = __shfl(id_l, k & 31, 64);
+            if (sub < ppi && pw + k < P) {
+                const float d = tile[cl][wave * 32 + k];
+                if (d != 0.f) atomicAdd(Q + ((size_t)b * n + id) * C + c0 + cl, d);
+            }
+        }
+    }
+    // combine the row slots (lanes q, q + LPR, ...), then the four waves
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+            double x = acc[j][v];
+#pragma unroll
+            for (int s = LPR; s < 64; s <<= 1) x += __shfl_xor(x, s, 64);
+            acc[j][v] = x;
+        }
+    if (r == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int v = 0; v < 5; ++v) red[wave][4 * q + j][v] = acc[j][v];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < CT * 5; t += 256) {
+        const int cl2 = t / 5, v = t - cl2 * 5;
+        partial[(((size_t)b * nparts_per_b + blockIdx.x) * C + c0 + cl2) * 5 + v] =
+            (red[0][cl2][v] + red[1][cl2][v]) + (red[2][cl2][v] + red[3][cl2][v]);
+    }
+}
+
 static bool lagg_supported(int C, int K)
 {
     if (C < 8 || C % 4 || K < 1 || K > 64) return false;
@@ -463,7 +630,19 @@ static bool lagg_supported(int C, int K)
 static size_t lagg_partial_bytes(int b, int C, int n, int M)
 {
     const size_t pf = (size_t)b * div_up(div_up(n, LAGG_NT), LAGG_TILES), pb = (size_t)b * div_up(div_up(M, LAGG_MT), LAGG_TILES);
-    return (pf > pb ? pf : pb) * C * 5 * sizeof(double);
+    const size_t pc = (size_t)b * div_up(div_up((long)M * 32, LAGG_PT), LAGG_TILES);  // collapse kernel (K = 32)
+    size_t m = pf > pb ? pf : pb;
+    if (pc > m) m = pc;
+    return m * C * 5 * sizeof(double);
+}
+
+// the materialising first layer: K = 32, channel chunks of 64 (or the whole of C in {8, 16, 32})
+static bool lagg_expand_supported(int C, int K)
+{
+    if (K != 32 || C < 8 || C % 4) return false;
+    const int ct = C < LAGG_XC ? C : LAGG_XC;
+    const int lpr = ct / 4;
+    return (lpr & (lpr - 1)) == 0 && C % ct == 0;
 }
 
 }  // namespace amc
@@ -571,4 +750,78 @@ AMC_API int amc3d_local_aggregation_backward(int b, int cout, int n, int npoints
     hipLaunchKernelGGL(lagg_bwd_apply_kernel, dim3(div_up(n, LAGG_NT), div_up(cout, 64), b), dim3(256), 0, stream, cout, n,
                        (const float *)Q, g_pm, gm, w_dp, (const float *)coef, dg_cm);
     return launch_status("amc3d_local_aggregation_backward");
+}
+
+// ---- first layer of a multi-layer SetAbstraction MLP: conv (before the gather) + BatchNorm + ReLU, x1 materialised ----
+AMC_API int amc3d_grouped_conv_bn_supported(int cout, int nsample) { return lagg_expand_supported(cout, nsample) ? 1 : 0; }
+
+// x1 (b,cout,npoints,32) = [relu](bn(G[idx] + W_dp . dp)); other arguments as amc3d_local_aggregation_forward
+AMC_API int amc3d_grouped_conv_bn_forward(int b, int cout, int n, int npoints, int nsample, int training, int relu, float eps,
+                                          float momentum, const float *g_cm, const int *idx, const float *dp, const float *w_dp,
+                                          const void *moments, const float *gamma, const float *beta, float *g_pm, float *x1,
+                                          float *mean, float *invstd, float *var_unbiased, double *gd, float *running_mean,
+                                          float *running_var, long long *num_batches_tracked, void *workspace,
+                                          size_t workspace_bytes, void *stream_)
+{
+    if (b <= 0 || npoints <= 0) return 0;
+    if (!lagg_expand_supported(cout, nsample) || n <= 0 || !g_cm || !idx || !dp || !w_dp || !gamma || !beta || !g_pm || !x1 ||
+        !mean || !invstd || (training && (!moments || !var_unbiased || !gd || !workspace ||
+        workspace_bytes < amc3d_local_aggregation_workspace_bytes(b, cout, n, npoints))) ||
+        (running_mean && (!running_var || !num_batches_tracked)))
+        return bad_arg("amc3d_grouped_conv_bn_forward: unsupported shape, null pointer or workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    LaggMoments gm{};
+    if (moments) gm = lagg_views(moments, b, n);
+    const int nparts_b = div_up(div_up(n, LAGG_NT), LAGG_TILES);
+    if (training) {
+        hipLaunchKernelGGL(lagg_stats_kernel, dim3(nparts_b, div_up(cout, 64), b), dim3(256), 0, stream, cout, n, g_cm, g_pm, gm,
+                           (double *)workspace, nparts_b);
+        hipLaunchKernelGGL(lagg_stats_finalize_kernel, dim3(cout), dim3(256), 0, stream, cout, nparts_b * b,
+                           (double)b * (double)npoints * (double)nsample, eps, momentum, (const double *)workspace, gm.mom, w_dp,
+                           mean, invstd, var_unbiased, gd, running_mean, running_var, num_batches_tracked);
+    } else if (int st = amc3d_transpose_cn(b, cout, n, g_cm, g_pm, stream_)) {
+        return st;
+    }
+    const long P = (long)npoints * nsample;
+    const int ct = cout < LAGG_XC ? cout : LAGG_XC;
+#define AMC_EXPAND(L)                                                                                                          \
+    hipLaunchKernelGGL(lagg_expand_kernel<L>, dim3(div_up(P, LAGG_PT), cout / ct, b), dim3(256), 0, stream, cout, n, P, relu, \
+                       (const float *)g_pm, idx, dp, w_dp, (const float *)mean, (const float *)invstd, gamma, beta, x1)
+    switch (ct / 4) { case 2: AMC_EXPAND(2); break; case 4: AMC_EXPAND(4); break; case 8: AMC_EXPAND(8); break; default: AMC_EXPAND(16); }
+#undef AMC_EXPAND
+    return launch_status("amc3d_grouped_conv_bn_forward");
+}
+
+// from dx1 (b,cout,npoints,32): dg_cm (b,cout,n), dw_dp (cout,3), dgamma, dbeta
+AMC_API int amc3d_grouped_conv_bn_backward(int b, int cout, int n, int npoints, int nsample, int relu, const float *dx1,
+                                           const float *g_pm, const int *idx, const float *dp, const float *w_dp,
+                                           const void *moments, const double *gd, const float *mean, const float *invstd,
+                                           const float *gamma, const float *beta, float *dg_cm, float *dw_dp, float *dgamma,
+                                           float *dbeta, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    if (b <= 0 || npoints <= 0) return 0;
+    if (!lagg_expand_supported(cout, nsample) || n <= 0 || !dx1 || !g_pm || !idx || !dp || !w_dp || !moments || !gd || !mean ||
+        !invstd || !gamma || !beta || !dg_cm || !dw_dp || !dgamma || !dbeta || !workspace ||
+        workspace_bytes < amc3d_local_aggregation_workspace_bytes(b, cout, n, npoints))
+        return bad_arg("amc3d_grouped_conv_bn_backward: unsupported shape, null pointer or workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    const LaggMoments gm = lagg_views(moments, b, n);
+    double *partial = (double *)workspace;
+    float *Q = (float *)((char *)workspace + lagg_partial_bytes(b, cout, n, npoints));
+    float *coef = Q + (size_t)b * n * cout;
+    if (int st = fill_i32((int *)Q, 0, (size_t)b * n * cout, stream)) return st;
+    const long P = (long)npoints * nsample;
+    const int ct = cout < LAGG_XC ? cout : LAGG_XC;
+    const int nparts_b = div_up(div_up(P, LAGG_PT), LAGG_TILES);
+#define AMC_COLLAPSE(L)                                                                                                        \
+    hipLaunchKernelGGL(lagg_collapse_kernel<L>, dim3(nparts_b, cout / ct, b), dim3(256), 0, stream, cout, n, P, relu, dx1, g_pm,  \
+                       idx, dp, w_dp, mean, invstd, gamma, beta, Q, partial, nparts_b)
+    switch (ct / 4) { case 2: AMC_COLLAPSE(2); break; case 4: AMC_COLLAPSE(4); break; case 8: AMC_COLLAPSE(8); break; default: AMC_COLLAPSE(16); }
+#undef AMC_COLLAPSE
+    hipLaunchKernelGGL(lagg_bwd_finalize_kernel, dim3(cout), dim3(256), 0, stream, cout, nparts_b * b,
+                       (double)b * (double)npoints * (double)nsample, (const double *)partial, gm.mom, gd, w_dp, mean, invstd,
+                       gamma, dgamma, dbeta, dw_dp, coef);
+    hipLaunchKernelGGL(lagg_bwd_apply_kernel, dim3(div_up(n, LAGG_NT), div_up(cout, 64), b), dim3(256), 0, stream, cout, n,
+                       (const float *)Q, g_pm, gm, w_dp, (const float *)coef, dg_cm);
+    return launch_status("amc3d_grouped_conv_bn_backward");
 }

@@ -20,14 +20,15 @@ import torch
 import torch.nn as nn
 
 from ..layers import (CHANNEL_MAP, create_act, create_convblock1d, create_convblock2d, create_grouper,
-                      furthest_point_sample, fused_first_conv, fused_local_aggregation, get_aggregation_feautres,
+                      furthest_point_sample, fused_first_block, fused_first_conv, fused_local_aggregation,
+                      get_aggregation_feautres,
                       random_sample, run_convblocks,
                       three_interpolate, three_nn)
 
 
 def _moments(convs, feature_type, idx, dp, n_support):
-    """geometry moments for a single-conv neighbourhood layer (the convolve-before-gather kernels need them), else None"""
-    if len(convs) != 1 or feature_type != 'dp_fj' or not idx.is_cuda:
+    """geometry moments of a neighbourhood layer (the convolve-before-gather kernels need them), else None"""
+    if feature_type != 'dp_fj' or not idx.is_cuda or len(convs) < 1:
         return None
     from amcontrast3d_amd import ops
     return ops.group_moments(idx, dp, n_support)
@@ -168,9 +169,12 @@ class SetAbstraction(nn.Module):
             if self.use_res:
                 identity = run_convblocks((self.skipconv,), fi)
         fused = fused_local_aggregation(self.convs, f, geom, self.feature_type)
-        pre = fused_first_conv(self.convs, f, geom, self.feature_type) if fused is None else None
+        x1 = fused_first_block(self.convs, f, geom, self.feature_type) if fused is None else None
+        pre = fused_first_conv(self.convs, f, geom, self.feature_type) if (fused is None and x1 is None) else None
         if fused is not None:  # single conv layer: conv on the source points, then gather + BN + ReLU + max in one pass
             f = fused
+        elif x1 is not None:   # two-layer MLP: first conv + BN + ReLU on the source points / one gather pass, then the rest
+            f = run_convblocks(list(self.convs)[1:], x1, pool_max=True, activated=True)
         elif pre is not None:  # gather + concat + first conv in one MFMA kernel
             f = run_convblocks(self.convs, None, pool_max=True, pre=pre)
         else:

@@ -182,17 +182,18 @@ def _pw_pays(conv, x):
     return positions >= 131072 and max(cin, cout) <= 128 or (max(cin, cout) <= 64 and positions >= 32768)
 
 
-def run_convblocks(blocks, x, pool_max=False, pre=None):
+def run_convblocks(blocks, x, pool_max=False, pre=None, activated=False):
     """Evaluate a stack of conv blocks (the nn.Sequential the factories above build), optionally followed by
     the max over the last (neighbour) dimension.  Where a block is conv -> plain BatchNorm [-> ReLU] in
     training mode, BatchNorm statistics, normalisation, ReLU and (for the last block) the max-pool run as
     fused gfx950 kernels (amcontrast3d_amd/csrc/bn.hip); everything else runs the stored modules as they are.
     Parameters, buffers and their bookkeeping stay those of the nn modules.
-    `pre`: the already computed output of the first block's convolution (the fused gather+conv kernel)."""
+    `pre`: the already computed output of the first block's convolution (the fused gather+conv kernel).
+    `activated`: x is the activated output of a first block evaluated elsewhere (fused_first_block); `blocks` are the rest."""
     from amcontrast3d_amd.ops import BatchNormAct, BatchNormMax, SyncBatchNormFused
     mods = list(blocks)
     pooled = False
-    fused = _sa_tail(mods, pool_max, pre)
+    fused = _sa_tail_activated(mods, x, pool_max) if activated else _sa_tail(mods, pool_max, pre)
     if fused is not None:
         return fused
     for bi, blk in enumerate(mods):
@@ -288,6 +289,53 @@ def fused_local_aggregation(blocks, f, geom, feature_type):
     if not _fusable_bn(bn, f):
         return None
     return ops.LocalAggregationFused.apply(f, geom['dp'], idx, geom['mom'], conv.weight, bn.weight, bn.bias, bn.eps, relu, bn)
+
+
+def fused_first_block(blocks, f, geom, feature_type):
+    """First block -- Conv2d 1x1 -> BatchNorm2d -> ReLU -- of a multi-layer neighbourhood MLP (PointNeXt-S'
+    SetAbstraction, sa_layers = 2) convolved before the gather, its ACTIVATED output x1 (B,C,M,32) materialised for the
+    blocks that follow (ops.GroupedConvBN), or None when the stack is not of that form."""
+    from amcontrast3d_amd import ops
+    import os
+    if (feature_type != 'dp_fj' or geom is None or 'idx' not in geom or geom.get('mom') is None or f is None or not f.is_cuda
+            or f.dtype != torch.float32 or len(blocks) < 2 or os.environ.get("AMC3D_NO_LOCAL_AGGREGATION")):
+        return None
+    blk = blocks[0]
+    if (not isinstance(blk, nn.Sequential) or len(blk) != 3 or not isinstance(blk[0], nn.Conv2d)
+            or not isinstance(blk[1], nn.modules.batchnorm._BatchNorm) or type(blk[2]) is not nn.ReLU):
+        return None
+    conv, bn = blk[0], blk[1]
+    idx = geom['idx']
+    if (conv.bias is not None or conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.groups != 1
+            or any(v != 0 for v in conv.padding) or conv.in_channels != f.shape[1] + 3
+            or not ops.grouped_conv_bn_supported(conv.out_channels, idx.shape[-1])):
+        return None
+    if _eval_bn(bn, f):
+        return ops.grouped_conv_bn_eval(f, geom['dp'], idx, conv.weight, bn, True)
+    if not _fusable_bn(bn, f):
+        return None
+    return ops.GroupedConvBN.apply(f, geom['dp'], idx, geom['mom'], conv.weight, bn.weight, bn.bias, bn.eps, True, bn)
+
+
+def _sa_tail_activated(mods, x1, pool_max):
+    """[1x1 conv, BN (, ReLU)] -> max over 32 neighbours on the activated first-layer output x1, as the recomputing
+    kernel family of csrc/sa_tail.hip (ops.SATailActivated), or None"""
+    import os
+    if not pool_max or len(mods) != 1 or x1.dim() != 4 or os.environ.get("AMC3D_NO_SA_TAIL"):
+        return None
+    s1 = list(mods[0]) if isinstance(mods[0], nn.Sequential) else None
+    if (s1 is None or len(s1) not in (2, 3) or (len(s1) == 3 and type(s1[2]) is not nn.ReLU) or not isinstance(s1[0], nn.Conv2d)
+            or not isinstance(s1[1], nn.modules.batchnorm._BatchNorm)):
+        return None
+    conv2, bn2 = s1[0], s1[1]
+    if (not _fusable_bn(bn2, x1) or conv2.bias is not None or conv2.kernel_size != (1, 1) or conv2.stride != (1, 1)
+            or conv2.groups != 1 or any(v != 0 for v in conv2.padding) or conv2.in_channels != x1.shape[1]):
+        return None
+    from amcontrast3d_amd import ops
+    if not (ops.sa_tail_supported(x1.shape[1], conv2.out_channels, x1.shape[-1])
+            and ops.sa_tail_pays(x1.shape[1], conv2.out_channels)):
+        return None
+    return ops.SATailActivated.apply(x1, conv2.weight, bn2.weight, bn2.bias, bn2.eps, len(s1) == 3, bn2)
 
 
 def fused_first_conv(blocks, f, geom, feature_type):

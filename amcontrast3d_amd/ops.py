@@ -875,6 +875,114 @@ class LocalAggregationFused(Function):
         return df, None, None, None, dw, dgamma, dbeta, None, None, None
 
 
+class GroupedConvBN(Function):
+    """x1 (B,C,M,32) = [relu](bn(conv1x1([dp ; f[idx]]))) -- the FIRST block of a multi-layer SetAbstraction MLP
+    (PointNeXt-S: sa_layers = 2; pointnext_AA.py:104-127, 164-166) convolved before the gather like LocalAggregationFused,
+    but with the activation materialised for the blocks that follow.  Backward: one pass over dx1 (csrc/lagg.hip
+    lagg_collapse_kernel) instead of BatchNorm-backward statistics + apply + the conv's two backward products."""
+
+    @staticmethod
+    def forward(ctx, f, dp, idx, moments, weight, gamma, beta, eps, relu, bn=None):
+        _need_gpu(f, dp, idx, moments, weight, gamma, beta)
+        _need_dtype(torch.float32, f=f, dp=dp, weight=weight)
+        _need_dtype(torch.int32, idx=idx)
+        f, dp, idx = f.contiguous(), dp.contiguous(), idx.contiguous()
+        B, Cin, N = f.shape
+        _, M, K = idx.shape
+        C = weight.shape[0]
+        assert weight.numel() == C * (Cin + 3)
+        dev = f.device
+        lib = _lib.load()
+        w2 = weight.reshape(C, Cin + 3)
+        w_dp, w_f = w2[:, :3].contiguous(), w2[:, 3:].contiguous()
+        g_cm = torch.empty(B, C, N, dtype=torch.float32, device=dev)
+        g_pm = torch.empty(B, N, C, dtype=torch.float32, device=dev)
+        x1 = torch.empty(B, C, M, K, dtype=torch.float32, device=dev)
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd, var_u = torch.empty_like(mean), torch.empty_like(mean)
+        gd = torch.empty(C, 3, dtype=torch.float64, device=dev)
+        wb = int(lib.amc3d_local_aggregation_workspace_bytes(B, C, N, M))
+        work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
+        mom, rm, rv, nbt = _bn_running_args(bn)
+        ctx.bf16 = mixed_precision() and min(Cin, C) >= 64 and B * N >= 4096
+        with torch.cuda.device(dev):
+            with timing.span("pointwise_conv_forward", 4 * B * N * (Cin + C), 2.0 * B * N * Cin * C):
+                _lib.check(_pw(lib, ctx.bf16)[0](B, Cin, C, N, _ptr(f), _ptr(w_f), None, _ptr(g_cm), _stream(f)),
+                           "pointwise_conv_forward")
+            with timing.span("grouped_conv_bn_forward", 8 * B * N * C + B * M * K * (8 * C + 16)):
+                _lib.check(lib.amc3d_grouped_conv_bn_forward(
+                    B, C, N, M, K, 1, int(bool(relu)), float(eps), mom, _ptr(g_cm), _ptr(idx), _ptr(dp), _ptr(w_dp),
+                    _ptr(moments), _ptr(gamma), _ptr(beta), _ptr(g_pm), _ptr(x1), _ptr(mean), _ptr(invstd), _ptr(var_u),
+                    _ptr(gd), rm, rv, nbt, _ptr(work), wb, _stream(f)), "grouped_conv_bn_forward")
+        if bn is not None and bn.track_running_stats and bn.running_mean is not None and bn.momentum is None:
+            bn_update_running(bn, mean, var_u)
+        ctx.save_for_backward(f, w_f, w_dp, g_pm, idx, dp, moments, gamma, beta, mean, invstd, gd)
+        ctx.relu, ctx.wshape = bool(relu), tuple(weight.shape)
+        return x1
+
+    @staticmethod
+    def backward(ctx, dx1):
+        f, w_f, w_dp, g_pm, idx, dp, moments, gamma, beta, mean, invstd, gd = ctx.saved_tensors
+        B, Cin, N = f.shape
+        _, M, K = idx.shape
+        C = w_f.shape[0]
+        dev = f.device
+        lib = _lib.load()
+        dx1 = dx1.contiguous()
+        dg_cm = torch.empty(B, C, N, dtype=torch.float32, device=dev)
+        dw_dp = torch.empty(C, 3, dtype=torch.float32, device=dev)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        wb = int(lib.amc3d_local_aggregation_workspace_bytes(B, C, N, M))
+        work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
+        need_f = ctx.needs_input_grad[0]
+        df = torch.empty_like(f) if need_f else None
+        dw_f = torch.empty(C, Cin, dtype=torch.float32, device=dev)
+        _, pw_wbytes, pw_bwd = _pw(lib, ctx.bf16)
+        wb2 = int(pw_wbytes(B, Cin, C, N))
+        work2 = torch.empty(max(wb2, 4), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            with timing.span("grouped_conv_bn_backward", B * M * K * (8 * C + 16) + 12 * B * N * C):
+                _lib.check(lib.amc3d_grouped_conv_bn_backward(
+                    B, C, N, M, K, int(ctx.relu), _ptr(dx1), _ptr(g_pm), _ptr(idx), _ptr(dp), _ptr(w_dp), _ptr(moments),
+                    _ptr(gd), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dg_cm), _ptr(dw_dp), _ptr(dgamma),
+                    _ptr(dbeta), _ptr(work), wb, _stream(f)), "grouped_conv_bn_backward")
+            with timing.span("pointwise_conv_backward", 4 * B * N * (Cin + C) * (1 + int(need_f)),
+                             2.0 * B * N * Cin * C * (1 + int(need_f))):
+                _lib.check(pw_bwd(B, Cin, C, N, _ptr(f), _ptr(w_f), _ptr(dg_cm), _ptr(df) if need_f else None, _ptr(dw_f),
+                                  _ptr(work2), wb2, _stream(f)), "pointwise_conv_backward")
+        dw = torch.cat((dw_dp, dw_f), dim=1).view(ctx.wshape)
+        return df, None, None, None, dw, dgamma, dbeta, None, None, None
+
+
+@torch.no_grad()
+def grouped_conv_bn_eval(f, dp, idx, weight, bn, relu):
+    """GroupedConvBN in inference mode (running statistics), no gradient -> x1 (B,C,M,32)"""
+    f, dp, idx = f.contiguous(), dp.contiguous(), idx.contiguous()
+    B, Cin, N = f.shape
+    _, M, K = idx.shape
+    C = weight.shape[0]
+    dev = f.device
+    lib = _lib.load()
+    w2 = weight.reshape(C, Cin + 3)
+    w_dp, w_f = w2[:, :3].contiguous(), w2[:, 3:].contiguous()
+    g_cm = torch.empty(B, C, N, dtype=torch.float32, device=dev)
+    g_pm = torch.empty(B, N, C, dtype=torch.float32, device=dev)
+    x1 = torch.empty(B, C, M, K, dtype=torch.float32, device=dev)
+    invstd = torch.rsqrt(bn.running_var + bn.eps)
+    with torch.cuda.device(dev):
+        _lib.check(lib.amc3d_pointwise_conv_forward(B, Cin, C, N, _ptr(f), _ptr(w_f), None, _ptr(g_cm), _stream(f)),
+                   "pointwise_conv_forward")
+        _lib.check(lib.amc3d_grouped_conv_bn_forward(
+            B, C, N, M, K, 0, int(bool(relu)), float(bn.eps), 0.0, _ptr(g_cm), _ptr(idx), _ptr(dp), _ptr(w_dp), None,
+            _ptr(bn.weight), _ptr(bn.bias), _ptr(g_pm), _ptr(x1), _ptr(bn.running_mean), _ptr(invstd), None, None, None,
+            None, None, None, 0, _stream(f)), "grouped_conv_bn_forward")
+    return x1
+
+
+def grouped_conv_bn_supported(cout, nsample):
+    return bool(_lib.load().amc3d_grouped_conv_bn_supported(int(cout), int(nsample)))
+
+
 @torch.no_grad()
 def local_aggregation_eval(f, dp, idx, weight, bn, relu):
     """the same layer in inference mode (running statistics), no gradient"""
@@ -1126,6 +1234,71 @@ class SATail(Function):
                                              _ptr(g1), _ptr(b1), _ptr(dy1), _ptr(dg1), _ptr(db1), _ptr(work1), wb1,
                                              _stream(y1)), "bn_backward")
         return dy1, dg1, db1, None, dw2.view(ctx.wshape), dg2, db2, None, None, None, None
+
+
+_identity_bn = {}  # (C, device) -> (zeros, ones): BatchNorm parameters under which relu(bn(x)) == x for x >= 0
+
+
+class SATailActivated(Function):
+    """pooled (B,C2,M) = max_k [relu2](bn2(conv2(x1))) from the ACTIVATED first-layer output x1 = relu(bn1(y1)) >= 0
+    (ops.GroupedConvBN): SATail's recomputing kernels with an identity first BatchNorm; the gradient it returns is dx1."""
+
+    @staticmethod
+    def forward(ctx, x1, w2, g2, b2, eps2, relu2, bn2=None):
+        _need_gpu(x1, w2, g2, b2)
+        x1 = x1.contiguous()
+        B, C1, M, K = x1.shape
+        C2 = w2.shape[0]
+        dev = x1.device
+        lib = _lib.load()
+        assert w2.numel() == C2 * C1 and lib.amc3d_sa_tail_supported(C1, C2, K)
+        key = (C1, str(dev))
+        if key not in _identity_bn:
+            _identity_bn[key] = (torch.zeros(C1, dtype=torch.float32, device=dev), torch.ones(C1, dtype=torch.float32, device=dev))
+        zeros, ones = _identity_bn[key]
+        w2f = w2.reshape(C2, C1).contiguous()
+        mean2 = torch.empty(C2, dtype=torch.float32, device=dev)
+        invstd2, var2 = torch.empty_like(mean2), torch.empty_like(mean2)
+        pooled = torch.empty(B, C2, M, dtype=torch.float32, device=dev)
+        wb = int(lib.amc3d_sa_tail_workspace_bytes(B, C1, C2, M))
+        work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
+        mom2, rm2, rv2, nbt2 = _bn_running_args(bn2)
+        with torch.cuda.device(dev), timing.span("sa_tail_forward", x1.numel() * 4 + pooled.numel() * 5, 2.0 * B * M * K * C1 * C2):
+            _lib.check(lib.amc3d_sa_tail_forward(B, C1, C2, M, K, _ptr(x1), _ptr(zeros), _ptr(ones), _ptr(ones), _ptr(zeros),
+                                                 _ptr(w2f), _ptr(g2), _ptr(b2), float(eps2), mom2, int(bool(relu2)),
+                                                 _ptr(pooled), _ptr(mean2), _ptr(invstd2), _ptr(var2), rm2, rv2,
+                                                 nbt2, _ptr(work), wb, _stream(x1)), "sa_tail_forward")
+        if bn2 is not None and bn2.track_running_stats and bn2.running_mean is not None and bn2.momentum is None:
+            bn_update_running(bn2, mean2, var2)
+        ctx.save_for_backward(x1, w2f, g2, b2, mean2, invstd2, zeros, ones)
+        ctx.relu2, ctx.wshape = bool(relu2), tuple(w2.shape)
+        ctx.pool_seq = _next_pool_seq() if _pool_log is not None else None
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        x1, w2f, g2, b2, mean2, invstd2, zeros, ones = ctx.saved_tensors
+        B, C1, M, K = x1.shape
+        C2 = w2f.shape[0]
+        dev = x1.device
+        dpooled = dpooled.contiguous()
+        lib = _lib.load()
+        dx1 = torch.empty_like(x1)
+        dw2 = torch.empty(C2, C1, dtype=torch.float32, device=dev)
+        dg2, db2 = torch.empty_like(g2), torch.empty_like(b2)
+        wb = int(lib.amc3d_sa_tail_workspace_bytes(B, C1, C2, M))
+        work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
+        arg = None
+        if ctx.pool_seq is not None and _pool_log is not None:
+            arg = _pool_log[ctx.pool_seq] = torch.empty(B, C2, M, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev), timing.span("sa_tail_backward", x1.numel() * 4 * 3 + dpooled.numel() * 10,
+                                                 2.0 * B * M * K * C1 * C2 * 4):
+            _lib.check(lib.amc3d_sa_tail_backward(B, C1, C2, M, K, _ptr(x1), _ptr(zeros), _ptr(ones), _ptr(ones), _ptr(zeros),
+                                                  _ptr(w2f), _ptr(mean2), _ptr(invstd2), _ptr(g2), _ptr(b2), int(ctx.relu2),
+                                                  _ptr(dpooled), _ptr(dx1), _ptr(dw2), _ptr(dg2), _ptr(db2),
+                                                  _ptr(arg) if arg is not None else None,
+                                                  _ptr(work), wb, _stream(x1)), "sa_tail_backward")
+        return dx1, dw2.view(ctx.wshape), dg2, db2, None, None, None
 
 
 def sa_tail_supported(c1, c2, k):

@@ -292,6 +292,26 @@ int amc3d_pointwise_conv_backward_bf16(int b, int cin, int cout, long P, const f
                                        const float *dy, float *dx, float *dweight, void *workspace,
                                        size_t workspace_bytes, void *stream);
 
+/* ---- first layer of a multi-layer SetAbstraction MLP (PointNeXt-S, sa_layers = 2; pointnext_AA.py:104-127, 164-166):
+ * the same convolve-before-gather conv + BatchNorm [+ ReLU], with the activation x1 (b,cout,npoints,32) materialised for
+ * the layers that follow.  forward: amc3d_pointwise_conv_forward -> g_cm, then this (statistics from the moments, one
+ * gather + write pass).  backward: from dx1, ONE pass masks the ReLU, scatters into the source points (row-contiguous float
+ * atomics) and accumulates BatchNorm's two sums and the dp weight gradient; dg_cm then goes to
+ * amc3d_pointwise_conv_backward.  Supported: nsample == 32, cout in {8,16,32} or a multiple of 64.  Workspace:
+ * amc3d_local_aggregation_workspace_bytes. */
+int amc3d_grouped_conv_bn_supported(int cout, int nsample);
+int amc3d_grouped_conv_bn_forward(int b, int cout, int n, int npoints, int nsample, int training, int relu, float eps,
+                                  float momentum, const float *g_cm, const int *idx, const float *dp, const float *w_dp,
+                                  const void *moments, const float *gamma, const float *beta, float *g_pm, float *x1,
+                                  float *mean, float *invstd, float *var_unbiased, double *gd, float *running_mean,
+                                  float *running_var, long long *num_batches_tracked, void *workspace,
+                                  size_t workspace_bytes, void *stream);
+int amc3d_grouped_conv_bn_backward(int b, int cout, int n, int npoints, int nsample, int relu, const float *dx1,
+                                   const float *g_pm, const int *idx, const float *dp, const float *w_dp,
+                                   const void *moments, const double *gd, const float *mean, const float *invstd,
+                                   const float *gamma, const float *beta, float *dg_cm, float *dw_dp, float *dgamma,
+                                   float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- tail of a two-layer SetAbstraction block, recomputed instead of materialised -----------------------------
  * BN1 -> ReLU -> Conv2d 1x1 (C1 -> C2) -> BN2 [-> ReLU] -> max over the K = 32 neighbours
  * (openpoints/models/backbone/pointnext_AA.py:104-127, 164-166) from the first conv's raw output y1 (B,C1,M,32),

@@ -116,3 +116,36 @@ def test_local_aggregation_eval_mode_and_moments():
     fj = ops.grouping_operation(f, idx)
     want = torch.relu(bn(torch.nn.functional.conv2d(torch.cat([dp, fj], 1), w))).max(-1).values
     assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("B,Cin,C,N,M", [(2, 8, 8, 900, 225), (2, 32, 32, 2000, 500), (3, 64, 64, 1200, 300),
+                                         (2, 128, 128, 640, 160), (1, 256, 256, 372, 93)])
+def test_grouped_conv_bn_first_block(B, Cin, C, N, M):
+    """ops.GroupedConvBN (first block of PointNeXt-S' two-layer SetAbstraction MLP: conv before the gather, activation
+    materialised) against grouping + cat + Conv2d + BatchNorm2d (batch statistics) + ReLU in fp64: x1, running buffers and
+    every gradient for a dense upstream gradient."""
+    from amcontrast3d_amd import ops
+    K = 32
+    p, idx, dp, f, w, gamma, beta, _ = _case(B, Cin, C, N, M, K, 31 + C, True)
+    go = torch.randn(B, C, M, K, generator=torch.Generator().manual_seed(3)).to(f.device)
+    bn = torch.nn.BatchNorm2d(C).to(f.device)
+    mom = ops.group_moments(idx, dp, N)
+    fr, wr, gr, br = (t.clone().requires_grad_(True) for t in (f, w, gamma, beta))
+    x1 = ops.GroupedConvBN.apply(fr, dp, idx, mom, wr, gr, br, 1e-5, True, bn)
+    x1.backward(go)
+    f64 = f.double().requires_grad_(True)
+    w64, g64, b64 = (t.double().requires_grad_(True) for t in (w, gamma, beta))
+    fj = f64.gather(2, idx.reshape(B, 1, -1).expand(-1, Cin, -1).long()).reshape(B, Cin, M, K)
+    y = torch.nn.functional.conv2d(torch.cat([dp.double(), fj], 1), w64)
+    mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=False)
+    ref = torch.relu((y - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + 1e-5) * g64[None, :, None, None]
+                     + b64[None, :, None, None])
+    ref.backward(go.double())
+    assert float((x1.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    cnt = y.numel() / C
+    assert float((bn.running_mean.double() - 0.1 * mean).abs().max()) <= 1e-5
+    assert float((bn.running_var.double() - (0.9 + 0.1 * var * cnt / (cnt - 1))).abs().max()) <= 1e-5 * max(1.0, float(var.max()))
+    for name, got, want in (("df", fr.grad, f64.grad), ("dw", wr.grad, w64.grad), ("dgamma", gr.grad, g64.grad),
+                            ("dbeta", br.grad, b64.grad)):
+        err = float((got.double() - want).abs().max())
+        assert err <= 1e-4 * max(1.0, float(want.abs().max())), (name, err, float(want.abs().max()))
