@@ -23,6 +23,8 @@
 // M-sized and N-sized sums.  df = W_f^T dG and dW_f = dG f^T are the pointwise conv's backward on N points.
 // The geometry moments depend on coordinates only and are part of the geometry plan (computed ahead, shared by all
 // blocks of a stage).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace amc {
@@ -524,10 +526,11 @@ __global__ __launch_bounds__(256) void lagg_collapse_kernel(int C, int n, long P
                                                             const float *__restrict__ dp, const float *__restrict__ w_dp,
                                                             const float *__restrict__ mean, const float *__restrict__ invstd,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                            float *__restrict__ Q, double *__restrict__ partial, int nparts_per_b)
+                                                            float *__restrict__ Q, double *__restrict__ partial, int nparts_per_b,
+                                                            int tiles_per_wg)
 {
     __shared__ float tile[LAGG_XC][LAGG_PT + 1];
-    __shared__ double red[4][LAGG_XC][5];
+    double(*red)[LAGG_XC][5] = reinterpret_cast<double(*)[LAGG_XC][5]>(&tile[0][0]);  // reused after the last tile (10 KiB of 33)
     constexpr int rpi = 64 / LPR, CT = 4 * LPR;  // channels of this workgroup's chunk
     const int b = blockIdx.z, c0 = blockIdx.y * LAGG_XC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -545,8 +548,8 @@ __global__ __launch_bounds__(256) void lagg_collapse_kernel(int C, int n, long P
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int v = 0; v < 5; ++v) acc[j][v] = 0.0;
-    for (int tt = 0; tt < LAGG_TILES; ++tt) {
-        const long p0 = ((long)blockIdx.x * LAGG_TILES + tt) * LAGG_PT;
+    for (int tt = 0; tt < tiles_per_wg; ++tt) {
+        const long p0 = ((long)blockIdx.x * tiles_per_wg + tt) * LAGG_PT;
         if (p0 >= P) break;
         __syncthreads();
         for (int t = threadIdx.x; t < CT * LAGG_PT; t += 256) {
@@ -605,6 +608,7 @@ __global__ __launch_bounds__(256) void lagg_collapse_kernel(int C, int n, long P
             for (int s = LPR; s < 64; s <<= 1) x += __shfl_xor(x, s, 64);
             acc[j][v] = x;
         }
+    __syncthreads();  // the tile is no longer read: its memory holds the cross-wave reduction
     if (r == 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -630,7 +634,7 @@ static bool lagg_supported(int C, int K)
 static size_t lagg_partial_bytes(int b, int C, int n, int M)
 {
     const size_t pf = (size_t)b * div_up(div_up(n, LAGG_NT), LAGG_TILES), pb = (size_t)b * div_up(div_up(M, LAGG_MT), LAGG_TILES);
-    const size_t pc = (size_t)b * div_up(div_up((long)M * 32, LAGG_PT), LAGG_TILES);  // collapse kernel (K = 32)
+    const size_t pc = (size_t)b * div_up((long)M * 32, LAGG_PT);  // collapse kernel (K = 32), at most one partial per tile
     size_t m = pf > pb ? pf : pb;
     if (pc > m) m = pc;
     return m * C * 5 * sizeof(double);
@@ -812,10 +816,11 @@ AMC_API int amc3d_grouped_conv_bn_backward(int b, int cout, int n, int npoints, 
     if (int st = fill_i32((int *)Q, 0, (size_t)b * n * cout, stream)) return st;
     const long P = (long)npoints * nsample;
     const int ct = cout < LAGG_XC ? cout : LAGG_XC;
-    const int nparts_b = div_up(div_up(P, LAGG_PT), LAGG_TILES);
+    const int ctiles = 2;  // tiles per workgroup (1, 2, 4 measured alike: the kernel runs at the float-atomic rate)
+    const int nparts_b = div_up(div_up(P, LAGG_PT), ctiles);
 #define AMC_COLLAPSE(L)                                                                                                        \
     hipLaunchKernelGGL(lagg_collapse_kernel<L>, dim3(nparts_b, cout / ct, b), dim3(256), 0, stream, cout, n, P, relu, dx1, g_pm,  \
-                       idx, dp, w_dp, mean, invstd, gamma, beta, Q, partial, nparts_b)
+                       idx, dp, w_dp, mean, invstd, gamma, beta, Q, partial, nparts_b, ctiles)
     switch (ct / 4) { case 2: AMC_COLLAPSE(2); break; case 4: AMC_COLLAPSE(4); break; case 8: AMC_COLLAPSE(8); break; default: AMC_COLLAPSE(16); }
 #undef AMC_COLLAPSE
     hipLaunchKernelGGL(lagg_bwd_finalize_kernel, dim3(cout), dim3(256), 0, stream, cout, nparts_b * b,
