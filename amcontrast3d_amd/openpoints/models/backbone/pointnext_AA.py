@@ -24,12 +24,65 @@ from typing import List
 import torch
 import torch.nn as nn
 
+from amcontrast3d_amd.ops import point_major_rows
+
 from ..build import MODELS
 from .pointnext_blocks import (_BLOCKS, FeaturePropogation, InvResMLP, LocalAggregation, ResBlock,  # noqa: F401
                                SetAbstraction, get_reduction_fn)
 
 
 _OFFSETS = {}
+
+
+class _Stage(dict):
+    """One entry of stageACE_list['down'] / ['up']: {'p_out', 'f_out', 'offset'} (pointnext_AA.py:458-462).  The
+    encoder's 'f_out' -- a transposed copy of its features -- is overwritten by the decoder before anything reads it
+    ('up' IS 'down', :464-465, 518-519), so it is made only if somebody asks for it first."""
+
+    def __init__(self, p_out, features, offset):
+        super().__init__(p_out=p_out, offset=offset)
+        self._features = features
+
+    def _materialise(self):
+        if self._features is not None and not dict.__contains__(self, 'f_out'):
+            from amcontrast3d_amd.ops import point_major_rows
+            dict.__setitem__(self, 'f_out', point_major_rows(self._features))
+        self._features = None
+
+    def __getitem__(self, key):
+        if key == 'f_out':
+            self._materialise()
+        return dict.__getitem__(self, key)
+
+    def __setitem__(self, key, value):
+        if key == 'f_out':
+            self._features = None
+        dict.__setitem__(self, key, value)
+
+    def __contains__(self, key):
+        return key == 'f_out' or dict.__contains__(self, key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        self._materialise()
+        return dict.keys(self)
+
+    def items(self):
+        self._materialise()
+        return dict.items(self)
+
+    def values(self):
+        self._materialise()
+        return dict.values(self)
+
+    def __iter__(self):
+        self._materialise()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        return 3
 
 
 def _segment_offset(n, device):
@@ -176,10 +229,9 @@ class PointNextEncoder_AMContrast3D(nn.Module):
             f.append(_f)
             if i != len(self.encoder) - 1:
                 flat_p = torch.flatten(_p, start_dim=0, end_dim=1)
-                flat_f = torch.flatten(_f.transpose(1, 2), start_dim=0, end_dim=1)
                 # the whole flattened batch is ONE segment: neighbours are searched across samples
                 offset = _segment_offset(flat_p.shape[0], flat_p.device)
-                down.append({'p_out': flat_p, 'f_out': flat_f, 'offset': offset})
+                down.append(_Stage(flat_p, _f, offset))  # 'f_out' = flatten(_f.transpose(1, 2)) on first access
         stageACE_list['down'] = down
         stageACE_list['up'] = down  # decoder overwrites ['f_out'] in place
         return p, f, stageACE_list
@@ -226,7 +278,7 @@ class PointNextDecoder_AMContrast3D(nn.Module):
             f[i - 1] = self.decoder[i][1:](
                 [p[i], self.decoder[i][0]([p[i - 1], f[i - 1]], [p[i], f[i]], geom=geometry['decoder'][i])])[1]
             # decoder embedding of this resolution, (B*n, C) rows, for the contrastive loss
-            stageACE_list['up'][i]['f_out'] = torch.flatten(f[i - 1].transpose(1, 2), start_dim=0, end_dim=1)
+            stageACE_list['up'][i]['f_out'] = point_major_rows(f[i - 1])
         return f[-len(self.decoder) - 1].squeeze(-1), stageACE_list
 
     def forward(self, p, f, stageACE_list):

@@ -764,6 +764,43 @@ class GroupedConv(Function):
 grouped_conv = GroupedConv.apply
 
 
+class PointMajorRows(Function):
+    """(B,C,n) channel-major features -> (B*n, C) rows: torch.flatten(f.transpose(1, 2), 0, 1), the per-stage embedding
+    the contrastive loss reads (pointnext_AA.py:459-460, 518-519), as ONE coalesced LDS-tiled transpose each way.  torch
+    makes the copy with a strided elementwise kernel and, in backward, adds the strided gradient view into the
+    channel-major gradient with another one (0.7 GB of scattered traffic per step, measured)."""
+
+    @staticmethod
+    def forward(ctx, f):
+        _need_gpu(f)
+        _need_dtype(torch.float32, f=f)
+        f = f.contiguous()
+        B, C, n = f.shape
+        out = torch.empty(B * n, C, dtype=torch.float32, device=f.device)
+        with torch.cuda.device(f.device), timing.span("transpose_rows", f.numel() * 8):
+            _lib.check(_lib.load().amc3d_transpose_cn(B, C, n, _ptr(f), _ptr(out), _stream(f)), "transpose_cn")
+        ctx.shape = (B, C, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, n = ctx.shape
+        g = g.contiguous()
+        out = torch.empty(B, C, n, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device), timing.span("transpose_rows", g.numel() * 8):
+            # (B, n, C) -> (B, C, n): the same kernel with the roles of the two axes exchanged
+            _lib.check(_lib.load().amc3d_transpose_cn(B, n, C, _ptr(g), _ptr(out), _stream(g)), "transpose_cn")
+        return out
+
+
+def point_major_rows(f):
+    """(B,C,n) -> (B*n,C); the fused transpose on fp32 GPU tensors, torch's flatten(transpose) otherwise"""
+    import os
+    if f.is_cuda and f.dtype == torch.float32 and f.dim() == 3 and not os.environ.get("AMC3D_NO_PM_ROWS"):
+        return PointMajorRows.apply(f)
+    return torch.flatten(f.transpose(1, 2), start_dim=0, end_dim=1)
+
+
 # ----------------------------------------------------------------------------------------------
 # single grouped conv + BatchNorm [+ReLU] + max over the neighbours, convolved before the gather (csrc/lagg.hip)
 # ----------------------------------------------------------------------------------------------
