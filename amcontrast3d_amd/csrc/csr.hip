@@ -1,0 +1,272 @@
+// Reverse adjacency (CSR) of a neighbourhood query, and what it replaces float atomics with (gfx950).
+//
+// The backward of a gathered layer sums, for every SOURCE point n, the gradients of all positions (m, k) that gathered
+// it: idx[b, m, k] == n.  The reference does that with float atomics (group_points_grad_kernel_fast,
+// group_points_gpu.cu:34-51), and so did this library; on MI355X float atomics run at ~1.3 TB/s of added bytes and stall
+// the issuing wave, 3x slower than reading the same bytes.  The edges depend on coordinates only, so the geometry plan
+// sorts them once per batch by target (stable LSD radix sort of (b*n + idx, position) pairs: hipCUB / rocPRIM device
+// primitive) and every backward pass becomes a gather over contiguous edge lists -- no atomics, a fixed summation order,
+// bit-reproducible results:
+//   amc3d_group_csr            idx (b,m,k) -> rev_start (b*n + 1), rev_edge (b*m*k) positions ordered by (target, position)
+//   amc3d_group_moments_csr    the geometry moments of lagg.hip from the lists (no scattered atomics, exact in-degree)
+//   amc3d_grouped_conv_bn_backward_csr   the collapse pass of the first SetAbstraction layer as a gather
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace amc {
+
+constexpr double CSR_FX_D = 68719476736.0;   // = LAGG_FX_D (2^36)
+constexpr double CSR_FX_M = 1073741824.0;    // = LAGG_FX_M (2^30)
+
+static size_t csr_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int csr_bits(long v)
+{
+    int b = 1;
+    while ((1L << b) < v) ++b;
+    return b;
+}
+
+static size_t csr_sort_temp(long e)
+{
+    size_t t = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t, (const unsigned *)nullptr, (unsigned *)nullptr, (const int *)nullptr,
+                                             (int *)nullptr, (int)e);
+    return csr_align(t);
+}
+
+__global__ void csr_keys_kernel(int n, long P, long E, const int *__restrict__ idx, unsigned *__restrict__ key, int *__restrict__ val)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const long b = e / P;
+    const int id = idx[e];
+    key[e] = (unsigned)(b * n + (id >= 0 && id < n ? id : 0));
+    val[e] = (int)(e - b * P);
+}
+
+// rev_start[g] = first sorted edge with key >= g (g = 0 .. G inclusive): binary search, no atomics
+__global__ void csr_start_kernel(long G, long E, const unsigned *__restrict__ skey, int *__restrict__ rev_start)
+{
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > G) return;
+    long lo = 0, hi = E;
+    while (lo < hi) {
+        const long mid = (lo + hi) >> 1;
+        if ((long)skey[mid] < g) lo = mid + 1; else hi = mid;
+    }
+    rev_start[g] = (int)lo;
+}
+
+// per source point: in-degree and fixed-point dp sum, in list order (deterministic); a lane per point
+__global__ void csr_moments_kernel(int n, long P, long G, const int *__restrict__ rev_start, const int *__restrict__ rev_edge,
+                                   const float *__restrict__ dp, int *__restrict__ cnt, long long *__restrict__ dfx)
+{
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const long b = g / n;
+    const int s = rev_start[g], e = rev_start[g + 1];
+    const float *d0 = dp + b * 3 * P, *d1 = d0 + P, *d2 = d1 + P;
+    double x = 0.0, y = 0.0, z = 0.0;
+    for (int i = s; i < e; ++i) {
+        const int p = rev_edge[i];
+        x += (double)d0[p]; y += (double)d1[p]; z += (double)d2[p];
+    }
+    cnt[g] = e - s;
+    dfx[g * 3 + 0] = __double2ll_rn(x * CSR_FX_D);
+    dfx[g * 3 + 1] = __double2ll_rn(y * CSR_FX_D);
+    dfx[g * 3 + 2] = __double2ll_rn(z * CSR_FX_D);
+}
+
+// global sums of dp and dp dp^T over all positions: block partials in double, fixed-point integer atomics (order-free)
+__global__ __launch_bounds__(256) void csr_global_moments_kernel(long P, const float *__restrict__ dp, unsigned long long *__restrict__ mom)
+{
+    __shared__ double red[4][9];
+    const int b = blockIdx.y;
+    const float *d0 = dp + (size_t)b * 3 * P, *d1 = d0 + P, *d2 = d1 + P;
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+        const double dx = d0[p], dy = d1[p], dz = d2[p];
+        s[0] += dx; s[1] += dy; s[2] += dz;
+        s[3] += dx * dx; s[4] += dx * dy; s[5] += dx * dz; s[6] += dy * dy; s[7] += dy * dz; s[8] += dz * dz;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        double v = s[j];
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wave][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        const double v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        atomicAdd(mom + threadIdx.x, (unsigned long long)__double2ll_rn(v * CSR_FX_M));
+    }
+}
+
+__device__ __forceinline__ float csr_bn(float x, float mean, float invstd, float gamma, float beta)
+{
+    return __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(x, mean), invstd), gamma), beta);
+}
+
+// Collapse as a gather: a group of CT lanes owns one source point g and walks its edge list; lane = channel.
+//   q[g][c] = sum_e d(e, c),  d = dx1_pm[position e][c] * [relu: bn(G[g][c] + W_dp[c] . dp_e) > 0]
+//   partial sums per channel {sum d, sum d xhat, sum d dp_j}.  dx1_pm is the POSITION-major gradient (b, P, C).
+// grid (point groups, channel chunks of 64, 1); a workgroup takes PTS consecutive source points per wave-group
+template <int CT>
+__global__ __launch_bounds__(256) void csr_collapse_kernel(int C, int n, long P, long G, int relu, const float *__restrict__ dx1_pm,
+                                                           const float *__restrict__ g_pm, const int *__restrict__ rev_start,
+                                                           const int *__restrict__ rev_edge, const float *__restrict__ dp,
+                                                           const float *__restrict__ w_dp, const float *__restrict__ mean,
+                                                           const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, float *__restrict__ Q,
+                                                           double *__restrict__ partial, int pts_per_group)
+{
+    constexpr int GROUPS = 256 / CT;  // point groups per workgroup
+    __shared__ double red[GROUPS][CT][5];
+    const int c0 = blockIdx.y * 64;
+    const int cl = threadIdx.x % CT, grp = threadIdx.x / CT;
+    const int c = c0 + cl;
+    const float w0 = w_dp[c * 3 + 0], w1 = w_dp[c * 3 + 1], w2 = w_dp[c * 3 + 2];
+    const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+    const long g_begin = ((long)blockIdx.x * GROUPS + grp) * pts_per_group;
+    for (int i = 0; i < pts_per_group; ++i) {
+        const long g = g_begin + i;
+        if (g >= G) break;
+        const long b = g / n;
+        const float gv = g_pm[g * C + c];
+        const float *d0 = dp + b * 3 * P, *d1 = d0 + P, *d2 = d1 + P;
+        const float *xrow = dx1_pm + b * P * C + c;
+        const int s = rev_start[g], e = rev_start[g + 1];
+        float q = 0.f;
+        for (int j0 = s; j0 < e; j0 += 8) {  // eight edges at a time: their loads are independent, one latency for all
+            int p[8];
+            float e0[8], e1[8], e2[8], d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = rev_edge[min(j0 + u, e - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                e0[u] = d0[p[u]]; e1[u] = d1[p[u]]; e2[u] = d2[p[u]];
+                d[u] = xrow[(long)p[u] * C];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float y = __fmaf_rn(w0, e0[u], __fmaf_rn(w1, e1[u], __fmaf_rn(w2, e2[u], gv)));
+                const float xh = __fmul_rn(__fsub_rn(y, mu), is);
+                float dv = d[u];
+                if (j0 + u >= e || (relu && !(__fadd_rn(__fmul_rn(xh, ga), be) > 0.f))) dv = 0.f;
+                q += dv;
+                const double dd = dv;
+                a0 += dd; a1 += dd * (double)xh; a2 += dd * (double)e0[u]; a3 += dd * (double)e1[u]; a4 += dd * (double)e2[u];
+            }
+        }
+        Q[g * C + c] = q;
+    }
+    red[grp][cl][0] = a0; red[grp][cl][1] = a1; red[grp][cl][2] = a2; red[grp][cl][3] = a3; red[grp][cl][4] = a4;
+    __syncthreads();
+    for (int t = threadIdx.x; t < CT * 5; t += 256) {
+        const int k = t / 5, v = t - k * 5;
+        double sum = 0.0;
+        for (int gq = 0; gq < GROUPS; ++gq) sum += red[gq][k][v];
+        partial[((size_t)blockIdx.x * C + c0 + k) * 5 + v] = sum;
+    }
+}
+
+}  // namespace amc
+
+using namespace amc;
+
+AMC_API size_t amc3d_group_csr_workspace_bytes(int b, int npoints, int nsample)
+{
+    const long E = (long)b * npoints * nsample;
+    if (E <= 0) return 0;
+    return 2 * csr_align((size_t)E * 4) + csr_align((size_t)E * 4) + csr_sort_temp(E) + 256;  // keys, sorted keys, values, temp
+}
+
+// rev_start (b*n + 1) int32: rev_edge[rev_start[b*n + j] .. rev_start[b*n + j + 1]) are the positions p = m*nsample + k of
+// batch b whose neighbour index is j, in ascending p; rev_edge (b*npoints*nsample) int32
+AMC_API int amc3d_group_csr(int b, int n, int npoints, int nsample, const int *idx, int *rev_start, int *rev_edge, void *workspace,
+                            size_t workspace_bytes, void *stream_)
+{
+    const long P = (long)npoints * nsample, E = (long)b * P, G = (long)b * n;
+    if (E <= 0 || n <= 0) return 0;
+    if (!idx || !rev_start || !rev_edge || !workspace || workspace_bytes < amc3d_group_csr_workspace_bytes(b, npoints, nsample) ||
+        E >= (1L << 31) || G >= (1L << 31))
+        return bad_arg("amc3d_group_csr: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    char *w = (char *)workspace;
+    unsigned *key = (unsigned *)w; w += csr_align((size_t)E * 4);
+    unsigned *skey = (unsigned *)w; w += csr_align((size_t)E * 4);
+    int *val = (int *)w; w += csr_align((size_t)E * 4);
+    size_t temp = csr_sort_temp(E);
+    hipLaunchKernelGGL(csr_keys_kernel, dim3(div_up(E, 256)), dim3(256), 0, stream, n, P, E, idx, key, val);
+    const hipError_t e = hipcub::DeviceRadixSort::SortPairs(w, temp, (const unsigned *)key, skey, (const int *)val, rev_edge, (int)E, 0,
+                                                            csr_bits(G), stream);
+    if (e != hipSuccess) { set_error("amc3d_group_csr: radix sort: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(csr_start_kernel, dim3(div_up(G + 1, 256)), dim3(256), 0, stream, G, E, (const unsigned *)skey, rev_start);
+    return launch_status("amc3d_group_csr");
+}
+
+// the moments buffer of amc3d_group_moments (same layout) from the reverse lists: exact in-degree, dp sums in list order
+AMC_API int amc3d_group_moments_csr(int b, int n, int npoints, int nsample, const int *rev_start, const int *rev_edge,
+                                    const float *dp, void *moments, size_t moments_bytes, void *stream_)
+{
+    if (b <= 0 || n <= 0) return 0;
+    if (!rev_start || !rev_edge || !dp || !moments || moments_bytes < amc3d_group_moments_bytes(b, n) || npoints <= 0 || nsample <= 0)
+        return bad_arg("amc3d_group_moments_csr: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const long P = (long)npoints * nsample, G = (long)b * n;
+    char *p = (char *)moments;
+    unsigned long long *mom = (unsigned long long *)p;
+    int *cnt = (int *)(p + 16 * 8);
+    long long *dfx = (long long *)(p + 16 * 8 + (size_t)G * 4 + ((size_t)G & 1) * 4);
+    if (int st = fill_i32((int *)moments, 0, 32, stream)) return st;  // the 16 global 64-bit words
+    hipLaunchKernelGGL(csr_moments_kernel, dim3(div_up(G, 256)), dim3(256), 0, stream, n, P, G, rev_start, rev_edge, dp, cnt, dfx);
+    const int blocks = (int)(div_up(P, 256 * 8) < 512 ? div_up(P, 256 * 8) : 512);
+    hipLaunchKernelGGL(csr_global_moments_kernel, dim3(blocks, b), dim3(256), 0, stream, P, dp, mom);
+    return launch_status("amc3d_group_moments_csr");
+}
+
+static int csr_pts_per_group(long G, int groups_per_wg)
+{
+    // ~2048 workgroups
+    long per = (G + 2048L * groups_per_wg - 1) / (2048L * groups_per_wg);
+    return (int)(per < 1 ? 1 : per);
+}
+
+namespace amc {
+size_t csr_partials(int b, int cout, int n)
+{
+    const int ct = cout < 64 ? cout : 64;
+    const int groups = 256 / ct;
+    const long G = (long)b * n;
+    const int per = csr_pts_per_group(G, groups);
+    return (size_t)div_up(G, (long)groups * per);
+}
+}  // namespace amc
+
+// stage 1 of amc3d_grouped_conv_bn_backward without atomics: Q (b,n,cout) and the per-workgroup partial sums
+// [nparts][cout][5] doubles from the POSITION-major gradient dx1_pm (b, npoints*nsample, cout); the caller finishes with the
+// finalize / apply kernels of lagg.hip (amc3d_grouped_conv_bn_backward does all of it when given rev lists)
+namespace amc {
+int csr_collapse(int b, int cout, int n, int npoints, int nsample, int relu, const float *dx1_pm, const float *g_pm,
+                 const int *rev_start, const int *rev_edge, const float *dp, const float *w_dp, const float *mean,
+                 const float *invstd, const float *gamma, const float *beta, float *Q, double *partial, int *nparts,
+                 hipStream_t stream)
+{
+    const long P = (long)npoints * nsample, G = (long)b * n;
+    const int ct = cout < 64 ? cout : 64;
+    const int groups = 256 / ct;
+    const int per = csr_pts_per_group(G, groups);
+    const int wgs = div_up(G, (long)groups * per);
+    *nparts = wgs;
+#define AMC_CSR(CTV)                                                                                                          \
+    hipLaunchKernelGGL(csr_collapse_kernel<CTV>, dim3(wgs, cout / ct), dim3(256), 0, stream, cout, n, P, G, relu, dx1_pm, g_pm, \
+                       rev_start, rev_edge, dp, w_dp, mean, invstd, gamma, beta, Q, partial, per)
+    switch (ct) { case 8: AMC_CSR(8); break; case 16: AMC_CSR(16); break; case 32: AMC_CSR(32); break; default: AMC_CSR(64); }
+#undef AMC_CSR
+    return launch_status("csr_collapse");
+}
+}  // namespace amc

@@ -23,6 +23,8 @@
 // themselves: the first neighbour (ascending index, torch.max's rule) attaining the maximum of the normalised values --
 // exactly the element the reference's max-pool routes the gradient to, also when two raw values round to the same
 // normalised value or a ReLU clamps several to zero.  BN1's own backward (from dx1) stays with bn.hip.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace amc {
@@ -353,7 +355,11 @@ static bool sat_aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 static bool sat_supported(int C1, int C2, int K) { return K == 32 && C1 >= 2 && C1 <= SAT_MAX_C1 && C1 % 2 == 0 && C2 >= 1 && C2 <= SAT_MAX_C2; }
 // the recomputation costs 2-3x the layer's MFMA work: it pays while the layer is HBM-bound (measured on MI355X:
 // 32 -> 64 channels faster fused, 64 -> 128 faster layer by layer, also with the single forward pass)
-static bool sat_pays(int C1, int C2) { return (long)C1 * C2 <= 32 * 64; }
+static bool sat_pays(int C1, int C2)
+{
+    static const long lim = getenv("AMC3D_SAT_PAYS") ? atol(getenv("AMC3D_SAT_PAYS")) : 32 * 64;
+    return (long)C1 * C2 <= lim;
+}
 
 static size_t sat_lds(int C1, int C2, int mode)
 {

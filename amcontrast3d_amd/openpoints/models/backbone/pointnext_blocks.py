@@ -26,12 +26,25 @@ from ..layers import (CHANNEL_MAP, create_act, create_convblock1d, create_convbl
                       three_interpolate, three_nn)
 
 
-def _moments(convs, feature_type, idx, dp, n_support):
+def _moments(convs, feature_type, idx, dp, n_support, csr=None):
     """geometry moments of a neighbourhood layer (the convolve-before-gather kernels need them), else None"""
     if feature_type != 'dp_fj' or not idx.is_cuda or len(convs) < 1:
         return None
     from amcontrast3d_amd import ops
+    if csr is not None:
+        return ops.group_moments_csr(idx, dp, n_support, (csr['start'], csr['edge']))
     return ops.group_moments(idx, dp, n_support)
+
+
+def _csr(convs, feature_type, idx, n_support):
+    """reverse adjacency of the query for layers whose backward sums dense per-position gradients into the source points
+    (the multi-layer SetAbstraction MLP of PointNeXt-S): gathers over sorted edge lists instead of float atomics"""
+    import os
+    if feature_type != 'dp_fj' or not idx.is_cuda or len(convs) < 2 or os.environ.get("AMC3D_NO_CSR"):
+        return None
+    from amcontrast3d_amd import ops
+    start, edge = ops.group_csr(idx, n_support)
+    return {'start': start, 'edge': edge}
 
 
 def get_reduction_fn(reduction):
@@ -149,7 +162,8 @@ class SetAbstraction(nn.Module):
         if not self.is_head and hasattr(self.grouper, 'query'):
             g['idx'] = self.grouper.query(g['new_p'], p)
             g['dp'] = self.grouper.relative_positions(g['idx'], g['new_p'], p)
-            g['mom'] = _moments(self.convs, self.feature_type, g['idx'], g['dp'], p.shape[1])
+            g['csr'] = _csr(self.convs, self.feature_type, g['idx'], p.shape[1])
+            g['mom'] = _moments(self.convs, self.feature_type, g['idx'], g['dp'], p.shape[1], g['csr'])
         return g
 
     def plan(self, p):

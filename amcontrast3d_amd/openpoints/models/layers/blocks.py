@@ -314,7 +314,10 @@ def fused_first_block(blocks, f, geom, feature_type):
         return ops.grouped_conv_bn_eval(f, geom['dp'], idx, conv.weight, bn, True)
     if not _fusable_bn(bn, f):
         return None
-    return ops.GroupedConvBN.apply(f, geom['dp'], idx, geom['mom'], conv.weight, bn.weight, bn.bias, bn.eps, True, bn)
+    csr = geom.get('csr')
+    if csr is not None:
+        csr = (csr['start'], csr['edge'])
+    return ops.GroupedConvBN.apply(f, geom['dp'], idx, geom['mom'], conv.weight, bn.weight, bn.bias, bn.eps, True, bn, csr)
 
 
 def _sa_tail_activated(mods, x1, pool_max):

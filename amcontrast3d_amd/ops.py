@@ -827,6 +827,43 @@ def group_moments(idx, dp, n_support):
     return out
 
 
+@torch.no_grad()
+def group_csr(idx, n_support):
+    """Reverse adjacency of a neighbourhood query idx (B,M,K) into n_support points: (rev_start (B*n+1), rev_edge (B*M*K))
+    int32 -- for every source point the positions that gathered it, in ascending position order (csrc/csr.hip).
+    Coordinates only: part of the geometry plan.  The backward passes that used float atomics gather over these lists."""
+    _need_gpu(idx)
+    _need_dtype(torch.int32, idx=idx)
+    idx = idx.contiguous()
+    B, M, K = idx.shape
+    n = int(n_support)
+    dev = idx.device
+    lib = _lib.load()
+    rev_start = torch.empty(B * n + 1, dtype=torch.int32, device=dev)
+    rev_edge = torch.empty(B * M * K, dtype=torch.int32, device=dev)
+    wb = int(lib.amc3d_group_csr_workspace_bytes(B, M, K))
+    work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev), timing.span("group_csr", idx.numel() * 12 + B * n * 4):
+        _lib.check(lib.amc3d_group_csr(B, n, M, K, _ptr(idx), _ptr(rev_start), _ptr(rev_edge), _ptr(work), wb, _stream(idx)),
+                   "group_csr")
+    return rev_start, rev_edge
+
+
+@torch.no_grad()
+def group_moments_csr(idx, dp, n_support, csr):
+    """group_moments from the reverse lists: exact in-degree, dp sums in list order, no scattered atomics"""
+    _need_gpu(idx, dp)
+    dp = dp.contiguous()
+    B, M, K = idx.shape
+    lib = _lib.load()
+    nb = int(lib.amc3d_group_moments_bytes(B, int(n_support)))
+    out = torch.empty(nb, dtype=torch.uint8, device=idx.device)
+    with torch.cuda.device(idx.device), timing.span("group_moments", idx.numel() * 16 + nb):
+        _lib.check(lib.amc3d_group_moments_csr(B, int(n_support), M, K, _ptr(csr[0]), _ptr(csr[1]), _ptr(dp), _ptr(out), nb,
+                                               _stream(idx)), "group_moments_csr")
+    return out
+
+
 class LocalAggregationFused(Function):
     """pooled (B,C,M) = max_k [relu](bn(conv1x1([dp ; f[idx]]))) -- grouping_operation + cat + Conv2d + BatchNorm2d (batch
     statistics) [+ ReLU] + max of LocalAggregation / single-layer SetAbstraction (pointnext_AA.py:57-63, 139-170) -- with
@@ -919,7 +956,7 @@ class GroupedConvBN(Function):
     lagg_collapse_kernel) instead of BatchNorm-backward statistics + apply + the conv's two backward products."""
 
     @staticmethod
-    def forward(ctx, f, dp, idx, moments, weight, gamma, beta, eps, relu, bn=None):
+    def forward(ctx, f, dp, idx, moments, weight, gamma, beta, eps, relu, bn=None, csr=None):
         _need_gpu(f, dp, idx, moments, weight, gamma, beta)
         _need_dtype(torch.float32, f=f, dp=dp, weight=weight)
         _need_dtype(torch.int32, idx=idx)
@@ -930,6 +967,7 @@ class GroupedConvBN(Function):
         assert weight.numel() == C * (Cin + 3)
         dev = f.device
         lib = _lib.load()
+        ctx.csr = csr  # (rev_start, rev_edge) of ops.group_csr, or None: backward then scatters with float atomics
         w2 = weight.reshape(C, Cin + 3)
         w_dp, w_f = w2[:, :3].contiguous(), w2[:, 3:].contiguous()
         g_cm = torch.empty(B, C, N, dtype=torch.float32, device=dev)
@@ -969,7 +1007,9 @@ class GroupedConvBN(Function):
         dg_cm = torch.empty(B, C, N, dtype=torch.float32, device=dev)
         dw_dp = torch.empty(C, 3, dtype=torch.float32, device=dev)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
-        wb = int(lib.amc3d_local_aggregation_workspace_bytes(B, C, N, M))
+        csr = ctx.csr
+        wb = int(lib.amc3d_grouped_conv_bn_csr_workspace_bytes(B, C, N, M, K) if csr is not None
+                 else lib.amc3d_local_aggregation_workspace_bytes(B, C, N, M))
         work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
         need_f = ctx.needs_input_grad[0]
         df = torch.empty_like(f) if need_f else None
@@ -979,16 +1019,22 @@ class GroupedConvBN(Function):
         work2 = torch.empty(max(wb2, 4), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             with timing.span("grouped_conv_bn_backward", B * M * K * (8 * C + 16) + 12 * B * N * C):
-                _lib.check(lib.amc3d_grouped_conv_bn_backward(
-                    B, C, N, M, K, int(ctx.relu), _ptr(dx1), _ptr(g_pm), _ptr(idx), _ptr(dp), _ptr(w_dp), _ptr(moments),
-                    _ptr(gd), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dg_cm), _ptr(dw_dp), _ptr(dgamma),
-                    _ptr(dbeta), _ptr(work), wb, _stream(f)), "grouped_conv_bn_backward")
+                if csr is not None:
+                    _lib.check(lib.amc3d_grouped_conv_bn_backward_csr(
+                        B, C, N, M, K, int(ctx.relu), _ptr(dx1), _ptr(g_pm), _ptr(csr[0]), _ptr(csr[1]), _ptr(dp), _ptr(w_dp),
+                        _ptr(moments), _ptr(gd), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dg_cm), _ptr(dw_dp),
+                        _ptr(dgamma), _ptr(dbeta), _ptr(work), wb, _stream(f)), "grouped_conv_bn_backward_csr")
+                else:
+                    _lib.check(lib.amc3d_grouped_conv_bn_backward(
+                        B, C, N, M, K, int(ctx.relu), _ptr(dx1), _ptr(g_pm), _ptr(idx), _ptr(dp), _ptr(w_dp), _ptr(moments),
+                        _ptr(gd), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dg_cm), _ptr(dw_dp), _ptr(dgamma),
+                        _ptr(dbeta), _ptr(work), wb, _stream(f)), "grouped_conv_bn_backward")
             with timing.span("pointwise_conv_backward", 4 * B * N * (Cin + C) * (1 + int(need_f)),
                              2.0 * B * N * Cin * C * (1 + int(need_f))):
                 _lib.check(pw_bwd(B, Cin, C, N, _ptr(f), _ptr(w_f), _ptr(dg_cm), _ptr(df) if need_f else None, _ptr(dw_f),
                                   _ptr(work2), wb2, _stream(f)), "pointwise_conv_backward")
         dw = torch.cat((dw_dp, dw_f), dim=1).view(ctx.wshape)
-        return df, None, None, None, dw, dgamma, dbeta, None, None, None
+        return df, None, None, None, dw, dgamma, dbeta, None, None, None, None
 
 
 @torch.no_grad()

@@ -312,6 +312,25 @@ int amc3d_grouped_conv_bn_backward(int b, int cout, int n, int npoints, int nsam
                                    const float *gamma, const float *beta, float *dg_cm, float *dw_dp, float *dgamma,
                                    float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- reverse adjacency of a neighbourhood query: gathers instead of float atomics in backward (csrc/csr.hip) ---------
+ * The reference's grouping backward scatters with atomicAdd (group_points_gpu.cu:34-51).  The edges depend on coordinates
+ * only: amc3d_group_csr sorts them once by target (stable radix sort), after which every source point sums its incoming
+ * positions in list order -- deterministic, no atomics.  rev_start (b*n + 1) int32, rev_edge (b*npoints*nsample) int32:
+ * rev_edge[rev_start[b*n + j] .. rev_start[b*n + j + 1]) = positions p = m*nsample + k of batch b with idx[b,m,k] == j. */
+size_t amc3d_group_csr_workspace_bytes(int b, int npoints, int nsample);
+int amc3d_group_csr(int b, int n, int npoints, int nsample, const int *idx, int *rev_start, int *rev_edge, void *workspace,
+                    size_t workspace_bytes, void *stream);
+/* the moments buffer of amc3d_group_moments from the lists (no scattered atomics) */
+int amc3d_group_moments_csr(int b, int n, int npoints, int nsample, const int *rev_start, const int *rev_edge,
+                            const float *dp, void *moments, size_t moments_bytes, void *stream);
+/* amc3d_grouped_conv_bn_backward as a gather over the lists (dx1 is transposed to position-major in the workspace) */
+size_t amc3d_grouped_conv_bn_csr_workspace_bytes(int b, int cout, int n, int npoints, int nsample);
+int amc3d_grouped_conv_bn_backward_csr(int b, int cout, int n, int npoints, int nsample, int relu, const float *dx1,
+                                       const float *g_pm, const int *rev_start, const int *rev_edge, const float *dp,
+                                       const float *w_dp, const void *moments, const double *gd, const float *mean,
+                                       const float *invstd, const float *gamma, const float *beta, float *dg_cm, float *dw_dp,
+                                       float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- tail of a two-layer SetAbstraction block, recomputed instead of materialised -----------------------------
  * BN1 -> ReLU -> Conv2d 1x1 (C1 -> C2) -> BN2 [-> ReLU] -> max over the K = 32 neighbours
  * (openpoints/models/backbone/pointnext_AA.py:104-127, 164-166) from the first conv's raw output y1 (B,C1,M,32),

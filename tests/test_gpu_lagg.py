@@ -149,3 +149,47 @@ def test_grouped_conv_bn_first_block(B, Cin, C, N, M):
                             ("dbeta", br.grad, b64.grad)):
         err = float((got.double() - want).abs().max())
         assert err <= 1e-4 * max(1.0, float(want.abs().max())), (name, err, float(want.abs().max()))
+
+
+def test_reverse_lists_moments_and_gather_backward():
+    """csrc/csr.hip: the reverse adjacency of a ball query (every position exactly once, under its target, ascending), the
+    geometry moments derived from it (identical in-degree, dp sums equal to the fixed-point atomics' up to the double
+    summation order), and GroupedConvBN's backward as a gather over the lists against its float-atomic form."""
+    from amcontrast3d_amd import ops
+    B, Cin, C, N, M, K = 3, 32, 64, 1500, 375, 32
+    p, idx, dp, f, w, gamma, beta, _ = _case(B, Cin, C, N, M, K, 77, True)
+    start, edge = ops.group_csr(idx, N)
+    s, e, flat = start.cpu().numpy(), edge.cpu().numpy(), idx.reshape(B, -1).cpu().numpy()
+    P = M * K
+    assert s[0] == 0 and s[-1] == B * P and np.all(np.diff(s) >= 0)
+    for b in range(B):
+        seg = e[s[b * N]:s[(b + 1) * N]]
+        assert sorted(seg.tolist()) == list(range(P))  # every position of the batch exactly once
+    for g in (0, 7, N + 3, 2 * N + 11, B * N - 1):
+        b, j = divmod(g, N)
+        lst = e[s[g]:s[g + 1]]
+        assert np.all(flat[b][lst] == j) and np.all(np.diff(lst) > 0)
+        assert len(lst) == int((flat[b] == j).sum())
+    m_atomic = ops.group_moments(idx, dp, N).cpu().numpy()
+    m_csr = ops.group_moments_csr(idx, dp, N, (start, edge)).cpu().numpy()
+    G = B * N
+    np.testing.assert_array_equal(m_atomic[128:128 + 4 * G], m_csr[128:128 + 4 * G])  # in-degrees
+    off = 128 + 4 * G + 4 * (G & 1)
+    da, dc = m_atomic[off:off + 24 * G].view(np.int64), m_csr[off:off + 24 * G].view(np.int64)
+    assert np.abs(da - dc).max() <= 64  # fixed point 2^-36: per-term rounding (atomics) vs one rounding of the double sum
+    assert np.abs(m_atomic[:72].view(np.int64) - m_csr[:72].view(np.int64)).max() <= 4096
+    go = torch.randn(B, C, M, K, generator=torch.Generator().manual_seed(4)).to(f.device)
+    grads = []
+    for csr in (None, (start, edge)):
+        fr, wr, gr, br = (t.clone().requires_grad_(True) for t in (f, w, gamma, beta))
+        mom = ops.group_moments(idx, dp, N)
+        x1 = ops.GroupedConvBN.apply(fr, dp, idx, mom, wr, gr, br, 1e-5, True, None, csr)
+        x1.backward(go)
+        grads.append([t.grad.clone() for t in (fr, wr, gr, br)])
+    for a, b_ in zip(*grads):
+        assert float((a - b_).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
+    # the gather form is bit-reproducible
+    fr, wr, gr, br = (t.clone().requires_grad_(True) for t in (f, w, gamma, beta))
+    x1 = ops.GroupedConvBN.apply(fr, dp, idx, ops.group_moments(idx, dp, N), wr, gr, br, 1e-5, True, None, (start, edge))
+    x1.backward(go)
+    assert all(torch.equal(a, t.grad) for a, t in zip(grads[1], (fr, wr, gr, br)))
