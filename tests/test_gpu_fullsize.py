@@ -22,8 +22,9 @@ instead of widening the tolerance (tests/test_gpu_model.py's 3e-2):
     parameter (the gradient passes through 17-58 batch-statistics BatchNorms; measured, see the printed table): the
     step is ill-conditioned in fp32, whoever evaluates it.  So the yardstick is the fp64 run ("truth", features and
     weights in double, coordinate-derived inputs as the fp32 values the reference computes): per parameter the GPU's
-    distance to truth must not exceed NOISE_FACTOR x the CPU-fp32 run's distance to truth (+ 2e-4 of the norm).  A
-    wrong term in any backward kernel moves its parameters by O(1), orders above that band.
+    distance to truth must not exceed NOISE_FACTOR x the CPU-fp32 run's distance to truth (floored at half the largest
+    such distance of the run; + 2e-4 of the norm).  A wrong term in any backward kernel moves its parameters by O(1),
+    orders above that band.
 No fixture covers these sizes (the reference cannot run here at all: CUDA-only natives); the oracle itself is pinned
 at small sizes by tests/test_oracle_model.py -- parity at these sizes is unpinned by the reference in that sense.
 """
@@ -152,8 +153,11 @@ def _compare(got, want, mm):
     for ratio, dg, dc, k in rows[:4]:
         print(f"   {dg:.2e} | {dc:.2e}   x{ratio:.2f}  {k}")
     print(f"   largest CPU-fp32 distance: {max(r[2] for r in rows):.2e}; largest GPU distance: {max(r[1] for r in rows):.2e}")
+    # per parameter the CPU's own distance is one random draw of the rounding noise: the band is NOISE_FACTOR x that draw,
+    # but never narrower than NOISE_FACTOR x half the largest CPU distance of this run (the noise LEVEL of the step)
+    floor = 0.5 * max(r[2] for r in rows)
     for ratio, dg, dc, k in rows:
-        assert dg <= NOISE_FACTOR * dc + 2e-4, (k, dg, dc)
+        assert dg <= NOISE_FACTOR * max(dc, floor) + 2e-4, (k, dg, dc, floor)
 
 
 @pytest.mark.parametrize("B", [2, 8])
@@ -163,7 +167,10 @@ def test_cfg2_pointnext_s_24000(B):
     _compare(got, want, False)
     # the paths bench.py times at this size
     assert calls.get("sa_tail_forward", 0) == 1 and calls.get("sa_tail_backward", 0) == 1, calls
-    assert calls.get("grouped_conv_forward", 0) >= 2 and calls.get("pointwise_conv_forward", 0) >= 5, calls
+    # every SetAbstraction: first conv + BN + ReLU convolved before the gather (GroupedConvBN), gather-based backward
+    assert calls.get("grouped_conv_bn_forward", 0) == 4 and calls.get("grouped_conv_bn_backward", 0) == 4, calls
+    assert calls.get("group_csr", 0) == 4 and calls.get("grouped_conv_forward", 0) == 0 and calls.get("group_points_grad", 0) == 0, calls
+    assert calls.get("group_points", 0) == calls.get("ball_query", 0) and calls.get("pointwise_conv_forward", 0) >= 9, calls
     assert calls.get("contrast_forward", 0) == 4 and calls.get("cross_entropy_forward", 0) == 1, calls
     lib = _lib.load()
     assert lib.amc3d_knnquery_uses_grid(B * 24000, 24, B * 24000, 1) == 1  # the loss's stage-0 k-NN runs on the cell grid
