@@ -60,19 +60,19 @@ SIGNATURES = {
     "amc3d_group_moments_bytes": (_sz, [_i, _i]),
     "amc3d_group_moments": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_local_aggregation_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "amc3d_local_aggregation_forward": (_i, [_i] * 7 + [_f, _f] + [_vp] * 19 + [_sz, _vp]),
-    "amc3d_local_aggregation_backward": (_i, [_i] * 6 + [_vp] * 18 + [_sz, _vp]),
+    "amc3d_local_aggregation_forward": (_i, [_i] * 7 + [_f, _f] + [_vp] * 18 + [_i, _vp, _vp, _sz, _vp]),
+    "amc3d_local_aggregation_backward": (_i, [_i] * 6 + [_vp] * 17 + [_i, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_pointwise_conv_forward_bf16": (_i, [_i, _i, _i, _l, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_pointwise_conv_workspace_bytes_bf16": (_sz, [_i, _i, _i, _l]),
     "amc3d_pointwise_conv_backward_bf16": (_i, [_i, _i, _i, _l, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_grouped_conv_bn_supported": (_i, [_i, _i]),
-    "amc3d_grouped_conv_bn_forward": (_i, [_i] * 7 + [_f, _f] + [_vp] * 17 + [_sz, _vp]),
-    "amc3d_grouped_conv_bn_backward": (_i, [_i] * 6 + [_vp] * 16 + [_sz, _vp]),
+    "amc3d_grouped_conv_bn_forward": (_i, [_i] * 7 + [_f, _f] + [_vp] * 16 + [_i, _vp, _vp, _sz, _vp]),
+    "amc3d_grouped_conv_bn_backward": (_i, [_i] * 6 + [_vp] * 15 + [_i, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_group_csr_workspace_bytes": (_sz, [_i, _i, _i]),
     "amc3d_group_csr": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_group_moments_csr": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_grouped_conv_bn_csr_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "amc3d_grouped_conv_bn_backward_csr": (_i, [_i] * 6 + [_vp] * 17 + [_sz, _vp]),
+    "amc3d_grouped_conv_bn_backward_csr": (_i, [_i] * 6 + [_vp] * 16 + [_i, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_sa_tail_supported": (_i, [_i, _i, _i]),
     "amc3d_sa_tail_pays": (_i, [_i, _i]),
     "amc3d_sa_tail_workspace_bytes": (_sz, [_i, _i, _i, _i]),

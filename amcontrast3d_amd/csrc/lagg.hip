@@ -140,16 +140,21 @@ __global__ __launch_bounds__(256) void lagg_stats_kernel(int C, int n, const flo
 }
 
 // mean / invstd / unbiased variance of y from the partials and the geometry moments; gd[c][3] = sum_n G D (kept for backward)
+// mode 0: everything from this rank's sums.  Statistics over several ranks (torch.nn.SyncBatchNorm semantics,
+// main_AA.py:146-148): mode 1 writes this rank's {sum y, sum y^2} per channel and its position count to sums (2C + 1
+// doubles) for the caller to all-reduce, mode 2 derives mean / invstd from the reduced sums.
 __global__ __launch_bounds__(256) void lagg_stats_finalize_kernel(int C, int nparts, double count, float eps, float momentum,
                                                                   const double *__restrict__ partial, const long long *__restrict__ mom,
                                                                   const float *__restrict__ w_dp, float *__restrict__ mean,
                                                                   float *__restrict__ invstd, float *__restrict__ var_unbiased,
                                                                   double *__restrict__ gd, float *__restrict__ running_mean,
-                                                                  float *__restrict__ running_var, long long *__restrict__ tracked)
+                                                                  float *__restrict__ running_var, long long *__restrict__ tracked,
+                                                                  int mode, double *__restrict__ sums)
 {
     __shared__ double red[4][5];
     const int c = blockIdx.x;
     double a[5] = {0, 0, 0, 0, 0};
+    if (mode == 2) nparts = 0;
     for (int k = threadIdx.x; k < nparts; k += 256) {
         const double *p = partial + ((size_t)k * C + c) * 5;
 #pragma unroll
@@ -172,15 +177,21 @@ __global__ __launch_bounds__(256) void lagg_stats_finalize_kernel(int C, int npa
     const double w0 = w_dp[c * 3 + 0], w1 = w_dp[c * 3 + 1], w2 = w_dp[c * 3 + 2];
     const double sy = a[0] + w0 * m[0] + w1 * m[1] + w2 * m[2];
     const double quad = w0 * w0 * m[3] + w1 * w1 * m[6] + w2 * w2 * m[8] + 2.0 * (w0 * w1 * m[4] + w0 * w2 * m[5] + w1 * w2 * m[7]);
-    const double sy2 = a[1] + 2.0 * (w0 * a[2] + w1 * a[3] + w2 * a[4]) + quad;
-    const double mu = sy / count;
+    double sy2 = a[1] + 2.0 * (w0 * a[2] + w1 * a[3] + w2 * a[4]) + quad, sy1 = sy;
+    if (mode != 2) { gd[c * 3 + 0] = a[2]; gd[c * 3 + 1] = a[3]; gd[c * 3 + 2] = a[4]; }
+    if (mode == 1) {
+        sums[2 * c] = sy1; sums[2 * c + 1] = sy2;
+        if (c == 0) sums[2 * C] = count;
+        return;
+    }
+    if (mode == 2) { sy1 = sums[2 * c]; sy2 = sums[2 * c + 1]; count = sums[2 * C]; }
+    const double mu = sy1 / count;
     double var = sy2 / count - mu * mu;
     if (var < 0.0) var = 0.0;
     const float mf = (float)mu, vu = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
     mean[c] = mf;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
     var_unbiased[c] = vu;
-    gd[c * 3 + 0] = a[2]; gd[c * 3 + 1] = a[3]; gd[c * 3 + 2] = a[4];
     if (running_mean && momentum >= 0.f) {
         running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * mf;
         running_var[c] = running_var[c] * (1.f - momentum) + momentum * vu;
@@ -372,16 +383,21 @@ __global__ __launch_bounds__(256) void lagg_bwd_scatter_kernel(int C, int n, int
 }
 
 // dgamma, dbeta, dW_dp and the per-channel coefficients of dG: coef[c] = {g*is, ma, mb*is, mu}
-__global__ __launch_bounds__(256) void lagg_bwd_finalize_kernel(int C, int nparts, double count, const double *__restrict__ partial,
+// mode 0: one rank.  mode 1: reduce this rank's partials, publish {sum dq, sum dq xhat} to dsums (2C doubles) for the
+// all-reduce, keep the five local sums in partial slot 0; mode 2: coefficients from the reduced dsums and the global count
+// (*count_dev), dW_dp from the local sums (parameter gradients stay rank-local, as torch's SyncBatchNorm leaves them)
+__global__ __launch_bounds__(256) void lagg_bwd_finalize_kernel(int C, int nparts, double count, double *__restrict__ partial,
                                                                 const long long *__restrict__ mom, const double *__restrict__ gd,
                                                                 const float *__restrict__ w_dp, const float *__restrict__ mean,
                                                                 const float *__restrict__ invstd, const float *__restrict__ gamma,
                                                                 float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                                float *__restrict__ dw_dp, float *__restrict__ coef)
+                                                                float *__restrict__ dw_dp, float *__restrict__ coef, int mode,
+                                                                double *__restrict__ dsums, const double *__restrict__ count_dev)
 {
     __shared__ double red[4][5];
     const int c = blockIdx.x;
     double a[5] = {0, 0, 0, 0, 0};
+    if (mode == 2) nparts = 1;  // slot 0 holds this rank's reduced sums
     for (int k = threadIdx.x; k < nparts; k += 256) {
         const double *p = partial + ((size_t)k * C + c) * 5;
 #pragma unroll
@@ -403,9 +419,16 @@ __global__ __launch_bounds__(256) void lagg_bwd_finalize_kernel(int C, int npart
     for (int j = 0; j < 9; ++j) m[j] = (double)mom[j] * (1.0 / LAGG_FX_M);
     const double S2[3][3] = {{m[3], m[4], m[5]}, {m[4], m[6], m[7]}, {m[5], m[7], m[8]}};
     const double mu = mean[c], is = invstd[c], g = gamma[c];
-    const double ma = a[0] / count, mb = a[1] / count, gi = g * is;
-    dbeta[c] = (float)a[0];
-    dgamma[c] = (float)a[1];
+    if (mode != 2) { dbeta[c] = (float)a[0]; dgamma[c] = (float)a[1]; }
+    if (mode == 1) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) partial[(size_t)c * 5 + j] = a[j];
+        dsums[2 * c] = a[0]; dsums[2 * c + 1] = a[1];
+        return;
+    }
+    double sa = a[0], sb = a[1];
+    if (mode == 2) { sa = dsums[2 * c]; sb = dsums[2 * c + 1]; count = *count_dev; }
+    const double ma = sa / count, mb = sb / count, gi = g * is;
     const double w[3] = {w_dp[c * 3 + 0], w_dp[c * 3 + 1], w_dp[c * 3 + 2]};
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -689,9 +712,10 @@ AMC_API int amc3d_local_aggregation_forward(int b, int cout, int n, int npoints,
                                             const float *w_dp, const void *moments, const float *gamma, const float *beta,
                                             float *g_pm, float *pooled, unsigned char *arg, float *ystar, float *mean,
                                             float *invstd, float *var_unbiased, double *gd, float *running_mean,
-                                            float *running_var, long long *num_batches_tracked, void *workspace,
-                                            size_t workspace_bytes, void *stream_)
+                                            float *running_var, long long *num_batches_tracked, int phase, double *sums,
+                                            void *workspace, size_t workspace_bytes, void *stream_)
 {
+    if (training && phase != 0 && !sums) return bad_arg("amc3d_local_aggregation_forward: phase 1 / 2 need the sums buffer");
     if (b <= 0 || npoints <= 0) return 0;
     if (!lagg_supported(cout, nsample) || n <= 0 || !g_cm || !idx || !dp || !w_dp || !gamma || !beta || !g_pm || !pooled || !arg ||
         !ystar || !mean || !invstd || (training && (!moments || !var_unbiased || !gd || !workspace ||
@@ -704,11 +728,13 @@ AMC_API int amc3d_local_aggregation_forward(int b, int cout, int n, int npoints,
     const int nparts_b = div_up(div_up(n, LAGG_NT), LAGG_TILES);
     double *partial = (double *)workspace;
     if (training) {
-        hipLaunchKernelGGL(lagg_stats_kernel, dim3(nparts_b, div_up(cout, 64), b), dim3(256), 0, stream, cout, n, g_cm, g_pm, gm,
-                           partial, nparts_b);
+        if (phase != 2)
+            hipLaunchKernelGGL(lagg_stats_kernel, dim3(nparts_b, div_up(cout, 64), b), dim3(256), 0, stream, cout, n, g_cm, g_pm, gm,
+                               partial, nparts_b);
         hipLaunchKernelGGL(lagg_stats_finalize_kernel, dim3(cout), dim3(256), 0, stream, cout, nparts_b * b,
                            (double)b * (double)npoints * (double)nsample, eps, momentum, (const double *)partial, gm.mom, w_dp,
-                           mean, invstd, var_unbiased, gd, running_mean, running_var, num_batches_tracked);
+                           mean, invstd, var_unbiased, gd, running_mean, running_var, num_batches_tracked, phase, sums);
+        if (phase == 1) return launch_status("amc3d_local_aggregation_forward");
     } else {
         // eval mode: only the point-major copy is needed
         if (int st = amc3d_transpose_cn(b, cout, n, g_cm, g_pm, stream_)) return st;
@@ -727,10 +753,11 @@ AMC_API int amc3d_local_aggregation_backward(int b, int cout, int n, int npoints
                                              const float *ystar, const unsigned char *arg, const float *g_pm, const int *idx,
                                              const float *dp, const float *w_dp, const void *moments, const double *gd,
                                              const float *mean, const float *invstd, const float *gamma, const float *beta,
-                                             float *dg_cm, float *dw_dp, float *dgamma, float *dbeta, void *workspace,
-                                             size_t workspace_bytes, void *stream_)
+                                             float *dg_cm, float *dw_dp, float *dgamma, float *dbeta, int phase, double *dsums,
+                                             const double *count_dev, void *workspace, size_t workspace_bytes, void *stream_)
 {
     if (b <= 0 || npoints <= 0) return 0;
+    if (phase != 0 && (!dsums || (phase == 2 && !count_dev))) return bad_arg("amc3d_local_aggregation_backward: phase 1 / 2 need dsums (and the count)");
     if (!lagg_supported(cout, nsample) || n <= 0 || !dpooled || !ystar || !arg || !g_pm || !idx || !dp || !w_dp || !moments || !gd ||
         !mean || !invstd || !gamma || !beta || !dg_cm || !dw_dp || !dgamma || !dbeta || !workspace ||
         workspace_bytes < amc3d_local_aggregation_workspace_bytes(b, cout, n, npoints))
@@ -740,17 +767,20 @@ AMC_API int amc3d_local_aggregation_backward(int b, int cout, int n, int npoints
     double *partial = (double *)workspace;
     float *Q = (float *)((char *)workspace + lagg_partial_bytes(b, cout, n, npoints));
     float *coef = Q + (size_t)b * n * cout;
-    if (int st = fill_i32((int *)Q, 0, (size_t)b * n * cout, stream)) return st;
     const int ct = cout < LAGG_CT ? cout : LAGG_CT;
     const int nparts_b = div_up(div_up(npoints, LAGG_MT), LAGG_TILES);
-    size_t lds = (size_t)3 * ct * (LAGG_MT + 1) * sizeof(float);
-    const size_t red = (size_t)4 * ct * 5 * sizeof(double);
-    if (lds < red) lds = red;
-    hipLaunchKernelGGL(lagg_bwd_scatter_kernel, dim3(nparts_b, cout / ct, b), dim3(256), lds, stream, cout, n, npoints, nsample,
-                       relu, dpooled, ystar, arg, idx, dp, mean, invstd, gamma, beta, Q, partial, nparts_b);
+    if (phase != 2) {
+        if (int st = fill_i32((int *)Q, 0, (size_t)b * n * cout, stream)) return st;
+        size_t lds = (size_t)3 * ct * (LAGG_MT + 1) * sizeof(float);
+        const size_t red = (size_t)4 * ct * 5 * sizeof(double);
+        if (lds < red) lds = red;
+        hipLaunchKernelGGL(lagg_bwd_scatter_kernel, dim3(nparts_b, cout / ct, b), dim3(256), lds, stream, cout, n, npoints, nsample,
+                           relu, dpooled, ystar, arg, idx, dp, mean, invstd, gamma, beta, Q, partial, nparts_b);
+    }
     hipLaunchKernelGGL(lagg_bwd_finalize_kernel, dim3(cout), dim3(256), 0, stream, cout, nparts_b * b,
-                       (double)b * (double)npoints * (double)nsample, (const double *)partial, gm.mom, gd, w_dp, mean, invstd,
-                       gamma, dgamma, dbeta, dw_dp, coef);
+                       (double)b * (double)npoints * (double)nsample, partial, gm.mom, gd, w_dp, mean, invstd,
+                       gamma, dgamma, dbeta, dw_dp, coef, phase, dsums, count_dev);
+    if (phase == 1) return launch_status("amc3d_local_aggregation_backward");
     hipLaunchKernelGGL(lagg_bwd_apply_kernel, dim3(div_up(n, LAGG_NT), div_up(cout, 64), b), dim3(256), 0, stream, cout, n,
                        (const float *)Q, g_pm, gm, w_dp, (const float *)coef, dg_cm);
     return launch_status("amc3d_local_aggregation_backward");
@@ -764,9 +794,10 @@ AMC_API int amc3d_grouped_conv_bn_forward(int b, int cout, int n, int npoints, i
                                           float momentum, const float *g_cm, const int *idx, const float *dp, const float *w_dp,
                                           const void *moments, const float *gamma, const float *beta, float *g_pm, float *x1,
                                           float *mean, float *invstd, float *var_unbiased, double *gd, float *running_mean,
-                                          float *running_var, long long *num_batches_tracked, void *workspace,
-                                          size_t workspace_bytes, void *stream_)
+                                          float *running_var, long long *num_batches_tracked, int phase, double *sums,
+                                          void *workspace, size_t workspace_bytes, void *stream_)
 {
+    if (training && phase != 0 && !sums) return bad_arg("amc3d_grouped_conv_bn_forward: phase 1 / 2 need the sums buffer");
     if (b <= 0 || npoints <= 0) return 0;
     if (!lagg_expand_supported(cout, nsample) || n <= 0 || !g_cm || !idx || !dp || !w_dp || !gamma || !beta || !g_pm || !x1 ||
         !mean || !invstd || (training && (!moments || !var_unbiased || !gd || !workspace ||
@@ -778,11 +809,13 @@ AMC_API int amc3d_grouped_conv_bn_forward(int b, int cout, int n, int npoints, i
     if (moments) gm = lagg_views(moments, b, n);
     const int nparts_b = div_up(div_up(n, LAGG_NT), LAGG_TILES);
     if (training) {
-        hipLaunchKernelGGL(lagg_stats_kernel, dim3(nparts_b, div_up(cout, 64), b), dim3(256), 0, stream, cout, n, g_cm, g_pm, gm,
-                           (double *)workspace, nparts_b);
+        if (phase != 2)
+            hipLaunchKernelGGL(lagg_stats_kernel, dim3(nparts_b, div_up(cout, 64), b), dim3(256), 0, stream, cout, n, g_cm, g_pm, gm,
+                               (double *)workspace, nparts_b);
         hipLaunchKernelGGL(lagg_stats_finalize_kernel, dim3(cout), dim3(256), 0, stream, cout, nparts_b * b,
                            (double)b * (double)npoints * (double)nsample, eps, momentum, (const double *)workspace, gm.mom, w_dp,
-                           mean, invstd, var_unbiased, gd, running_mean, running_var, num_batches_tracked);
+                           mean, invstd, var_unbiased, gd, running_mean, running_var, num_batches_tracked, phase, sums);
+        if (phase == 1) return launch_status("amc3d_grouped_conv_bn_forward");
     } else if (int st = amc3d_transpose_cn(b, cout, n, g_cm, g_pm, stream_)) {
         return st;
     }
@@ -801,9 +834,11 @@ AMC_API int amc3d_grouped_conv_bn_backward(int b, int cout, int n, int npoints, 
                                            const float *g_pm, const int *idx, const float *dp, const float *w_dp,
                                            const void *moments, const double *gd, const float *mean, const float *invstd,
                                            const float *gamma, const float *beta, float *dg_cm, float *dw_dp, float *dgamma,
-                                           float *dbeta, void *workspace, size_t workspace_bytes, void *stream_)
+                                           float *dbeta, int phase, double *dsums, const double *count_dev, void *workspace,
+                                           size_t workspace_bytes, void *stream_)
 {
     if (b <= 0 || npoints <= 0) return 0;
+    if (phase != 0 && (!dsums || (phase == 2 && !count_dev))) return bad_arg("amc3d_grouped_conv_bn_backward: phase 1 / 2 need dsums (and the count)");
     if (!lagg_expand_supported(cout, nsample) || n <= 0 || !dx1 || !g_pm || !idx || !dp || !w_dp || !moments || !gd || !mean ||
         !invstd || !gamma || !beta || !dg_cm || !dw_dp || !dgamma || !dbeta || !workspace ||
         workspace_bytes < amc3d_local_aggregation_workspace_bytes(b, cout, n, npoints))
@@ -813,19 +848,22 @@ AMC_API int amc3d_grouped_conv_bn_backward(int b, int cout, int n, int npoints, 
     double *partial = (double *)workspace;
     float *Q = (float *)((char *)workspace + lagg_partial_bytes(b, cout, n, npoints));
     float *coef = Q + (size_t)b * n * cout;
-    if (int st = fill_i32((int *)Q, 0, (size_t)b * n * cout, stream)) return st;
     const long P = (long)npoints * nsample;
     const int ct = cout < LAGG_XC ? cout : LAGG_XC;
     const int ctiles = 2;  // tiles per workgroup (1, 2, 4 measured alike: the kernel runs at the float-atomic rate)
     const int nparts_b = div_up(div_up(P, LAGG_PT), ctiles);
+    if (phase != 2) {
+    if (int st = fill_i32((int *)Q, 0, (size_t)b * n * cout, stream)) return st;
 #define AMC_COLLAPSE(L)                                                                                                        \
     hipLaunchKernelGGL(lagg_collapse_kernel<L>, dim3(nparts_b, cout / ct, b), dim3(256), 0, stream, cout, n, P, relu, dx1, g_pm,  \
                        idx, dp, w_dp, mean, invstd, gamma, beta, Q, partial, nparts_b, ctiles)
     switch (ct / 4) { case 2: AMC_COLLAPSE(2); break; case 4: AMC_COLLAPSE(4); break; case 8: AMC_COLLAPSE(8); break; default: AMC_COLLAPSE(16); }
 #undef AMC_COLLAPSE
+    }
     hipLaunchKernelGGL(lagg_bwd_finalize_kernel, dim3(cout), dim3(256), 0, stream, cout, nparts_b * b,
-                       (double)b * (double)npoints * (double)nsample, (const double *)partial, gm.mom, gd, w_dp, mean, invstd,
-                       gamma, dgamma, dbeta, dw_dp, coef);
+                       (double)b * (double)npoints * (double)nsample, partial, gm.mom, gd, w_dp, mean, invstd,
+                       gamma, dgamma, dbeta, dw_dp, coef, phase, dsums, count_dev);
+    if (phase == 1) return launch_status("amc3d_grouped_conv_bn_backward");
     hipLaunchKernelGGL(lagg_bwd_apply_kernel, dim3(div_up(n, LAGG_NT), div_up(cout, 64), b), dim3(256), 0, stream, cout, n,
                        (const float *)Q, g_pm, gm, w_dp, (const float *)coef, dg_cm);
     return launch_status("amc3d_grouped_conv_bn_backward");
@@ -855,10 +893,11 @@ AMC_API int amc3d_grouped_conv_bn_backward_csr(int b, int cout, int n, int npoin
                                                const float *g_pm, const int *rev_start, const int *rev_edge, const float *dp,
                                                const float *w_dp, const void *moments, const double *gd, const float *mean,
                                                const float *invstd, const float *gamma, const float *beta, float *dg_cm,
-                                               float *dw_dp, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
-                                               void *stream_)
+                                               float *dw_dp, float *dgamma, float *dbeta, int phase, double *dsums,
+                                               const double *count_dev, void *workspace, size_t workspace_bytes, void *stream_)
 {
     if (b <= 0 || npoints <= 0) return 0;
+    if (phase != 0 && (!dsums || (phase == 2 && !count_dev))) return bad_arg("amc3d_grouped_conv_bn_backward_csr: phase 1 / 2 need dsums (and the count)");
     if (!lagg_expand_supported(cout, nsample) || n <= 0 || !dx1 || !g_pm || !rev_start || !rev_edge || !dp || !w_dp || !moments ||
         !gd || !mean || !invstd || !gamma || !beta || !dg_cm || !dw_dp || !dgamma || !dbeta || !workspace ||
         workspace_bytes < amc3d_grouped_conv_bn_csr_workspace_bytes(b, cout, n, npoints, nsample))
@@ -874,14 +913,17 @@ AMC_API int amc3d_grouped_conv_bn_backward_csr(int b, int cout, int n, int npoin
     const long P = (long)npoints * nsample;
     // (b, cout, P) -> (b, P, cout)
     if (P >= (1L << 31)) return bad_arg("amc3d_grouped_conv_bn_backward_csr: too many positions");
-    if (int st = amc3d_transpose_cn(b, cout, (int)P, dx1, dx1_pm, stream_)) return st;
-    int nparts = 0;
-    if (int st = csr_collapse(b, cout, n, npoints, nsample, relu, dx1_pm, g_pm, rev_start, rev_edge, dp, w_dp, mean, invstd, gamma,
-                              beta, Q, partial, &nparts, stream))
-        return st;
+    int nparts = (int)parts;
+    if (phase != 2) {
+        if (int st = amc3d_transpose_cn(b, cout, (int)P, dx1, dx1_pm, stream_)) return st;
+        if (int st = csr_collapse(b, cout, n, npoints, nsample, relu, dx1_pm, g_pm, rev_start, rev_edge, dp, w_dp, mean, invstd,
+                                  gamma, beta, Q, partial, &nparts, stream))
+            return st;
+    }
     hipLaunchKernelGGL(lagg_bwd_finalize_kernel, dim3(cout), dim3(256), 0, stream, cout, nparts,
-                       (double)b * (double)npoints * (double)nsample, (const double *)partial, gm.mom, gd, w_dp, mean, invstd,
-                       gamma, dgamma, dbeta, dw_dp, coef);
+                       (double)b * (double)npoints * (double)nsample, partial, gm.mom, gd, w_dp, mean, invstd,
+                       gamma, dgamma, dbeta, dw_dp, coef, phase, dsums, count_dev);
+    if (phase == 1) return launch_status("amc3d_grouped_conv_bn_backward_csr");
     hipLaunchKernelGGL(lagg_bwd_apply_kernel, dim3(div_up(n, LAGG_NT), div_up(cout, 64), b), dim3(256), 0, stream, cout, n,
                        (const float *)Q, g_pm, gm, w_dp, (const float *)coef, dg_cm);
     return launch_status("amc3d_grouped_conv_bn_backward_csr");

@@ -286,9 +286,11 @@ def fused_local_aggregation(blocks, f, geom, feature_type):
     relu = len(blk) == 3
     if _eval_bn(bn, f):
         return ops.local_aggregation_eval(f, geom['dp'], idx, conv.weight, bn, relu)
-    if not _fusable_bn(bn, f):
+    group = _synced_bn_group(bn, f)  # nn.SyncBatchNorm over several ranks: the statistics are exchanged between two phases
+    if group is None and not _fusable_bn(bn, f):
         return None
-    return ops.LocalAggregationFused.apply(f, geom['dp'], idx, geom['mom'], conv.weight, bn.weight, bn.bias, bn.eps, relu, bn)
+    return ops.LocalAggregationFused.apply(f, geom['dp'], idx, geom['mom'], conv.weight, bn.weight, bn.bias, bn.eps, relu, bn,
+                                           group)
 
 
 def fused_first_block(blocks, f, geom, feature_type):
@@ -312,12 +314,14 @@ def fused_first_block(blocks, f, geom, feature_type):
         return None
     if _eval_bn(bn, f):
         return ops.grouped_conv_bn_eval(f, geom['dp'], idx, conv.weight, bn, True)
-    if not _fusable_bn(bn, f):
+    group = _synced_bn_group(bn, f)
+    if group is None and not _fusable_bn(bn, f):
         return None
     csr = geom.get('csr')
     if csr is not None:
         csr = (csr['start'], csr['edge'])
-    return ops.GroupedConvBN.apply(f, geom['dp'], idx, geom['mom'], conv.weight, bn.weight, bn.bias, bn.eps, True, bn, csr)
+    return ops.GroupedConvBN.apply(f, geom['dp'], idx, geom['mom'], conv.weight, bn.weight, bn.bias, bn.eps, True, bn, csr,
+                                   group)
 
 
 def _sa_tail_activated(mods, x1, pool_max):

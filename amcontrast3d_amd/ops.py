@@ -864,15 +864,23 @@ def group_moments_csr(idx, dp, n_support, csr):
     return out
 
 
+def _sync(group, buf):
+    """all-reduce of a statistics buffer between the two phases of a layer: eager, between captured graph segments"""
+    import torch.distributed as dist
+    from . import graphs
+    graphs.collective(lambda: dist.all_reduce(buf, group=group))
+
+
 class LocalAggregationFused(Function):
     """pooled (B,C,M) = max_k [relu](bn(conv1x1([dp ; f[idx]]))) -- grouping_operation + cat + Conv2d + BatchNorm2d (batch
     statistics) [+ ReLU] + max of LocalAggregation / single-layer SetAbstraction (pointnext_AA.py:57-63, 139-170) -- with
     the conv applied to the N source points BEFORE the gather:  W.[dp ; f[idx]] = (W_f.f)[idx] + W_dp.dp.
     f (B,Cin,N) fp32, dp (B,3,M,K), idx (B,M,K) int32, moments = group_moments(idx, dp, N), weight (C,Cin+3,1,1),
-    `bn`: the nn.BatchNorm2d whose running buffers are updated (None: no update)."""
+    `bn`: the nn.BatchNorm2d whose running buffers are updated (None: no update); `group`: a process group over which the
+    statistics are taken (nn.SyncBatchNorm semantics: one all-reduce of 2C+1 doubles forward, 2C backward), or None."""
 
     @staticmethod
-    def forward(ctx, f, dp, idx, moments, weight, gamma, beta, eps, relu, bn=None):
+    def forward(ctx, f, dp, idx, moments, weight, gamma, beta, eps, relu, bn=None, group=None):
         _need_gpu(f, dp, idx, moments, weight, gamma, beta)
         _need_dtype(torch.float32, f=f, dp=dp, weight=weight)
         _need_dtype(torch.int32, idx=idx)
@@ -893,31 +901,42 @@ class LocalAggregationFused(Function):
         mean = torch.empty(C, dtype=torch.float32, device=dev)
         invstd, var_u = torch.empty_like(mean), torch.empty_like(mean)
         gd = torch.empty(C, 3, dtype=torch.float64, device=dev)
+        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
         wb = int(lib.amc3d_local_aggregation_workspace_bytes(B, C, N, M))
         work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
         mom, rm, rv, nbt = _bn_running_args(bn)
         ctx.bf16 = mixed_precision() and min(Cin, C) >= 64 and B * N >= 4096  # the conv on the source points on the bf16 MFMA
+
+        def call(phase):
+            _lib.check(lib.amc3d_local_aggregation_forward(
+                B, C, N, M, K, 1, int(bool(relu)), float(eps), mom, _ptr(g_cm), _ptr(idx), _ptr(dp), _ptr(w_dp),
+                _ptr(moments), _ptr(gamma), _ptr(beta), _ptr(g_pm), _ptr(pooled), _ptr(arg), _ptr(ystar), _ptr(mean),
+                _ptr(invstd), _ptr(var_u), _ptr(gd), rm, rv, nbt, phase, _ptr(sums), _ptr(work), wb, _stream(f)),
+                "local_aggregation_forward")
+
         with torch.cuda.device(dev):
             with timing.span("pointwise_conv_forward", 4 * B * N * (Cin + C), 2.0 * B * N * Cin * C):
                 _lib.check(_pw(lib, ctx.bf16)[0](B, Cin, C, N, _ptr(f), _ptr(w_f), None, _ptr(g_cm), _stream(f)),
                            "pointwise_conv_forward")
             # algorithmic bytes: G read (statistics) + the gathered rows, idx, dp + the pooled outputs
             with timing.span("local_aggregation_forward", 8 * B * N * C + B * M * K * (4 * C + 16) + 9 * B * M * C):
-                _lib.check(lib.amc3d_local_aggregation_forward(
-                    B, C, N, M, K, 1, int(bool(relu)), float(eps), mom, _ptr(g_cm), _ptr(idx), _ptr(dp), _ptr(w_dp),
-                    _ptr(moments), _ptr(gamma), _ptr(beta), _ptr(g_pm), _ptr(pooled), _ptr(arg), _ptr(ystar), _ptr(mean),
-                    _ptr(invstd), _ptr(var_u), _ptr(gd), rm, rv, nbt, _ptr(work), wb, _stream(f)), "local_aggregation_forward")
+                if group is None:
+                    call(0)
+                else:
+                    call(1)
+                    _sync(group, sums)
+                    call(2)
         if bn is not None and bn.track_running_stats and bn.running_mean is not None and bn.momentum is None:
             bn_update_running(bn, mean, var_u)  # cumulative average: its own launch
-        ctx.save_for_backward(f, w_f, w_dp, g_pm, idx, dp, moments, gamma, beta, mean, invstd, gd, ystar, arg)
-        ctx.relu, ctx.wshape = bool(relu), tuple(weight.shape)
+        ctx.save_for_backward(f, w_f, w_dp, g_pm, idx, dp, moments, gamma, beta, mean, invstd, gd, ystar, arg, sums)
+        ctx.relu, ctx.wshape, ctx.group = bool(relu), tuple(weight.shape), group
         if _pool_log is not None:
             _pool_log[_next_pool_seq()] = arg
         return pooled
 
     @staticmethod
     def backward(ctx, dpooled):
-        f, w_f, w_dp, g_pm, idx, dp, moments, gamma, beta, mean, invstd, gd, ystar, arg = ctx.saved_tensors
+        f, w_f, w_dp, g_pm, idx, dp, moments, gamma, beta, mean, invstd, gd, ystar, arg, sums = ctx.saved_tensors
         B, Cin, N = f.shape
         _, M, K = idx.shape
         C = w_f.shape[0]
@@ -927,6 +946,8 @@ class LocalAggregationFused(Function):
         dg_cm = torch.empty(B, C, N, dtype=torch.float32, device=dev)
         dw_dp = torch.empty(C, 3, dtype=torch.float32, device=dev)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        dsums = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        count = ctypes.c_void_p(sums.data_ptr() + 16 * C)
         wb = int(lib.amc3d_local_aggregation_workspace_bytes(B, C, N, M))
         work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
         need_f = ctx.needs_input_grad[0]
@@ -935,28 +956,39 @@ class LocalAggregationFused(Function):
         _, pw_wbytes, pw_bwd = _pw(lib, ctx.bf16)
         wb2 = int(pw_wbytes(B, Cin, C, N))
         work2 = torch.empty(max(wb2, 4), dtype=torch.uint8, device=dev)
+
+        def call(phase):
+            _lib.check(lib.amc3d_local_aggregation_backward(
+                B, C, N, M, K, int(ctx.relu), _ptr(dpooled), _ptr(ystar), _ptr(arg), _ptr(g_pm), _ptr(idx), _ptr(dp),
+                _ptr(w_dp), _ptr(moments), _ptr(gd), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dg_cm),
+                _ptr(dw_dp), _ptr(dgamma), _ptr(dbeta), phase, _ptr(dsums), count, _ptr(work), wb, _stream(f)),
+                "local_aggregation_backward")
+
         with torch.cuda.device(dev):
             with timing.span("local_aggregation_backward", 17 * B * M * C + 12 * B * N * C):
-                _lib.check(lib.amc3d_local_aggregation_backward(
-                    B, C, N, M, K, int(ctx.relu), _ptr(dpooled), _ptr(ystar), _ptr(arg), _ptr(g_pm), _ptr(idx), _ptr(dp),
-                    _ptr(w_dp), _ptr(moments), _ptr(gd), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dg_cm),
-                    _ptr(dw_dp), _ptr(dgamma), _ptr(dbeta), _ptr(work), wb, _stream(f)), "local_aggregation_backward")
+                if ctx.group is None:
+                    call(0)
+                else:
+                    call(1)
+                    _sync(ctx.group, dsums)
+                    call(2)
             with timing.span("pointwise_conv_backward", 4 * B * N * (Cin + C) * (1 + int(need_f)),
                              2.0 * B * N * Cin * C * (1 + int(need_f))):
                 _lib.check(pw_bwd(B, Cin, C, N, _ptr(f), _ptr(w_f), _ptr(dg_cm), _ptr(df) if need_f else None, _ptr(dw_f),
                                   _ptr(work2), wb2, _stream(f)), "pointwise_conv_backward")
         dw = torch.cat((dw_dp, dw_f), dim=1).view(ctx.wshape)
-        return df, None, None, None, dw, dgamma, dbeta, None, None, None
+        return df, None, None, None, dw, dgamma, dbeta, None, None, None, None
 
 
 class GroupedConvBN(Function):
     """x1 (B,C,M,32) = [relu](bn(conv1x1([dp ; f[idx]]))) -- the FIRST block of a multi-layer SetAbstraction MLP
     (PointNeXt-S: sa_layers = 2; pointnext_AA.py:104-127, 164-166) convolved before the gather like LocalAggregationFused,
     but with the activation materialised for the blocks that follow.  Backward: one pass over dx1 (csrc/lagg.hip
-    lagg_collapse_kernel) instead of BatchNorm-backward statistics + apply + the conv's two backward products."""
+    lagg_collapse_kernel, or csrc/csr.hip over reverse edge lists when `csr` is given) instead of BatchNorm-backward
+    statistics + apply + the conv's two backward products.  `group`: statistics over a process group (SyncBatchNorm)."""
 
     @staticmethod
-    def forward(ctx, f, dp, idx, moments, weight, gamma, beta, eps, relu, bn=None, csr=None):
+    def forward(ctx, f, dp, idx, moments, weight, gamma, beta, eps, relu, bn=None, csr=None, group=None):
         _need_gpu(f, dp, idx, moments, weight, gamma, beta)
         _need_dtype(torch.float32, f=f, dp=dp, weight=weight)
         _need_dtype(torch.int32, idx=idx)
@@ -976,28 +1008,38 @@ class GroupedConvBN(Function):
         mean = torch.empty(C, dtype=torch.float32, device=dev)
         invstd, var_u = torch.empty_like(mean), torch.empty_like(mean)
         gd = torch.empty(C, 3, dtype=torch.float64, device=dev)
+        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
         wb = int(lib.amc3d_local_aggregation_workspace_bytes(B, C, N, M))
         work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
         mom, rm, rv, nbt = _bn_running_args(bn)
         ctx.bf16 = mixed_precision() and min(Cin, C) >= 64 and B * N >= 4096
+
+        def call(phase):
+            _lib.check(lib.amc3d_grouped_conv_bn_forward(
+                B, C, N, M, K, 1, int(bool(relu)), float(eps), mom, _ptr(g_cm), _ptr(idx), _ptr(dp), _ptr(w_dp),
+                _ptr(moments), _ptr(gamma), _ptr(beta), _ptr(g_pm), _ptr(x1), _ptr(mean), _ptr(invstd), _ptr(var_u),
+                _ptr(gd), rm, rv, nbt, phase, _ptr(sums), _ptr(work), wb, _stream(f)), "grouped_conv_bn_forward")
+
         with torch.cuda.device(dev):
             with timing.span("pointwise_conv_forward", 4 * B * N * (Cin + C), 2.0 * B * N * Cin * C):
                 _lib.check(_pw(lib, ctx.bf16)[0](B, Cin, C, N, _ptr(f), _ptr(w_f), None, _ptr(g_cm), _stream(f)),
                            "pointwise_conv_forward")
             with timing.span("grouped_conv_bn_forward", 8 * B * N * C + B * M * K * (8 * C + 16)):
-                _lib.check(lib.amc3d_grouped_conv_bn_forward(
-                    B, C, N, M, K, 1, int(bool(relu)), float(eps), mom, _ptr(g_cm), _ptr(idx), _ptr(dp), _ptr(w_dp),
-                    _ptr(moments), _ptr(gamma), _ptr(beta), _ptr(g_pm), _ptr(x1), _ptr(mean), _ptr(invstd), _ptr(var_u),
-                    _ptr(gd), rm, rv, nbt, _ptr(work), wb, _stream(f)), "grouped_conv_bn_forward")
+                if group is None:
+                    call(0)
+                else:
+                    call(1)
+                    _sync(group, sums)
+                    call(2)
         if bn is not None and bn.track_running_stats and bn.running_mean is not None and bn.momentum is None:
             bn_update_running(bn, mean, var_u)
-        ctx.save_for_backward(f, w_f, w_dp, g_pm, idx, dp, moments, gamma, beta, mean, invstd, gd)
-        ctx.relu, ctx.wshape = bool(relu), tuple(weight.shape)
+        ctx.save_for_backward(f, w_f, w_dp, g_pm, idx, dp, moments, gamma, beta, mean, invstd, gd, sums)
+        ctx.relu, ctx.wshape, ctx.group = bool(relu), tuple(weight.shape), group
         return x1
 
     @staticmethod
     def backward(ctx, dx1):
-        f, w_f, w_dp, g_pm, idx, dp, moments, gamma, beta, mean, invstd, gd = ctx.saved_tensors
+        f, w_f, w_dp, g_pm, idx, dp, moments, gamma, beta, mean, invstd, gd, sums = ctx.saved_tensors
         B, Cin, N = f.shape
         _, M, K = idx.shape
         C = w_f.shape[0]
@@ -1007,6 +1049,8 @@ class GroupedConvBN(Function):
         dg_cm = torch.empty(B, C, N, dtype=torch.float32, device=dev)
         dw_dp = torch.empty(C, 3, dtype=torch.float32, device=dev)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        dsums = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        count = ctypes.c_void_p(sums.data_ptr() + 16 * C)
         csr = ctx.csr
         wb = int(lib.amc3d_grouped_conv_bn_csr_workspace_bytes(B, C, N, M, K) if csr is not None
                  else lib.amc3d_local_aggregation_workspace_bytes(B, C, N, M))
@@ -1017,24 +1061,34 @@ class GroupedConvBN(Function):
         _, pw_wbytes, pw_bwd = _pw(lib, ctx.bf16)
         wb2 = int(pw_wbytes(B, Cin, C, N))
         work2 = torch.empty(max(wb2, 4), dtype=torch.uint8, device=dev)
+
+        def call(phase):
+            if csr is not None:
+                _lib.check(lib.amc3d_grouped_conv_bn_backward_csr(
+                    B, C, N, M, K, int(ctx.relu), _ptr(dx1), _ptr(g_pm), _ptr(csr[0]), _ptr(csr[1]), _ptr(dp), _ptr(w_dp),
+                    _ptr(moments), _ptr(gd), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dg_cm), _ptr(dw_dp),
+                    _ptr(dgamma), _ptr(dbeta), phase, _ptr(dsums), count, _ptr(work), wb, _stream(f)),
+                    "grouped_conv_bn_backward_csr")
+            else:
+                _lib.check(lib.amc3d_grouped_conv_bn_backward(
+                    B, C, N, M, K, int(ctx.relu), _ptr(dx1), _ptr(g_pm), _ptr(idx), _ptr(dp), _ptr(w_dp), _ptr(moments),
+                    _ptr(gd), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dg_cm), _ptr(dw_dp), _ptr(dgamma),
+                    _ptr(dbeta), phase, _ptr(dsums), count, _ptr(work), wb, _stream(f)), "grouped_conv_bn_backward")
+
         with torch.cuda.device(dev):
             with timing.span("grouped_conv_bn_backward", B * M * K * (8 * C + 16) + 12 * B * N * C):
-                if csr is not None:
-                    _lib.check(lib.amc3d_grouped_conv_bn_backward_csr(
-                        B, C, N, M, K, int(ctx.relu), _ptr(dx1), _ptr(g_pm), _ptr(csr[0]), _ptr(csr[1]), _ptr(dp), _ptr(w_dp),
-                        _ptr(moments), _ptr(gd), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dg_cm), _ptr(dw_dp),
-                        _ptr(dgamma), _ptr(dbeta), _ptr(work), wb, _stream(f)), "grouped_conv_bn_backward_csr")
+                if ctx.group is None:
+                    call(0)
                 else:
-                    _lib.check(lib.amc3d_grouped_conv_bn_backward(
-                        B, C, N, M, K, int(ctx.relu), _ptr(dx1), _ptr(g_pm), _ptr(idx), _ptr(dp), _ptr(w_dp), _ptr(moments),
-                        _ptr(gd), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dg_cm), _ptr(dw_dp), _ptr(dgamma),
-                        _ptr(dbeta), _ptr(work), wb, _stream(f)), "grouped_conv_bn_backward")
+                    call(1)
+                    _sync(ctx.group, dsums)
+                    call(2)
             with timing.span("pointwise_conv_backward", 4 * B * N * (Cin + C) * (1 + int(need_f)),
                              2.0 * B * N * Cin * C * (1 + int(need_f))):
                 _lib.check(pw_bwd(B, Cin, C, N, _ptr(f), _ptr(w_f), _ptr(dg_cm), _ptr(df) if need_f else None, _ptr(dw_f),
                                   _ptr(work2), wb2, _stream(f)), "pointwise_conv_backward")
         dw = torch.cat((dw_dp, dw_f), dim=1).view(ctx.wshape)
-        return df, None, None, None, dw, dgamma, dbeta, None, None, None, None
+        return df, None, None, None, dw, dgamma, dbeta, None, None, None, None, None
 
 
 @torch.no_grad()
@@ -1058,7 +1112,7 @@ def grouped_conv_bn_eval(f, dp, idx, weight, bn, relu):
         _lib.check(lib.amc3d_grouped_conv_bn_forward(
             B, C, N, M, K, 0, int(bool(relu)), float(bn.eps), 0.0, _ptr(g_cm), _ptr(idx), _ptr(dp), _ptr(w_dp), None,
             _ptr(bn.weight), _ptr(bn.bias), _ptr(g_pm), _ptr(x1), _ptr(bn.running_mean), _ptr(invstd), None, None, None,
-            None, None, None, 0, _stream(f)), "grouped_conv_bn_forward")
+            None, None, 0, None, None, 0, _stream(f)), "grouped_conv_bn_forward")
     return x1
 
 
@@ -1089,7 +1143,7 @@ def local_aggregation_eval(f, dp, idx, weight, bn, relu):
         _lib.check(lib.amc3d_local_aggregation_forward(
             B, C, N, M, K, 0, int(bool(relu)), float(bn.eps), 0.0, _ptr(g_cm), _ptr(idx), _ptr(dp), _ptr(w_dp), None,
             _ptr(bn.weight), _ptr(bn.bias), _ptr(g_pm), _ptr(pooled), _ptr(arg), _ptr(ystar), _ptr(bn.running_mean),
-            _ptr(invstd), None, None, None, None, None, None, 0, _stream(f)), "local_aggregation_forward")
+            _ptr(invstd), None, None, None, None, None, 0, None, None, 0, _stream(f)), "local_aggregation_forward")
     return pooled
 
 

@@ -272,15 +272,20 @@ int amc3d_local_aggregation_forward(int b, int cout, int n, int npoints, int nsa
                                     const void *moments, const float *gamma, const float *beta, float *g_pm, float *pooled,
                                     unsigned char *arg, float *ystar, float *mean, float *invstd, float *var_unbiased,
                                     double *gd, float *running_mean, float *running_var, long long *num_batches_tracked,
-                                    void *workspace, size_t workspace_bytes, void *stream);
+                                    int phase, double *sums, void *workspace, size_t workspace_bytes, void *stream);
+/* Statistics over several ranks (the reference converts every BatchNorm to SyncBatchNorm when world_size > 1,
+ * main_AA.py:146-148): phase 0 = one rank, everything in one call.  phase 1 writes this rank's {sum y, sum y^2} per channel
+ * and its position count to sums (2*cout + 1 doubles) and returns; the caller all-reduces sums; phase 2 finishes from the
+ * reduced sums (same arguments, same workspace).  Backward likewise: phase 1 -> dsums (2*cout doubles: sum dq, sum dq xhat),
+ * all-reduce, phase 2 with count = sums + 2*cout of the forward call; parameter gradients stay rank-local. */
 /* dg_cm (b,cout,n) = gradient w.r.t. g_cm (feed it to amc3d_pointwise_conv_backward for df and dW_f); dw_dp (cout,3),
  * dgamma, dbeta (cout).  The pooled gradient is scattered with cout * npoints float atomics (not x nsample). */
 int amc3d_local_aggregation_backward(int b, int cout, int n, int npoints, int nsample, int relu, const float *dpooled,
                                      const float *ystar, const unsigned char *arg, const float *g_pm, const int *idx,
                                      const float *dp, const float *w_dp, const void *moments, const double *gd,
                                      const float *mean, const float *invstd, const float *gamma, const float *beta,
-                                     float *dg_cm, float *dw_dp, float *dgamma, float *dbeta, void *workspace,
-                                     size_t workspace_bytes, void *stream);
+                                     float *dg_cm, float *dw_dp, float *dgamma, float *dbeta, int phase, double *dsums,
+                                     const double *count, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- the same three products in bf16 compute / fp32 accumulate (mixed precision: main_AA.py:389-394 wraps model and
  * criterion in autocast; BASELINE config 5).  Tensors stay fp32 in memory; operands are rounded to bf16 as they are
@@ -304,13 +309,14 @@ int amc3d_grouped_conv_bn_forward(int b, int cout, int n, int npoints, int nsamp
                                   float momentum, const float *g_cm, const int *idx, const float *dp, const float *w_dp,
                                   const void *moments, const float *gamma, const float *beta, float *g_pm, float *x1,
                                   float *mean, float *invstd, float *var_unbiased, double *gd, float *running_mean,
-                                  float *running_var, long long *num_batches_tracked, void *workspace,
-                                  size_t workspace_bytes, void *stream);
+                                  float *running_var, long long *num_batches_tracked, int phase, double *sums,
+                                  void *workspace, size_t workspace_bytes, void *stream);
 int amc3d_grouped_conv_bn_backward(int b, int cout, int n, int npoints, int nsample, int relu, const float *dx1,
                                    const float *g_pm, const int *idx, const float *dp, const float *w_dp,
                                    const void *moments, const double *gd, const float *mean, const float *invstd,
                                    const float *gamma, const float *beta, float *dg_cm, float *dw_dp, float *dgamma,
-                                   float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
+                                   float *dbeta, int phase, double *dsums, const double *count, void *workspace,
+                                   size_t workspace_bytes, void *stream);
 
 /* ---- reverse adjacency of a neighbourhood query: gathers instead of float atomics in backward (csrc/csr.hip) ---------
  * The reference's grouping backward scatters with atomicAdd (group_points_gpu.cu:34-51).  The edges depend on coordinates
@@ -329,7 +335,8 @@ int amc3d_grouped_conv_bn_backward_csr(int b, int cout, int n, int npoints, int 
                                        const float *g_pm, const int *rev_start, const int *rev_edge, const float *dp,
                                        const float *w_dp, const void *moments, const double *gd, const float *mean,
                                        const float *invstd, const float *gamma, const float *beta, float *dg_cm, float *dw_dp,
-                                       float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
+                                       float *dgamma, float *dbeta, int phase, double *dsums, const double *count,
+                                       void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- tail of a two-layer SetAbstraction block, recomputed instead of materialised -----------------------------
  * BN1 -> ReLU -> Conv2d 1x1 (C1 -> C2) -> BN2 [-> ReLU] -> max over the K = 32 neighbours

@@ -113,7 +113,7 @@ def test_two_ranks_match_whole_batch_and_torch_syncbn():
                 assert v <= TOL, (rank, key, k, v)
 
 
-def _model_worker(rank, world, port, q):
+def _model_worker(rank, world, port, q, variant="S", kw=None):
     """PointNeXt-S with every BN converted to SyncBatchNorm (as main_AA.py:146-148 does), one cloud per rank, against
     the plain model on both clouds in one process: same logits; parameter gradients of a sum-type objective add up."""
     os.environ.update({"RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
@@ -127,11 +127,11 @@ def _model_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     c = EasyConfig()
-    c.update(configs.model_cfg("S", dropout=0))
+    c.update(configs.model_cfg(variant, dropout=0, **(kw or {})))
     torch.manual_seed(0)
     plain = build_model_from_cfg(c).to(dev).train()
     c2 = EasyConfig()
-    c2.update(configs.model_cfg("S", dropout=0))
+    c2.update(configs.model_cfg(variant, dropout=0, **(kw or {})))
     synced = build_model_from_cfg(c2).to(dev).train()
     synced.load_state_dict(plain.state_dict())
     synced = torch.nn.SyncBatchNorm.convert_sync_batchnorm(synced)
@@ -145,10 +145,12 @@ def _model_worker(rank, world, port, q):
     (ls * probe[rank:rank + 1]).sum().backward()
     n_sync = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in synced.modules())
     worst_g, worst_name = 0.0, None
+    gmax = max(float(pp.grad.norm()) for pp in plain.parameters())
     for (name, pp), ps in zip(plain.named_parameters(), synced.parameters()):
         g = ps.grad.clone()
         dist.all_reduce(g)
-        err = float((g - pp.grad).norm() / (pp.grad.norm() + 1e-12))
+        # a ~zero gradient (a conv bias in front of a BatchNorm) is judged on the scale of the others
+        err = float((g - pp.grad).norm() / max(float(pp.grad.norm()), 1e-3 * gmax))
         if err > worst_g:
             worst_g, worst_name = err, name
     stats = max(float((a.running_var - b.running_var).abs().max())
@@ -160,11 +162,14 @@ def _model_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_model_with_synced_bn_equals_whole_batch_model():
+@pytest.mark.parametrize("variant,kw,nbn", [("S", None, 17), ("L", {"width": 16, "blocks": [1, 2, 2, 1, 1]}, 19)])
+def test_model_with_synced_bn_equals_whole_batch_model(variant, kw, nbn):
+    """PointNeXt-S (GroupedConvBN + the recomputing tail / bn_max under SyncBatchNorm) and a model with InvResMLP blocks
+    (LocalAggregationFused): the convolve-before-gather layers exchange their statistics between two phases"""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_model_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_model_worker, args=(r, world, port, q, variant, kw)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in range(world))
@@ -172,7 +177,7 @@ def test_model_with_synced_bn_equals_whole_batch_model():
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, logit_err, grad_err, grad_name, stat_err, n_sync in res:
-        assert n_sync == 17
+        assert n_sync == nbn, n_sync
         assert logit_err <= 1e-4, (rank, logit_err)
         assert stat_err <= 1e-4, (rank, stat_err)
         # arg-max routing of the neighbourhood max-pool flips on near-ties (tests/test_gpu_model.py: GRAD_RTOL)
