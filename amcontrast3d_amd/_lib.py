@@ -30,6 +30,7 @@ SIGNATURES = {
     "amc3d_furthest_point_sampling": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_three_nn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_three_interpolate": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_three_interpolate_add": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_three_interpolate_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_knnquery_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "amc3d_knnquery_uses_grid": (_i, [_i, _i, _i, _i]),

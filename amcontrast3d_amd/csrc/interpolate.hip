@@ -68,9 +68,11 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(int n, int m,
 // out[b,c,p] = w0*points[b,c,i0] + w1*points[b,c,i1] + w2*points[b,c,i2], evaluated
 // left to right without contraction (interpolate_gpu.cu:103).  One thread per
 // (b,p) keeps idx/weight in registers and walks the channels: coalesced stores.
+// `base` (optional, (b,c,n)): out = base + interpolation -- the skip branch of a FeaturePropagation conv applied before
+// the interpolation (W . [f1 ; up(f2)] = W1 . f1 + up(W2 . f2): the interpolation is linear and commutes with the 1x1 conv)
 __global__ void three_interpolate_kernel(int c, int m, int n, int ch_per, const float *__restrict__ points,
                                          const int *__restrict__ idx, const float *__restrict__ weight,
-                                         float *__restrict__ out)
+                                         const float *__restrict__ base, float *__restrict__ out)
 {
     const int bs = blockIdx.y;
     const int pt = blockIdx.x * blockDim.x + threadIdx.x;
@@ -86,7 +88,7 @@ __global__ void three_interpolate_kernel(int c, int m, int n, int ch_per, const 
     for (int ch = ch0; ch < ch1; ++ch) {
         const float *row = src + (size_t)ch * m;
         const float v = __fadd_rn(__fadd_rn(__fmul_rn(w0, row[i0]), __fmul_rn(w1, row[i1])), __fmul_rn(w2, row[i2]));
-        dst[(size_t)ch * n] = v;
+        dst[(size_t)ch * n] = base ? __fadd_rn(base[(size_t)bs * c * n + pt + (size_t)ch * n], v) : v;
     }
 }
 
@@ -136,17 +138,35 @@ AMC_API int amc3d_three_nn(int b, int n, int m, const float *unknown, const floa
     return launch_status("amc3d_three_nn");
 }
 
+static int three_interpolate_launch(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
+                                    const float *base, float *out, void *stream);
+
 AMC_API int amc3d_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
                                     const float *weight, float *out, void *stream)
 {
     if (b <= 0 || c <= 0 || n <= 0) return 0;
     if (!points || !idx || !weight || !out) return bad_arg("amc3d_three_interpolate: null pointer");
+    return three_interpolate_launch(b, c, m, n, points, idx, weight, nullptr, out, stream);
+}
+
+// out (b,c,n) = base (b,c,n) + three_interpolate(points (b,c,m)); out may alias base
+AMC_API int amc3d_three_interpolate_add(int b, int c, int m, int n, const float *points, const int *idx,
+                                        const float *weight, const float *base, float *out, void *stream)
+{
+    if (b <= 0 || c <= 0 || n <= 0) return 0;
+    if (!points || !idx || !weight || !base || !out) return bad_arg("amc3d_three_interpolate_add: null pointer");
+    return three_interpolate_launch(b, c, m, n, points, idx, weight, base, out, stream);
+}
+
+static int three_interpolate_launch(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
+                                    const float *base, float *out, void *stream)
+{
     long chunks = 262144 / ((long)b * n);
     if (chunks < 1) chunks = 1;
     if (chunks > c) chunks = c;
     const int ch_per = div_up(c, chunks);
     hipLaunchKernelGGL(three_interpolate_kernel, dim3(div_up(n, 256), b, div_up(c, ch_per)), dim3(256), 0,
-                       (hipStream_t)stream, c, m, n, ch_per, points, idx, weight, out);
+                       (hipStream_t)stream, c, m, n, ch_per, points, idx, weight, base, out);
     return launch_status("amc3d_three_interpolate");
 }
 

@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from ..layers import (CHANNEL_MAP, create_act, create_convblock1d, create_convblock2d, create_grouper,
+                      feature_propagation_first_block,
                       furthest_point_sample, fused_first_block, fused_first_conv, fused_local_aggregation,
                       get_aggregation_feautres,
                       random_sample, run_convblocks,
@@ -237,6 +238,9 @@ class FeaturePropogation(nn.Module):
         p2, f2 = pf2
         if geom is None:
             geom = self.plan(p1, p2)
+        first = feature_propagation_first_block(self.convs[0], f1, f2, geom) if len(self.convs) else None
+        if first is not None:  # the first conv on both branches before the interpolation: no concatenated tensor
+            return run_convblocks(list(self.convs)[1:], first)
         up = three_interpolate(f2, geom['idx'], geom['weight'])
         return run_convblocks(self.convs, up if f1 is None else torch.cat((f1, up), dim=1))
 

@@ -159,9 +159,60 @@ def conv1x1(conv, x):
             # whose weight gradient is wrapped in layout transposes (scratch/pw_bench3.py: 30-50 us per layer)
             from amcontrast3d_amd.ops import library_gemm_conv
             return library_gemm_conv(x, conv.weight)
-        with torch.autocast("cuda", enabled=False):  # small leftovers: the torch module in fp32 (tensors stay fp32)
+        # what is left (small layers with a bias: the skip convs of SA2-4): this library's kernel too -- the convolution
+        # library answers them with layout transposes around implicit-GEMM kernels (and a find-mode search at first use)
+        if os.environ.get("AMC3D_SMALL_CONV_OWN"):  # measured: 0.35 ms/step slower than the convolution library on these three layers
+            from amcontrast3d_amd.ops import pointwise_conv
+            return pointwise_conv(x, conv.weight, conv.bias)
+        with torch.autocast("cuda", enabled=False):
             return conv(x)
     return conv(x)
+
+
+def conv1x1_weight(x, w):
+    """1x1 convolution of x (B,Cin,P) with an explicit bias-free weight w (Cout,Cin): the routing of conv1x1 for a slice
+    of a module's weight (the two halves of a FeaturePropogation conv)"""
+    from amcontrast3d_amd import ops
+    cin, cout = w.shape[1], w.shape[0]
+    positions = x.numel() // x.shape[1]
+    w3 = w.reshape(cout, cin, 1)
+    if ops.mixed_precision() and min(cin, cout) >= 64 and positions >= 4096:
+        return ops.pointwise_conv(x, w3, None, True)
+    if (min(cin, cout) >= 64 and positions < 65536 and cin % 4 == 0 and torch.is_grad_enabled()
+            and not os.environ.get("AMC3D_NO_LIBRARY_GEMM")):
+        return ops.library_gemm_conv(x, w3)
+    return ops.pointwise_conv(x, w3, None)
+
+
+def feature_propagation_first_block(blk, f1, f2, geom):
+    """First block of FeaturePropogation (pointnext_AA.py:210-226: interpolate f2 onto the fine cloud, concatenate with the
+    skip features f1, Conv1d -> BatchNorm1d -> ReLU) with the conv applied BEFORE the interpolation:
+        W . [f1 ; up(f2)] = W1 . f1 + up(W2 . f2)
+    (the 3-NN interpolation is linear and mixes points, the 1x1 conv mixes channels: they commute).  The interpolated
+    tensor has Cout instead of C2 channels (half at every level), its conv runs on the coarse cloud (4x fewer points), and
+    no concatenated (B, C1+C2, n) tensor exists.  -> the block's output, or None when it is not of that form."""
+    from amcontrast3d_amd import ops
+    if (not isinstance(blk, nn.Sequential) or len(blk) != 3 or type(blk[0]) not in (nn.Conv1d, Conv1d)
+            or not isinstance(blk[1], nn.modules.batchnorm._BatchNorm) or type(blk[2]) is not nn.ReLU
+            or f1 is None or not f1.is_cuda or f1.dtype != torch.float32 or f2.dtype != torch.float32
+            or os.environ.get("AMC3D_NO_FP_SPLIT")):
+        return None
+    conv, bn = blk[0], blk[1]
+    c1 = f1.shape[1]
+    if (conv.bias is not None or conv.kernel_size != (1,) or conv.stride != (1,) or conv.groups != 1
+            or conv.in_channels != c1 + f2.shape[1]):
+        return None
+    w = conv.weight[:, :, 0]
+    y = ops.three_interpolate_add(conv1x1_weight(f2, w[:, c1:].contiguous()), geom['idx'], geom['weight'],
+                                  conv1x1_weight(f1, w[:, :c1].contiguous()))
+    group = _synced_bn_group(bn, y)
+    if _eval_bn(bn, y):
+        return ops.bn_eval(y, bn, True, False)
+    if group is not None:
+        return ops.SyncBatchNormFused.apply(y, bn.weight, bn.bias, bn.eps, True, False, bn, group)[0]
+    if _fusable_bn(bn, y):
+        return ops.BatchNormAct.apply(y, bn.weight, bn.bias, bn.eps, True, bn)[0]
+    return blk[2](bn(y))
 
 
 def _bf16_pays(conv, x):

@@ -309,6 +309,45 @@ class ThreeInterpolate(Function):
 three_interpolate = ThreeInterpolate.apply
 
 
+class ThreeInterpolateAdd(Function):
+    """base (B,C,n) + three_interpolate(features (B,C,m), idx, weight): the interpolated branch of a FeaturePropogation
+    conv added onto the skip branch in the interpolation kernel itself (no (B,C1+C2,n) concatenation is ever built)"""
+
+    @staticmethod
+    def forward(ctx, features, idx, weight, base):
+        _need_gpu(features, idx, weight, base)
+        _need_dtype(torch.float32, features=features, weight=weight, base=base)
+        _need_dtype(torch.int32, idx=idx)
+        features, idx, weight, base = features.contiguous(), idx.contiguous(), weight.contiguous(), base.contiguous()
+        B, c, m = features.size()
+        n = idx.size(1)
+        assert base.shape == (B, c, n)
+        ctx.save_for_backward(idx, weight)
+        ctx.m = m
+        output = torch.empty(B, c, n, dtype=torch.float32, device=features.device)
+        with torch.cuda.device(features.device), timing.span("three_interpolate", features.numel() * 4 + idx.numel() * 8 + output.numel() * 8):
+            _lib.check(_lib.load().amc3d_three_interpolate_add(B, c, m, n, _ptr(features), _ptr(idx), _ptr(weight), _ptr(base),
+                                                               _ptr(output), _stream(features)), "three_interpolate_add")
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        m = ctx.m
+        B, c, n = grad_out.size()
+        grad_out_data = grad_out.detach().contiguous()
+        grad_features = torch.zeros(B, c, m, dtype=torch.float32, device=grad_out.device)
+        with torch.cuda.device(grad_out.device), timing.span("three_interpolate_grad", grad_out_data.numel() * 4 + idx.numel() * 8 + grad_features.numel() * 4):
+            work = torch.empty(B * c * m, dtype=torch.float32, device=grad_out.device)
+            _lib.check(_lib.load().amc3d_three_interpolate_grad(B, c, n, m, _ptr(grad_out_data), _ptr(idx), _ptr(weight),
+                                                                _ptr(grad_features), _ptr(work), work.numel() * 4,
+                                                                _stream(grad_out)), "three_interpolate_grad")
+        return grad_features, None, None, grad_out
+
+
+three_interpolate_add = ThreeInterpolateAdd.apply
+
+
 def three_interpolation(unknown_xyz, known_xyz, know_feat):
     """Inverse-distance 3-NN interpolation (upsampling.py:92-102)."""
     dist, idx = three_nn(unknown_xyz, known_xyz)

@@ -306,6 +306,7 @@ def main():
         from openpoints.models.layers import blocks
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ["NCCL_DEBUG"] = os.environ.get("AMC3D_NCCL_DEBUG", "WARN")
         tdist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         blocks._FORCE_SYNCED_BN = sync_bn = True
     use_graph = not args.no_graph and not use_ddp

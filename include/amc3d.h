@@ -112,6 +112,10 @@ int amc3d_three_nn(int b, int n, int m, const float *unknown, const float *known
 int amc3d_three_interpolate(int b, int c, int m, int n, const float *points,
                             const int *idx, const float *weight, float *out, void *stream);
 
+/* out (b,c,n) = base (b,c,n) + three_interpolate(points (b,c,m), idx, weight): FeaturePropogation's first conv
+ * (pointnext_AA.py:210-226) applied before the interpolation, W . [f1 ; up(f2)] = W1 . f1 + up(W2 . f2) */
+int amc3d_three_interpolate_add(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
+                                const float *base, float *out, void *stream);
 /* replaces three_interpolate_grad_wrapper_fast (interpolate_gpu.cu:127-169):
  * grad_points (b,c,m) += ...; caller zero-initialises (upsampling.py:82).
  * Optional workspace: amc3d_scatter_workspace_bytes(b,c,m), as above. */
