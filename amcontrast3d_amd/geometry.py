@@ -131,10 +131,13 @@ def precompute_refine(model, plan):
     return out
 
 
+_FPS_KEYS = ("fps_idx", "new_p", "fps_idx32")  # what the sampling chain produces (the serial part of a plan)
+
+
 def split(plan):
     """(fps part, rest part) of a full plan, as structures referencing the plan's own tensors."""
-    fps = [{"fps_idx": b[0]["fps_idx"], "new_p": b[0]["new_p"]} for b in plan["encoder"]]
-    rest = {"encoder": [[{k: v for k, v in b[0].items() if k not in ("fps_idx", "new_p")}] + list(b[1:])
+    fps = [{k: b[0][k] for k in _FPS_KEYS if k in b[0]} for b in plan["encoder"]]
+    rest = {"encoder": [[{k: v for k, v in b[0].items() if k not in _FPS_KEYS}] + list(b[1:])
                         for b in plan["encoder"]],
             "decoder": plan["decoder"], "loss": plan["loss"]}
     if "refine" in plan:
@@ -199,15 +202,37 @@ def _walk(obj, fn):
     return obj
 
 
-def copy_into(dst, src):
-    """In-place copy of every tensor of plan `src` into the same-shaped plan `dst` (static buffers
-    for graph replay).  Views (e.g. idx[:, 1:]) are copied through their storage like any tensor."""
+def _pairs(dst, src, out):
     if torch.is_tensor(dst):
         if dst.data_ptr() != src.data_ptr():
-            dst.copy_(src)
+            out.append((dst, src))
     elif isinstance(dst, dict):
         for k in dst:
-            copy_into(dst[k], src[k])
+            _pairs(dst[k], src[k], out)
     elif isinstance(dst, (list, tuple)):
         for d, s in zip(dst, src):
-            copy_into(d, s)
+            _pairs(d, s, out)
+
+
+def copy_into(dst, src):
+    """In-place copy of every tensor of plan `src` into the same-shaped plan `dst` (static buffers
+    for graph replay).  Views (e.g. idx[:, 1:]) are copied through their storage like any tensor.
+    The copies of one call go out as multi-tensor launches (one per dtype), not one launch per tensor: a plan holds
+    ~40 tensors and the pipeline's rotate step copies four plans between two steps of the training stream."""
+    import os
+    pairs = []
+    _pairs(dst, src, pairs)
+    if os.environ.get("AMC3D_NO_FOREACH_COPY"):
+        for d, s in pairs:
+            d.copy_(s)
+        return
+    by_dtype = {}
+    for d, s in pairs:
+        if d.is_contiguous() and s.is_contiguous() and d.dtype == s.dtype and d.shape == s.shape:
+            by_dtype.setdefault(d.dtype, ([], []))
+            by_dtype[d.dtype][0].append(d)
+            by_dtype[d.dtype][1].append(s)
+        else:
+            d.copy_(s)
+    for ds, ss in by_dtype.values():
+        torch._foreach_copy_(ds, ss)

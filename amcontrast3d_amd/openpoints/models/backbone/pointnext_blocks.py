@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from ..layers import (CHANNEL_MAP, create_act, create_convblock1d, create_convblock2d, create_grouper,
-                      feature_propagation_first_block,
+                      feature_propagation_first_block, gather_operation,
                       furthest_point_sample, fused_first_block, fused_first_conv, fused_local_aggregation,
                       get_aggregation_feautres,
                       random_sample, run_convblocks,
@@ -154,8 +154,12 @@ class SetAbstraction(nn.Module):
         """FPS picks and the sub-sampled cloud (the serial part of the geometry)"""
         if self.is_head or self.all_aggr:
             return {'fps_idx': None, 'new_p': p}
-        idx = self.sample_fn(p, p.shape[1] // self.stride).long()
-        return {'fps_idx': idx, 'new_p': torch.gather(p, 1, idx.unsqueeze(-1).expand(-1, -1, 3))}
+        idx32 = self.sample_fn(p, p.shape[1] // self.stride)
+        idx = idx32.long()
+        g = {'fps_idx': idx, 'new_p': torch.gather(p, 1, idx.unsqueeze(-1).expand(-1, -1, 3))}
+        if idx32.dtype == torch.int32:
+            g['fps_idx32'] = idx32.contiguous()
+        return g
 
     @torch.no_grad()
     def plan_group(self, p, g):
@@ -180,7 +184,14 @@ class SetAbstraction(nn.Module):
         idx, new_p = geom['fps_idx'], geom['new_p']
         fi = None
         if self.use_res or 'df' in self.feature_type:
-            fi = torch.gather(f, -1, idx.unsqueeze(1).expand(-1, f.shape[1], -1))
+            import os
+            if (f.is_cuda and f.dtype == torch.float32 and geom.get('fps_idx32') is not None
+                    and os.environ.get("AMC3D_OWN_GATHER")):
+                # gather_points kernels (the reference's GatherOperation): measured 0.24 ms/step slower than torch.gather
+                # here (its backward scatters with float atomics, torch's index-add over sorted FPS picks does not)
+                fi = gather_operation(f.contiguous(), geom['fps_idx32'])
+            else:
+                fi = torch.gather(f, -1, idx.unsqueeze(1).expand(-1, f.shape[1], -1))
             if self.use_res:
                 identity = run_convblocks((self.skipconv,), fi)
         fused = fused_local_aggregation(self.convs, f, geom, self.feature_type)
