@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void lagg_geom_kernel(int n, long P, const int
 // grid (n-tile groups, channel chunks of 64, b)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lagg_stats_kernel(int C, int n, const float *__restrict__ g_cm, float *__restrict__ g_pm,
-                                                         LaggMoments gm, double *__restrict__ partial, int nparts_per_b)
+                                                         LaggMoments gm, double *__restrict__ partial, int nparts_per_b,
+                                                         int tiles_per_wg)
 {
     __shared__ float tile[64][LAGG_NT + 1];
     __shared__ double red[4][64][5];
@@ -107,8 +108,8 @@ __global__ __launch_bounds__(256) void lagg_stats_kernel(int C, int n, const flo
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = c0 + lane;
     double a[5] = {0, 0, 0, 0, 0};
-    for (int tt = 0; tt < LAGG_TILES; ++tt) {
-        const int n0 = (blockIdx.x * LAGG_TILES + tt) * LAGG_NT;
+    for (int tt = 0; tt < tiles_per_wg; ++tt) {
+        const int n0 = (blockIdx.x * tiles_per_wg + tt) * LAGG_NT;
         if (n0 >= n) break;
         __syncthreads();
         for (int r = wave; r < 64; r += 4) {  // r: channel of the chunk, lane: point
@@ -209,7 +210,8 @@ __device__ __forceinline__ float lagg_bn(float x, float mean, float invstd, floa
 // grid (m tiles of 32, channel chunks of <= 128, b); a wave owns 8 centroids; LPR lanes share one gathered row
 // (16 bytes each), 64/LPR rows per load instruction
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lagg_pool_kernel(int C, int n, int M, int K, int lpr, int relu,
+template <int LPR>
+__global__ __launch_bounds__(256) void lagg_pool_kernel(int C, int n, int M, int K, int cpw, int relu,
                                                         const float *__restrict__ g_pm, const int *__restrict__ idx,
                                                         const float *__restrict__ dp, const float *__restrict__ w_dp,
                                                         const float *__restrict__ mean, const float *__restrict__ invstd,
@@ -218,25 +220,25 @@ __global__ __launch_bounds__(256) void lagg_pool_kernel(int C, int n, int M, int
                                                         float *__restrict__ ystar)
 {
     extern __shared__ float lagg_smem[];
-    const int ct = min(LAGG_CT, C - (int)blockIdx.y * LAGG_CT);  // channels of this chunk (a multiple of 4)
-    float *sp = lagg_smem;                        // [ct][LAGG_MT + 1] pooled
-    float *sy = sp + ct * (LAGG_MT + 1);          // ystar
-    float *sa = sy + ct * (LAGG_MT + 1);          // arg (as float bits of an int)
-    const int b = blockIdx.z, c0 = blockIdx.y * LAGG_CT, m0 = blockIdx.x * LAGG_MT;
+    constexpr int ct = 4 * LPR, rpi = 64 / LPR;   // channels of this chunk; gathered rows per load instruction
+    const int MT = 4 * cpw;                        // centroids per workgroup (cpw per wave)
+    float *sp = lagg_smem;                         // [ct][MT + 1] pooled
+    float *sy = sp + ct * (MT + 1);                // ystar
+    float *sa = sy + ct * (MT + 1);                // arg (as float bits of an int)
+    const int b = blockIdx.z, c0 = blockIdx.y * ct, m0 = blockIdx.x * MT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = lane % lpr, r = lane / lpr, rpi = 64 / lpr;
-    const bool chan_ok = 4 * q < ct;
+    const int q = lane % LPR, r = lane / LPR;
     const int cq = c0 + 4 * q;
     float w[4][3], mu[4], is[4], ga[4], be[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int c = chan_ok ? cq + j : c0;
+        const int c = cq + j;
         w[j][0] = w_dp[c * 3 + 0]; w[j][1] = w_dp[c * 3 + 1]; w[j][2] = w_dp[c * 3 + 2];
         mu[j] = mean[c]; is[j] = invstd[c]; ga[j] = gamma[c]; be[j] = beta[c];
     }
     const long P = (long)M * K;
-    for (int i = 0; i < LAGG_MT / 4; ++i) {
-        const int ml = wave * (LAGG_MT / 4) + i, m = m0 + ml;
+    for (int i = 0; i < cpw; ++i) {
+        const int ml = wave * cpw + i, m = m0 + ml;
         if (m >= M) break;  // wave-uniform
         int id_l = 0;
         float d0 = 0.f, d1 = 0.f, d2 = 0.f;
@@ -248,24 +250,29 @@ __global__ __launch_bounds__(256) void lagg_pool_kernel(int C, int n, int M, int
         float best[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
         float by[4] = {0.f, 0.f, 0.f, 0.f};
         int bk[4] = {0, 0, 0, 0};
-        for (int k0 = 0; k0 < K; k0 += rpi) {
+        auto visit = [&](int k0) {
             const int k = k0 + r;
             const int ks = k < K ? k : K - 1;
             const int id = __shfl(id_l, ks, 64);
             const float e0 = __shfl(d0, ks, 64), e1 = __shfl(d1, ks, 64), e2 = __shfl(d2, ks, 64);
-            if (k < K && chan_ok) {
-                const float4 g = *reinterpret_cast<const float4 *>(g_pm + ((size_t)b * n + id) * C + cq);
-                const float gs[4] = {g.x, g.y, g.z, g.w};
+            const float4 g = *reinterpret_cast<const float4 *>(g_pm + ((size_t)b * n + id) * C + cq);
+            const float gs[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float y = __fmaf_rn(w[j][0], e0, __fmaf_rn(w[j][1], e1, __fmaf_rn(w[j][2], e2, gs[j])));
-                    float v = lagg_bn(y, mu[j], is[j], ga[j], be[j]);
-                    if (relu) v = fmaxf(v, 0.f);
-                    if (v > best[j]) { best[j] = v; bk[j] = k; by[j] = y; }
-                }
+            for (int j = 0; j < 4; ++j) {
+                const float y = __fmaf_rn(w[j][0], e0, __fmaf_rn(w[j][1], e1, __fmaf_rn(w[j][2], e2, gs[j])));
+                float v = lagg_bn(y, mu[j], is[j], ga[j], be[j]);
+                if (relu) v = fmaxf(v, 0.f);
+                if (k < K && v > best[j]) { best[j] = v; bk[j] = k; by[j] = y; }
             }
+        };
+        if (K == 32) {  // the configured neighbourhood size: fully unrolled, all gathers of a centroid in flight together
+#pragma unroll
+            for (int k0 = 0; k0 < 32; k0 += rpi) visit(k0);
+        } else {
+            for (int k0 = 0; k0 < K; k0 += rpi) visit(k0);
         }
-        for (int s = lpr; s < 64; s <<= 1) {  // combine the row slots, first index wins among equal values
+#pragma unroll
+        for (int s = LPR; s < 64; s <<= 1) {  // combine the row slots, first index wins among equal values
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float ov = __shfl_xor(best[j], s, 64), oy = __shfl_xor(by[j], s, 64);
@@ -273,24 +280,24 @@ __global__ __launch_bounds__(256) void lagg_pool_kernel(int C, int n, int M, int
                 if (ov > best[j] || (ov == best[j] && ok < bk[j])) { best[j] = ov; bk[j] = ok; by[j] = oy; }
             }
         }
-        if (r == 0 && chan_ok) {
+        if (r == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int cl = 4 * q + j;
-                sp[cl * (LAGG_MT + 1) + ml] = best[j];
-                sy[cl * (LAGG_MT + 1) + ml] = by[j];
-                sa[cl * (LAGG_MT + 1) + ml] = __int_as_float(bk[j]);
+                sp[cl * (MT + 1) + ml] = best[j];
+                sy[cl * (MT + 1) + ml] = by[j];
+                sa[cl * (MT + 1) + ml] = __int_as_float(bk[j]);
             }
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < ct * LAGG_MT; t += 256) {
-        const int cl = t / LAGG_MT, ml = t - cl * LAGG_MT, m = m0 + ml;
+    for (int t = threadIdx.x; t < ct * MT; t += 256) {
+        const int cl = t / MT, ml = t - cl * MT, m = m0 + ml;
         if (m < M) {
             const size_t o = ((size_t)b * C + c0 + cl) * M + m;
-            pooled[o] = sp[cl * (LAGG_MT + 1) + ml];
-            ystar[o] = sy[cl * (LAGG_MT + 1) + ml];
-            arg[o] = (unsigned char)__float_as_int(sa[cl * (LAGG_MT + 1) + ml]);
+            pooled[o] = sp[cl * (MT + 1) + ml];
+            ystar[o] = sy[cl * (MT + 1) + ml];
+            arg[o] = (unsigned char)__float_as_int(sa[cl * (MT + 1) + ml]);
         }
     }
 }
@@ -654,9 +661,16 @@ static bool lagg_supported(int C, int K)
     return (lpr & (lpr - 1)) == 0 && C % ct == 0;  // 8,16,32,64,128 and multiples of 128
 }
 
+// tiles per workgroup of the statistics kernel: one while that still leaves the grid small (latency-bound kernel)
+static int lagg_stats_tiles(int b, int C, int n)
+{
+    const long wgs1 = (long)b * div_up(n, LAGG_NT) * div_up(C, 64);
+    return wgs1 <= 8192 ? 1 : LAGG_TILES;
+}
+
 static size_t lagg_partial_bytes(int b, int C, int n, int M)
 {
-    const size_t pf = (size_t)b * div_up(div_up(n, LAGG_NT), LAGG_TILES), pb = (size_t)b * div_up(div_up(M, LAGG_MT), LAGG_TILES);
+    const size_t pf = (size_t)b * div_up(div_up(n, LAGG_NT), lagg_stats_tiles(b, C, n)), pb = (size_t)b * div_up(div_up(M, LAGG_MT), LAGG_TILES);
     const size_t pc = (size_t)b * div_up((long)M * 32, LAGG_PT);  // collapse kernel (K = 32), at most one partial per tile
     size_t m = pf > pb ? pf : pb;
     if (pc > m) m = pc;
@@ -725,12 +739,13 @@ AMC_API int amc3d_local_aggregation_forward(int b, int cout, int n, int npoints,
     hipStream_t stream = (hipStream_t)stream_;
     LaggMoments gm{};
     if (moments) gm = lagg_views(moments, b, n);
-    const int nparts_b = div_up(div_up(n, LAGG_NT), LAGG_TILES);
+    const int stiles = lagg_stats_tiles(b, cout, n);
+    const int nparts_b = div_up(div_up(n, LAGG_NT), stiles);
     double *partial = (double *)workspace;
     if (training) {
         if (phase != 2)
             hipLaunchKernelGGL(lagg_stats_kernel, dim3(nparts_b, div_up(cout, 64), b), dim3(256), 0, stream, cout, n, g_cm, g_pm, gm,
-                               partial, nparts_b);
+                               partial, nparts_b, stiles);
         hipLaunchKernelGGL(lagg_stats_finalize_kernel, dim3(cout), dim3(256), 0, stream, cout, nparts_b * b,
                            (double)b * (double)npoints * (double)nsample, eps, momentum, (const double *)partial, gm.mom, w_dp,
                            mean, invstd, var_unbiased, gd, running_mean, running_var, num_batches_tracked, phase, sums);
@@ -740,10 +755,17 @@ AMC_API int amc3d_local_aggregation_forward(int b, int cout, int n, int npoints,
         if (int st = amc3d_transpose_cn(b, cout, n, g_cm, g_pm, stream_)) return st;
     }
     const int ct = cout < LAGG_CT ? cout : LAGG_CT;
-    const size_t lds = (size_t)3 * ct * (LAGG_MT + 1) * sizeof(float);
-    hipLaunchKernelGGL(lagg_pool_kernel, dim3(div_up(npoints, LAGG_MT), cout / ct, b), dim3(256), lds, stream, cout, n, npoints,
-                       nsample, ct / 4, relu, (const float *)g_pm, idx, dp, w_dp, (const float *)mean, (const float *)invstd, gamma,
-                       beta, pooled, arg, ystar);
+    // centroids per wave: 8, fewer where that leaves the chip with under ~2 workgroups per CU (the coarse stages)
+    int cpw = 8;
+    while (cpw > 1 && (long)div_up(npoints, 4 * cpw) * (cout / ct) * b < 1024) cpw >>= 1;
+    const size_t lds = (size_t)3 * ct * (4 * cpw + 1) * sizeof(float);
+#define AMC_POOL(L)                                                                                                            \
+    hipLaunchKernelGGL(lagg_pool_kernel<L>, dim3(div_up(npoints, 4 * cpw), cout / ct, b), dim3(256), lds, stream, cout, n, npoints, \
+                       nsample, cpw, relu, (const float *)g_pm, idx, dp, w_dp, (const float *)mean, (const float *)invstd, gamma,  \
+                       beta, pooled, arg, ystar)
+    switch (ct / 4) { case 2: AMC_POOL(2); break; case 4: AMC_POOL(4); break; case 8: AMC_POOL(8); break; case 16: AMC_POOL(16); break;
+                      default: AMC_POOL(32); }
+#undef AMC_POOL
     return launch_status("amc3d_local_aggregation_forward");
 }
 
@@ -807,11 +829,12 @@ AMC_API int amc3d_grouped_conv_bn_forward(int b, int cout, int n, int npoints, i
     hipStream_t stream = (hipStream_t)stream_;
     LaggMoments gm{};
     if (moments) gm = lagg_views(moments, b, n);
-    const int nparts_b = div_up(div_up(n, LAGG_NT), LAGG_TILES);
+    const int stiles = lagg_stats_tiles(b, cout, n);
+    const int nparts_b = div_up(div_up(n, LAGG_NT), stiles);
     if (training) {
         if (phase != 2)
             hipLaunchKernelGGL(lagg_stats_kernel, dim3(nparts_b, div_up(cout, 64), b), dim3(256), 0, stream, cout, n, g_cm, g_pm, gm,
-                               (double *)workspace, nparts_b);
+                               (double *)workspace, nparts_b, stiles);
         hipLaunchKernelGGL(lagg_stats_finalize_kernel, dim3(cout), dim3(256), 0, stream, cout, nparts_b * b,
                            (double)b * (double)npoints * (double)nsample, eps, momentum, (const double *)workspace, gm.mom, w_dp,
                            mean, invstd, var_unbiased, gd, running_mean, running_var, num_batches_tracked, phase, sums);
