@@ -39,8 +39,15 @@ SIGNATURES = {
     "amc3d_posmask": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "amc3d_ambiguity_workspace_bytes": (_sz, [_i]),
     "amc3d_ambiguity": (_i, [_i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "amc3d_contrast_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
-    "amc3d_contrast_backward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_contrast_csr_workspace_bytes": (_sz, [_i]),
+    "amc3d_contrast_csr": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "amc3d_contrast_backward_csr_supported": (_i, [_i]),
+    "amc3d_contrast_backward_csr": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp,
+                                         _vp, _vp]),
+    "amc3d_select_anchors_ints": (_sz, [_i]),
+    "amc3d_select_anchors": (_i, [_i, _vp, _vp, _sz, _vp]),
+    "amc3d_contrast_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_contrast_backward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_grouped_conv_supported": (_i, [_i, _i]),
     "amc3d_transpose_cn": (_i, [_i, _i, _i, _vp, _vp, _vp]),
     "amc3d_grouped_conv_forward": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -73,12 +80,12 @@ SIGNATURES = {
     "amc3d_group_csr": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_group_moments_csr": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_grouped_conv_bn_csr_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "amc3d_grouped_conv_bn_backward_csr": (_i, [_i] * 6 + [_vp] * 16 + [_i, _vp, _vp, _vp, _sz, _vp]),
+    "amc3d_grouped_conv_bn_backward_csr": (_i, [_i] * 6 + [_vp, _i] + [_vp] * 15 + [_i, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_sa_tail_supported": (_i, [_i, _i, _i]),
     "amc3d_sa_tail_pays": (_i, [_i, _i]),
     "amc3d_sa_tail_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "amc3d_sa_tail_forward": (_i, [_i, _i, _i, _i, _i] + [_vp] * 8 + [_f, _f, _i] + [_vp] * 8 + [_sz, _vp]),
-    "amc3d_sa_tail_backward": (_i, [_i, _i, _i, _i, _i] + [_vp] * 10 + [_i] + [_vp] * 7 + [_sz, _vp]),
+    "amc3d_sa_tail_backward": (_i, [_i, _i, _i, _i, _i] + [_vp] * 10 + [_i, _vp, _vp, _i] + [_vp] * 5 + [_sz, _vp]),
     "amc3d_bn_workspace_bytes": (_sz, [_i]),
     "amc3d_bn_stats": (_i, [_i, _i, _l, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_bn_forward": (_i, [_i, _i, _l, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -174,6 +174,48 @@ __global__ __launch_bounds__(256) void csr_collapse_kernel(int C, int n, long P,
     }
 }
 
+
+// ---- reverse lists of the loss stages' k-NN edges (anchor i, neighbour slot j) restricted to the selected anchors -------
+// Counting sort (in-degree by integer atomics, exclusive scan, cursor fill), then every short list is put in ascending
+// order so the gather that uses it sums in a fixed order.  E = (selected anchors) * k, a device-side quantity: the launch
+// covers m * k slots and the surplus threads leave at once.
+__global__ void nbr_degree_kernel(int m, int k, int nbr_stride, const int *__restrict__ nbr, const int *__restrict__ sel,
+                                  int *__restrict__ deg)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long w = t / k;
+    if (w >= sel[0]) return;
+    const int i = sel[1 + w], j = (int)(t - w * k);
+    const int nb = nbr[(size_t)i * nbr_stride + j];
+    if (nb >= 0 && nb < m) atomicAdd(deg + nb, 1);
+}
+
+__global__ void nbr_fill_kernel(int m, int k, int nbr_stride, const int *__restrict__ nbr, const int *__restrict__ sel,
+                                const int *__restrict__ rev_start, int *__restrict__ cursor, int *__restrict__ rev_edge)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long w = t / k;
+    if (w >= sel[0]) return;
+    const int i = sel[1 + w], j = (int)(t - w * k);
+    const int nb = nbr[(size_t)i * nbr_stride + j];
+    if (nb >= 0 && nb < m) rev_edge[rev_start[nb] + atomicAdd(cursor + nb, 1)] = i * k + j;
+}
+
+constexpr int NBR_SORT_MAX = 96;  // longer lists (degenerate clouds) keep their fill order
+__global__ void nbr_order_kernel(int m, const int *__restrict__ rev_start, int *__restrict__ rev_edge)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= m) return;
+    const int e0 = rev_start[n], d = rev_start[n + 1] - e0;
+    if (d < 2 || d > NBR_SORT_MAX) return;
+    int *l = rev_edge + e0;
+    for (int x = 1; x < d; ++x) {  // insertion sort: the lists hold ~k entries
+        const int v = l[x];
+        int y = x - 1;
+        while (y >= 0 && l[y] > v) { l[y + 1] = l[y]; --y; }
+        l[y + 1] = v;
+    }
+}
 }  // namespace amc
 
 using namespace amc;
@@ -207,6 +249,40 @@ AMC_API int amc3d_group_csr(int b, int n, int npoints, int nsample, const int *i
     if (e != hipSuccess) { set_error("amc3d_group_csr: radix sort: %s", hipGetErrorString(e)); return (int)e; }
     hipLaunchKernelGGL(csr_start_kernel, dim3(div_up(G + 1, 256)), dim3(256), 0, stream, G, E, (const unsigned *)skey, rev_start);
     return launch_status("amc3d_group_csr");
+}
+
+// Loss stage: rev (m + 1 + m*k) int32 = [rev_start (m+1) | rev_edge]: rev_edge[rev_start[n] .. rev_start[n+1]) are the
+// positions i*k + j, ascending, of the SELECTED anchors i (list sel of amc3d_select_anchors) whose neighbour j is n.
+AMC_API size_t amc3d_contrast_csr_workspace_bytes(int m)
+{
+    if (m <= 0) return 0;
+    size_t t = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t, (const int *)nullptr, (int *)nullptr, m + 1);
+    return 2 * csr_align((size_t)(m + 1) * 4) + csr_align(t) + 256;
+}
+
+AMC_API int amc3d_contrast_csr(int m, int k, int nbr_stride, const int *nbr, const int *sel, int *rev, void *workspace,
+                               size_t workspace_bytes, void *stream_)
+{
+    if (m <= 0) return 0;
+    if (k <= 0 || nbr_stride < k || !nbr || !sel || !rev || !workspace || (long)m * k >= (1L << 31) ||
+        workspace_bytes < amc3d_contrast_csr_workspace_bytes(m))
+        return bad_arg("amc3d_contrast_csr: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    char *w = (char *)workspace;
+    int *deg = (int *)w; w += csr_align((size_t)(m + 1) * 4);
+    int *cursor = (int *)w; w += csr_align((size_t)(m + 1) * 4);
+    size_t temp = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, temp, (const int *)nullptr, (int *)nullptr, m + 1);
+    if (int st = fill_i32(deg, 0, (size_t)(cursor - deg) + m + 1, stream)) return st;  // deg and cursor, one launch
+    const long slots = (long)m * k;
+    hipLaunchKernelGGL(nbr_degree_kernel, dim3(div_up(slots, 256)), dim3(256), 0, stream, m, k, nbr_stride, nbr, sel, deg);
+    const hipError_t e = hipcub::DeviceScan::ExclusiveSum(w, temp, (const int *)deg, rev, m + 1, stream);
+    if (e != hipSuccess) { set_error("amc3d_contrast_csr: scan: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(nbr_fill_kernel, dim3(div_up(slots, 256)), dim3(256), 0, stream, m, k, nbr_stride, nbr, sel,
+                       (const int *)rev, cursor, rev + m + 1);
+    hipLaunchKernelGGL(nbr_order_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, m, (const int *)rev, rev + m + 1);
+    return launch_status("amc3d_contrast_csr");
 }
 
 // the moments buffer of amc3d_group_moments (same layout) from the reverse lists: exact in-degree, dp sums in list order

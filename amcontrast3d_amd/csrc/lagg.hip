@@ -913,7 +913,7 @@ AMC_API size_t amc3d_grouped_conv_bn_csr_workspace_bytes(int b, int cout, int n,
 }
 
 AMC_API int amc3d_grouped_conv_bn_backward_csr(int b, int cout, int n, int npoints, int nsample, int relu, const float *dx1,
-                                               const float *g_pm, const int *rev_start, const int *rev_edge, const float *dp,
+                                               int dx1_position_major, const float *g_pm, const int *rev_start, const int *rev_edge, const float *dp,
                                                const float *w_dp, const void *moments, const double *gd, const float *mean,
                                                const float *invstd, const float *gamma, const float *beta, float *dg_cm,
                                                float *dw_dp, float *dgamma, float *dbeta, int phase, double *dsums,
@@ -938,7 +938,10 @@ AMC_API int amc3d_grouped_conv_bn_backward_csr(int b, int cout, int n, int npoin
     if (P >= (1L << 31)) return bad_arg("amc3d_grouped_conv_bn_backward_csr: too many positions");
     int nparts = (int)parts;
     if (phase != 2) {
-        if (int st = amc3d_transpose_cn(b, cout, (int)P, dx1, dx1_pm, stream_)) return st;
+        if (dx1_position_major) {
+            if ((uintptr_t)dx1 & 15) return bad_arg("amc3d_grouped_conv_bn_backward_csr: position-major dx1 must be 16-byte aligned");
+            dx1_pm = const_cast<float *>(dx1);  // read only
+        } else if (int st = amc3d_transpose_cn(b, cout, (int)P, dx1, dx1_pm, stream_)) return st;
         if (int st = csr_collapse(b, cout, n, npoints, nsample, relu, dx1_pm, g_pm, rev_start, rev_edge, dp, w_dp, mean, invstd,
                                   gamma, beta, Q, partial, &nparts, stream))
             return st;

@@ -128,6 +128,114 @@ __global__ __launch_bounds__(256) void row_norm_kernel(int m, int C, const float
 }
 
 // ---------------------------------------------------------------------------------------------
+// The anchors that enter the loss, 0 < a <= 1 (MarginContrast.py:250-252), as a compact ascending list:
+// sel[0] = count, sel[1..count] = anchor ids, sel[m+1..] = per-256-block counts (scratch).  The list depends on
+// coordinates and labels only, so it is built with the stage's plan; the contrast kernels then run one full
+// wave per SELECTED anchor instead of testing a_i per anchor (about a quarter are selected on S3DIS-like rooms).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void select_count_kernel(int m, const float *__restrict__ a, int *__restrict__ sel)
+{
+    __shared__ int s_cnt[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool s = i < m && 0.f < a[i] && a[i] <= 1.f;
+    const int c = (int)__popcll(__ballot(s));
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) sel[(size_t)m + 1 + blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+__global__ __launch_bounds__(256) void select_write_kernel(int m, const float *__restrict__ a, int *__restrict__ sel)
+{
+    __shared__ int s_part[4], s_cnt[4];
+    const int *bc = sel + (size_t)m + 1;
+    int before = 0;  // selected anchors in the blocks in front of this one
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) before += bc[b];
+    for (int s = 32; s >= 1; s >>= 1) before += __shfl_xor(before, s, 64);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool sl = i < m && 0.f < a[i] && a[i] <= 1.f;
+    const unsigned long long mask = __ballot(sl);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { s_part[wv] = before; s_cnt[wv] = (int)__popcll(mask); }
+    __syncthreads();
+    int base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    for (int w = 0; w < wv; ++w) base += s_cnt[w];
+    if (sl) sel[1 + base + (int)__popcll(mask & ((1ull << lane) - 1ull))] = i;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        sel[0] = s_part[0] + s_part[1] + s_part[2] + s_part[3] + s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Contrast forward, one wave per anchor (C == 4 * LPR): LPR lanes read one embedding row as 16-byte pieces, so
+// every wave instruction fetches 64/LPR whole rows (full 64-byte sectors, where a lane-per-neighbour stream
+// takes 16 bytes of each sector per instruction), with four such rounds in flight before the first is used.
+// Same per-element arithmetic as contrast_forward_kernel below; the channel sum is a tree over the LPR lanes.
+// sel == nullptr: every anchor is visited and tested.
+// ---------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void contrast_forward_rows_kernel(
+    int m, int k, int nbr_stride, const float *__restrict__ f, const float *__restrict__ norm,
+    const int *__restrict__ nbr, const unsigned char *__restrict__ posmask, const float *__restrict__ a,
+    const int *__restrict__ sel, float mu, float nu, float temperature, float *__restrict__ sim,
+    float *__restrict__ loss_pt)
+{
+    constexpr int R = 64 / LPR;  // rows per round
+    constexpr int U = 4;         // rounds in flight
+    const int lane = threadIdx.x & 63, q = lane & (LPR - 1), r = lane / LPR;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (sel ? sel[0] : m)) return;
+    const int i = sel ? sel[1 + w] : w;
+    const float ai = a[i];
+    if (!(0.f < ai && ai <= 1.f)) {
+        if (lane == 0) loss_pt[i] = 0.f;
+        return;
+    }
+    const float ni = norm[i];
+    const float margin = __fadd_rn(__fmul_rn(mu, ai), nu);
+    const float4 *f4 = reinterpret_cast<const float4 *>(f);
+    float4 u = f4[(size_t)i * LPR + q];
+    u.x = __fdiv_rn(u.x, ni); u.y = __fdiv_rn(u.y, ni); u.z = __fdiv_rn(u.z, ni); u.w = __fdiv_rn(u.w, ni);
+    float psum = 0.f, tsum = 0.f;
+    for (int j0 = 0; j0 < k; j0 += U * R) {
+        int nb[U];
+        bool pos[U];
+        float nj[U];
+        float4 v[U];
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+            const int j = j0 + t * R + r;
+            nb[t] = j < k ? nbr[(size_t)i * nbr_stride + j] : -1;
+            pos[t] = j < k ? posmask[(size_t)i * k + j] != 0 : false;
+        }
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+            nj[t] = nb[t] >= 0 ? norm[nb[t]] : 1.f;
+            v[t] = nb[t] >= 0 ? f4[(size_t)nb[t] * LPR + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+            float acc = u.x * __fdiv_rn(v[t].x, nj[t]);
+            acc += u.y * __fdiv_rn(v[t].y, nj[t]);
+            acc += u.z * __fdiv_rn(v[t].z, nj[t]);
+            acc += u.w * __fdiv_rn(v[t].w, nj[t]);
+#pragma unroll
+            for (int s = LPR / 2; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
+            if (nb[t] >= 0) {
+                if (q == 0) sim[(size_t)i * k + j0 + t * R + r] = acc;
+                const float e = expf(__fdiv_rn(pos[t] ? __fsub_rn(acc, margin) : acc, temperature));
+                psum += pos[t] ? e : 0.f;
+                tsum += e;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = LPR; s < 64; s <<= 1) {  // every lane of a row slot holds the slot's sums: fold the slots
+        psum += __shfl_xor(psum, s, 64);
+        tsum += __shfl_xor(tsum, s, 64);
+    }
+    if (lane == 0) loss_pt[i] = -logf(__fadd_rn(__fdiv_rn(psum, tsum), 1e-12f));
+}
+
+// ---------------------------------------------------------------------------------------------
 // Contrast forward (MarginContrast.py:250-257, 117-174 with margin 'adaptive', db '-m', Method1):
 // 32 lanes per anchor, lane j owns neighbour j (k <= 32 per round); the anchor row is a broadcast
 // load, the neighbour row a per-lane 16-byte stream that stays in L1 across the channel loop.
@@ -136,15 +244,16 @@ __global__ __launch_bounds__(256) void row_norm_kernel(int m, int C, const float
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void contrast_forward_kernel(
     int m, int C, int k, int nbr_stride, const float *__restrict__ f, const float *__restrict__ norm,
-    const int *__restrict__ nbr, const unsigned char *__restrict__ posmask, const float *__restrict__ a, float mu,
-    float nu, float temperature, float *__restrict__ sim, float *__restrict__ loss_pt)
+    const int *__restrict__ nbr, const unsigned char *__restrict__ posmask, const float *__restrict__ a,
+    const int *__restrict__ sel, float mu, float nu, float temperature, float *__restrict__ sim,
+    float *__restrict__ loss_pt)
 {
     const int sub = threadIdx.x & 31;
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    if (i >= m) return;
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (w >= (sel ? sel[0] : m)) return;
+    const int i = sel ? sel[1 + w] : w;
     const float ai = a[i];
-    const bool sel = 0.f < ai && ai <= 1.f;
-    if (!sel) {
+    if (!(0.f < ai && ai <= 1.f)) {
         if (sub == 0) loss_pt[i] = 0.f;
         return;
     }
@@ -243,17 +352,22 @@ __global__ __launch_bounds__(1024) void masked_mean_kernel(int m, const float *_
 // of one row (the shape global float atomics run at full rate for).
 //   l = -log(r + eps), r = P/S, e_j = exp(s'_j / T):  dl/ds_j = -(e_j (pos_j S - P)) / ((r+eps) S^2 T)
 //   ds_j/df_i = (fhat_j - s_j fhat_i)/|f_i|,  ds_j/df_j = (fhat_i - s_j fhat_j)/|f_j|
+// Memory-level parallelism: lane j of the group first loads everything neighbour j needs that is not a row
+// (its index, norm, similarity, mask -- one round trip for all k), the walk then broadcasts those by shuffle and
+// keeps U neighbour rows in flight ahead of the atomics.  sel as in the forward.
 // ---------------------------------------------------------------------------------------------
 template <int LPA, int VPT>
 __global__ __launch_bounds__(256) void contrast_backward_kernel(
     int m, int C, int k, int nbr_stride, const float *__restrict__ f, const float *__restrict__ norm,
-    const int *__restrict__ nbr, const unsigned char *__restrict__ posmask, const float *__restrict__ a, float mu,
-    float nu, float temperature, const float *__restrict__ sim, const float *__restrict__ mean_cnt,
-    const float *__restrict__ grad_out, float *__restrict__ grad_f)
+    const int *__restrict__ nbr, const unsigned char *__restrict__ posmask, const float *__restrict__ a,
+    const int *__restrict__ sel, float mu, float nu, float temperature, const float *__restrict__ sim,
+    const float *__restrict__ mean_cnt, const float *__restrict__ grad_out, float *__restrict__ grad_f)
 {
+    constexpr int U = VPT >= 8 ? 2 : (VPT >= 4 ? 4 : 8);  // neighbour rows in flight
     const int sub = threadIdx.x & (LPA - 1);
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) / LPA;
-    if (i >= m) return;
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) / LPA;
+    if (w >= (sel ? sel[0] : m)) return;
+    const int i = sel ? sel[1 + w] : w;
     const float ai = a[i];
     if (!(0.f < ai && ai <= 1.f)) return;
     const float scale = grad_out[0] / mean_cnt[1];
@@ -267,14 +381,27 @@ __global__ __launch_bounds__(256) void contrast_backward_kernel(
         fhi[v] = c < C ? __fdiv_rn(f[(size_t)i * C + c], ni) : 0.f;
         gi[v] = 0.f;
     }
-    // P and S over all neighbours (lanes stride over j)
+    // lane `sub` holds neighbour j0 + sub of the current chunk of LPA neighbours
+    int nb_l = -1;
+    bool pos_l = false;
+    float sj_l = 0.f, nj_l = 1.f, e_l = 0.f;
+    auto load_chunk = [&](int j0) {
+        const int j = j0 + sub;
+        nb_l = -1; pos_l = false; sj_l = 0.f; nj_l = 1.f; e_l = 0.f;
+        if (j < k) {
+            nb_l = nbr[(size_t)i * nbr_stride + j];
+            pos_l = posmask[(size_t)i * k + j] != 0;
+            sj_l = sim[(size_t)i * k + j];
+            nj_l = norm[nb_l];
+            e_l = expf(__fdiv_rn(pos_l ? __fsub_rn(sj_l, margin) : sj_l, temperature));
+        }
+    };
+    // P and S over all neighbours
     float psum = 0.f, tsum = 0.f;
-    for (int j = sub; j < k; j += LPA) {
-        const bool pos = posmask[(size_t)i * k + j] != 0;
-        const float sj = sim[(size_t)i * k + j];
-        const float e = expf(__fdiv_rn(pos ? __fsub_rn(sj, margin) : sj, temperature));
-        psum += pos ? e : 0.f;
-        tsum += e;
+    for (int j0 = (k - 1) / LPA * LPA; j0 >= 0; j0 -= LPA) {  // ends on chunk 0, which the walk starts with
+        load_chunk(j0);
+        psum += pos_l ? e_l : 0.f;
+        tsum += e_l;
     }
 #pragma unroll
     for (int s = LPA / 2; s >= 1; s >>= 1) {
@@ -285,21 +412,41 @@ __global__ __launch_bounds__(256) void contrast_backward_kernel(
     const float coef = -scale / ((r + 1e-12f) * tsum * tsum * temperature);
     if (psum == 0.f) return;  // no positive neighbour: constant loss, zero gradient
 
-    for (int j = 0; j < k; ++j) {
-        const int nb = nbr[(size_t)i * nbr_stride + j];
-        const bool pos = posmask[(size_t)i * k + j] != 0;
-        const float sj = sim[(size_t)i * k + j];
-        const float e = expf(__fdiv_rn(pos ? __fsub_rn(sj, margin) : sj, temperature));
-        const float g = coef * e * ((pos ? tsum : 0.f) - psum);  // dL/ds_j
-        const float nj = norm[nb];
-        const float gin = g / ni, gjn = g / nj;
+    for (int j0 = 0; j0 < k; j0 += LPA) {
+        if (j0 > 0) load_chunk(j0);
+        const float g_l = coef * e_l * ((pos_l ? tsum : 0.f) - psum);  // dL/ds_j
+        const int cnt = min(LPA, k - j0);
+        for (int jj = 0; jj < cnt; jj += U) {
+            int nb[U];
+            float fj[U][VPT];
 #pragma unroll
-        for (int v = 0; v < VPT; ++v) {
-            const int c = sub + v * LPA;
-            if (c < C) {
-                const float fhj = __fdiv_rn(f[(size_t)nb * C + c], nj);
-                gi[v] += gin * (fhj - sj * fhi[v]);
-                atomicAdd(grad_f + (size_t)nb * C + c, gjn * (fhi[v] - sj * fhj));
+            for (int u = 0; u < U; ++u) {
+                const int src = min(jj + u, LPA - 1);
+                const int t = __shfl(nb_l, src, LPA);
+                nb[u] = jj + u < cnt ? t : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int v = 0; v < VPT; ++v) {
+                    const int c = sub + v * LPA;
+                    fj[u][v] = (nb[u] >= 0 && c < C) ? f[(size_t)nb[u] * C + c] : 0.f;
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int src = min(jj + u, LPA - 1);
+                const float g = __shfl(g_l, src, LPA), sj = __shfl(sj_l, src, LPA), nj = __shfl(nj_l, src, LPA);
+                if (nb[u] < 0) continue;
+                const float gin = g / ni, gjn = g / nj;
+#pragma unroll
+                for (int v = 0; v < VPT; ++v) {
+                    const int c = sub + v * LPA;
+                    if (c < C) {
+                        const float fhj = __fdiv_rn(fj[u][v], nj);
+                        gi[v] += gin * (fhj - sj * fhi[v]);
+                        atomicAdd(grad_f + (size_t)nb[u] * C + c, gjn * (fhi[v] - sj * fhj));
+                    }
+                }
             }
         }
     }
@@ -308,6 +455,113 @@ __global__ __launch_bounds__(256) void contrast_backward_kernel(
         const int c = sub + v * LPA;
         if (c < C) atomicAdd(grad_f + (size_t)i * C + c, gi[v]);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Contrast backward as a gather (no float atomics, fixed summation order, every row of grad_f written once).
+// With g_ij = dL/ds_ij (0 for anchors that are not selected or have no positive neighbour) both halves of the gradient
+// have one form:   dL/df_n = sum over edges (n, x) of  g/|f_n| * (fhat_x - s * fhat_n)
+//   own edges       x = neighbour j of n           (g, s) = (g_nj, s_nj)       when n is a selected anchor
+//   incoming edges  x = anchor i with nbr[i,j] = n (g, s) = (g_ij, s_ij)       listed in rev (amc3d_contrast_csr)
+// contrast_coef_kernel writes g for the selected anchors; contrast_backward_rows_kernel walks, one wave per row n
+// (C == 4 * LPR, 64/LPR edges per round, U rounds of rows in flight), both edge sets and stores the row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void contrast_coef_kernel(
+    int m, int k, const unsigned char *__restrict__ posmask, const float *__restrict__ a, const int *__restrict__ sel,
+    float mu, float nu, float temperature, const float *__restrict__ sim, const float *__restrict__ mean_cnt,
+    const float *__restrict__ grad_out, float *__restrict__ gco)
+{
+    const int sub = threadIdx.x & 31;
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (w >= sel[0]) return;
+    const int i = sel[1 + w];
+    const float ai = a[i];
+    const float scale = grad_out[0] / mean_cnt[1];
+    const float margin = __fadd_rn(__fmul_rn(mu, ai), nu);
+    float psum = 0.f, tsum = 0.f;
+    for (int j = sub; j < k; j += 32) {
+        const bool pos = posmask[(size_t)i * k + j] != 0;
+        const float sj = sim[(size_t)i * k + j];
+        const float e = expf(__fdiv_rn(pos ? __fsub_rn(sj, margin) : sj, temperature));
+        psum += pos ? e : 0.f;
+        tsum += e;
+    }
+    for (int s = 16; s >= 1; s >>= 1) {
+        psum += __shfl_xor(psum, s, 64);
+        tsum += __shfl_xor(tsum, s, 64);
+    }
+    const float r = psum / tsum;
+    const float coef = psum == 0.f ? 0.f : -scale / ((r + 1e-12f) * tsum * tsum * temperature);
+    for (int j = sub; j < k; j += 32) {
+        const bool pos = posmask[(size_t)i * k + j] != 0;
+        const float sj = sim[(size_t)i * k + j];
+        const float e = expf(__fdiv_rn(pos ? __fsub_rn(sj, margin) : sj, temperature));
+        gco[(size_t)i * k + j] = psum == 0.f ? 0.f : coef * e * ((pos ? tsum : 0.f) - psum);
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void contrast_backward_rows_kernel(
+    int m, int k, int nbr_stride, const float *__restrict__ f, const float *__restrict__ norm,
+    const int *__restrict__ nbr, const float *__restrict__ a, const int *__restrict__ rev,
+    const float *__restrict__ sim, const float *__restrict__ gco, float *__restrict__ grad_f)
+{
+    constexpr int R = 64 / LPR;  // edges per round
+    constexpr int U = 4;         // rounds in flight
+    const int lane = threadIdx.x & 63, q = lane & (LPR - 1), r = lane / LPR;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= m) return;
+    const float an = a[n];
+    const int own = (0.f < an && an <= 1.f) ? k : 0;
+    const int e0 = rev[n], deg = rev[n + 1] - e0;
+    const int *rev_edge = rev + m + 1;
+    const int total = own + deg;
+    const float4 *f4 = reinterpret_cast<const float4 *>(f);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (total > 0) {
+        const float nn = norm[n];
+        float4 fn = f4[(size_t)n * LPR + q];
+        fn.x = __fdiv_rn(fn.x, nn); fn.y = __fdiv_rn(fn.y, nn); fn.z = __fdiv_rn(fn.z, nn); fn.w = __fdiv_rn(fn.w, nn);
+        for (int t0 = 0; t0 < total; t0 += U * R) {
+            int x[U];
+            float g[U], sv[U], nx[U];
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * R + r;
+                x[u] = -1; g[u] = 0.f; sv[u] = 0.f;
+                if (t < total) {
+                    int pos;
+                    if (t < own) { pos = n * k + t; x[u] = nbr[(size_t)n * nbr_stride + t]; }
+                    else { pos = rev_edge[e0 + t - own]; x[u] = pos / k; }
+                    g[u] = gco[pos];
+                    sv[u] = sim[pos];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                nx[u] = x[u] >= 0 ? norm[x[u]] : 1.f;
+                v[u] = x[u] >= 0 ? f4[(size_t)x[u] * LPR + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (x[u] < 0) continue;
+                const float gn = g[u] / nn;
+                acc.x += gn * (__fdiv_rn(v[u].x, nx[u]) - sv[u] * fn.x);
+                acc.y += gn * (__fdiv_rn(v[u].y, nx[u]) - sv[u] * fn.y);
+                acc.z += gn * (__fdiv_rn(v[u].z, nx[u]) - sv[u] * fn.z);
+                acc.w += gn * (__fdiv_rn(v[u].w, nx[u]) - sv[u] * fn.w);
+            }
+        }
+#pragma unroll
+        for (int s = LPR; s < 64; s <<= 1) {
+            acc.x += __shfl_xor(acc.x, s, 64);
+            acc.y += __shfl_xor(acc.y, s, 64);
+            acc.z += __shfl_xor(acc.z, s, 64);
+            acc.w += __shfl_xor(acc.w, s, 64);
+        }
+    }
+    if (r == 0) reinterpret_cast<float4 *>(grad_f)[(size_t)n * LPR + q] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -446,8 +700,22 @@ AMC_API int amc3d_ambiguity(int m, int k, int nbr_stride, int mode, float beta, 
     return launch_status("amc3d_ambiguity");
 }
 
+AMC_API size_t amc3d_select_anchors_ints(int m) { return (size_t)(m > 0 ? m : 0) + 1 + (size_t)div_up(m > 0 ? m : 1, 256); }
+
+AMC_API int amc3d_select_anchors(int m, const float *a, int *sel, size_t sel_ints, void *stream_)
+{
+    if (m < 0 || !sel || sel_ints < amc3d_select_anchors_ints(m) || (m > 0 && !a))
+        return bad_arg("amc3d_select_anchors: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (m == 0) return fill_i32(sel, 0, 1, stream);
+    const int nb = div_up(m, 256);
+    hipLaunchKernelGGL(select_count_kernel, dim3(nb), dim3(256), 0, stream, m, a, sel);
+    hipLaunchKernelGGL(select_write_kernel, dim3(nb), dim3(256), 0, stream, m, a, sel);
+    return launch_status("amc3d_select_anchors");
+}
+
 AMC_API int amc3d_contrast_forward(int m, int C, int k, int nbr_stride, const float *f, const int *nbr,
-                                   const unsigned char *posmask, const float *a, float mu, float nu,
+                                   const unsigned char *posmask, const float *a, const int *sel, float mu, float nu,
                                    float temperature, float *norm, float *sim, float *loss_pt, float *mean_cnt,
                                    void *stream_)
 {
@@ -456,15 +724,27 @@ AMC_API int amc3d_contrast_forward(int m, int C, int k, int nbr_stride, const fl
         return bad_arg("amc3d_contrast_forward: bad argument");
     hipStream_t stream = (hipStream_t)stream_;
     hipLaunchKernelGGL(row_norm_kernel, dim3(div_up(m, 4)), dim3(256), 0, stream, m, C, f, norm);
-    hipLaunchKernelGGL(contrast_forward_kernel, dim3(div_up((long)m * 32, 256)), dim3(256), 0, stream, m, C, k,
-                       nbr_stride, f, norm, nbr, posmask, a, mu, nu, temperature, sim, loss_pt);
+#define AMC_FWD(LPR)                                                                                                 \
+    hipLaunchKernelGGL((contrast_forward_rows_kernel<LPR>), dim3(div_up(m, 4)), dim3(256), 0, stream, m, k, nbr_stride, \
+                       f, norm, nbr, posmask, a, sel, mu, nu, temperature, sim, loss_pt)
+    const bool al16 = (((uintptr_t)f) & 15) == 0;
+    if (al16 && C == 16) AMC_FWD(4);
+    else if (al16 && C == 32) AMC_FWD(8);
+    else if (al16 && C == 64) AMC_FWD(16);
+    else if (al16 && C == 128) AMC_FWD(32);
+    else if (al16 && C == 256) AMC_FWD(64);
+    else
+        hipLaunchKernelGGL(contrast_forward_kernel, dim3(div_up((long)m * 32, 256)), dim3(256), 0, stream, m, C, k,
+                           nbr_stride, f, norm, nbr, posmask, a, sel, mu, nu, temperature, sim, loss_pt);
+#undef AMC_FWD
+    // anchors the list skips never write loss_pt; masked_mean_kernel reads the selected ones only
     hipLaunchKernelGGL(masked_mean_kernel, dim3(1), dim3(1024), 0, stream, m, loss_pt, a, mean_cnt);
     return launch_status("amc3d_contrast_forward");
 }
 
 AMC_API int amc3d_contrast_backward(int m, int C, int k, int nbr_stride, const float *f, const float *norm,
-                                    const int *nbr, const unsigned char *posmask, const float *a, float mu, float nu,
-                                    float temperature, const float *sim, const float *mean_cnt,
+                                    const int *nbr, const unsigned char *posmask, const float *a, const int *sel,
+                                    float mu, float nu, float temperature, const float *sim, const float *mean_cnt,
                                     const float *grad_out, float *grad_f, void *stream_)
 {
     if (m <= 0) return 0;
@@ -473,8 +753,8 @@ AMC_API int amc3d_contrast_backward(int m, int C, int k, int nbr_stride, const f
     hipStream_t stream = (hipStream_t)stream_;
 #define AMC_BWD(LPA, VPT)                                                                                           \
     hipLaunchKernelGGL((contrast_backward_kernel<LPA, VPT>), dim3(div_up((long)m * LPA, 256)), dim3(256), 0, stream, \
-                       m, C, k, nbr_stride, f, norm, nbr, posmask, a, mu, nu, temperature, sim, mean_cnt, grad_out,  \
-                       grad_f)
+                       m, C, k, nbr_stride, f, norm, nbr, posmask, a, sel, mu, nu, temperature, sim, mean_cnt,       \
+                       grad_out, grad_f)
     if (C <= 32) AMC_BWD(32, 1);
     else if (C <= 64) AMC_BWD(64, 1);
     else if (C <= 128) AMC_BWD(64, 2);
@@ -482,6 +762,36 @@ AMC_API int amc3d_contrast_backward(int m, int C, int k, int nbr_stride, const f
     else AMC_BWD(64, 8);
 #undef AMC_BWD
     return launch_status("amc3d_contrast_backward");
+}
+
+AMC_API int amc3d_contrast_backward_csr_supported(int C)
+{
+    return C == 16 || C == 32 || C == 64 || C == 128 || C == 256;
+}
+
+AMC_API int amc3d_contrast_backward_csr(int m, int C, int k, int nbr_stride, const float *f, const float *norm,
+                                        const int *nbr, const unsigned char *posmask, const float *a, const int *sel,
+                                        const int *rev, float mu, float nu, float temperature, const float *sim,
+                                        const float *mean_cnt, const float *grad_out, float *gco, float *grad_f,
+                                        void *stream_)
+{
+    if (m <= 0) return 0;
+    if (!amc3d_contrast_backward_csr_supported(C) || k <= 0 || nbr_stride < k || !f || !norm || !nbr || !posmask || !a ||
+        !sel || !rev || !sim || !mean_cnt || !grad_out || !gco || !grad_f || (((uintptr_t)f | (uintptr_t)grad_f) & 15))
+        return bad_arg("amc3d_contrast_backward_csr: bad argument (C must be 16, 32, 64, 128 or 256; 16-byte aligned rows)");
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(contrast_coef_kernel, dim3(div_up((long)m * 32, 256)), dim3(256), 0, stream, m, k, posmask, a, sel, mu,
+                       nu, temperature, sim, mean_cnt, grad_out, gco);
+#define AMC_BWD(LPR)                                                                                                  \
+    hipLaunchKernelGGL((contrast_backward_rows_kernel<LPR>), dim3(div_up(m, 4)), dim3(256), 0, stream, m, k, nbr_stride, f, \
+                       norm, nbr, a, rev, sim, (const float *)gco, grad_f)
+    if (C == 16) AMC_BWD(4);
+    else if (C == 32) AMC_BWD(8);
+    else if (C == 64) AMC_BWD(16);
+    else if (C == 128) AMC_BWD(32);
+    else AMC_BWD(64);
+#undef AMC_BWD
+    return launch_status("amc3d_contrast_backward_csr");
 }
 
 AMC_API size_t amc3d_cross_entropy_workspace_bytes(int B, long N)

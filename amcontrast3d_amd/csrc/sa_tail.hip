@@ -52,7 +52,8 @@ struct SatArgs {
     // mode 2 / 3
     const float *dpooled;
     const float *mean_dq, *mean_dqx;       // mode 3: per-channel means of dq and dq * xhat over all B*M*32 positions
-    float *dx1;                            // mode 3: (B, C1, M, 32)
+    float *dx1;                            // mode 3: (B, C1, M, 32), or (B, M, 32, C1) when dx1_pm
+    int dx1_pm;                            // mode 3: position-major rows (what the gathering backward of the first layer reads)
     unsigned char *arg_out;                // mode 2, optional: (B, C2, M) the arg-max the gradient is routed to
     float *partial_w;                      // mode 3: [part][C2][C1]
 };
@@ -219,7 +220,15 @@ __global__ __launch_bounds__(256) void sat_kernel(SatArgs a)
                     accd = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accd, 0, 0, 0);
                 }
                 const long p = p0 + wave * 32 + pl;
-                if (p < P) {
+                if (p < P && a.dx1_pm) {
+                    // a lane holds channels 8q + 4kh .. +3 of its position: four 16-byte stores, the kh pair of a
+                    // position covering 32 contiguous bytes per instruction (C1 % 4 == 0, checked by the host)
+                    float4 *row4 = reinterpret_cast<float4 *>(a.dx1 + ((size_t)b * P + p) * C1 + it * 32 + 4 * kh);
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4)
+                        if (it * 32 + 8 * q4 + 4 * kh < C1)
+                            row4[2 * q4] = make_float4(accd[4 * q4], accd[4 * q4 + 1], accd[4 * q4 + 2], accd[4 * q4 + 3]);
+                } else if (p < P) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
@@ -437,11 +446,13 @@ AMC_API int amc3d_sa_tail_forward(int B, int C1, int C2, int M, int K, const flo
 AMC_API int amc3d_sa_tail_backward(int B, int C1, int C2, int M, int K, const float *y1, const float *mean1,
                                    const float *invstd1, const float *gamma1, const float *beta1, const float *w2,
                                    const float *mean2, const float *invstd2, const float *gamma2, const float *beta2,
-                                   int relu2, const float *dpooled, float *dx1, float *dw2,
+                                   int relu2, const float *dpooled, float *dx1, int dx1_position_major, float *dw2,
                                    float *dgamma2, float *dbeta2, unsigned char *arg_out, void *workspace,
                                    size_t workspace_bytes, void *stream_)
 {
     if (B <= 0 || M <= 0) return 0;
+    if (dx1_position_major && ((C1 & 3) || !sat_aligned16(dx1)))
+        return bad_arg("amc3d_sa_tail_backward: position-major dx1 needs C1 % 4 == 0 and a 16-byte aligned buffer");
     if (!sat_supported(C1, C2, K) || !y1 || !mean1 || !invstd1 || !gamma1 || !beta1 || !w2 || !mean2 || !invstd2 || !gamma2 ||
         !beta2 || !dpooled || !dx1 || !dw2 || !dgamma2 || !dbeta2 || !workspace || !sat_aligned16(y1) ||
         workspace_bytes < amc3d_sa_tail_workspace_bytes(B, C1, C2, M))
@@ -461,7 +472,7 @@ AMC_API int amc3d_sa_tail_backward(int B, int C1, int C2, int M, int K, const fl
                        (double)B * (double)M * 32.0, 0.f, -1.f, 1, (const double *)partial, dbeta2, dgamma2, means, means + C2,
                        (float *)nullptr, (float *)nullptr, (long long *)nullptr, B, M, relu2, (const float *)nullptr,
                        (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
-    a.mean_dq = means; a.mean_dqx = means + C2; a.dx1 = dx1; a.partial_w = partial_w;
+    a.mean_dq = means; a.mean_dqx = means + C2; a.dx1 = dx1; a.dx1_pm = dx1_position_major ? 1 : 0; a.partial_w = partial_w;
     sat_launch<3>(a, groups, stream);
     if (int st = launch_status("amc3d_sa_tail_backward")) return st;
     return reduce_partials(C2 * C1, (int)parts, partial_w, dw2, stream);

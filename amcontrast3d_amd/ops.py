@@ -474,15 +474,54 @@ def ambiguity(p, posmask, neighbor_idx, cctype, beta):
     return a
 
 
+def select_anchors(a):
+    """a (m) fp32 -> int32 list of the anchors with 0 < a <= 1 (MarginContrast.py:250-252), ascending:
+    [0] = count, [1..count] = ids (the tail of the tensor is scratch).  Part of a stage's plan: it depends on
+    coordinates and labels only."""
+    _need_gpu(a)
+    _need_dtype(torch.float32, a=a)
+    assert a.is_contiguous() and a.dim() == 1
+    m = a.shape[0]
+    lib = _lib.load()
+    n = int(lib.amc3d_select_anchors_ints(m))
+    sel = torch.empty(n, dtype=torch.int32, device=a.device)
+    with torch.cuda.device(a.device), timing.span("select_anchors", m * 12):
+        _lib.check(lib.amc3d_select_anchors(m, _ptr(a), _ptr(sel), n, _stream(a)), "select_anchors")
+    return sel
+
+
+def contrast_csr(neighbor_idx, anchors):
+    """Reverse lists of a loss stage's k-NN edges: neighbor_idx (m,k) int32 (may be idx[:, 1:]), anchors =
+    select_anchors(a) -> int32 [rev_start (m+1) | rev_edge (m*k)]: for every row n the positions i*k + j, ascending, of the
+    selected anchors i whose j-th neighbour is n.  Part of a stage's plan; ContrastStage's backward gathers along it
+    instead of scattering with float atomics."""
+    _need_gpu(neighbor_idx, anchors)
+    _need_dtype(torch.int32, anchors=anchors)
+    nptr, k, stride, keep = _nbr_view(neighbor_idx)
+    m = neighbor_idx.shape[0]
+    lib = _lib.load()
+    rev = torch.empty(m + 1 + m * k, dtype=torch.int32, device=anchors.device)
+    wbytes = int(lib.amc3d_contrast_csr_workspace_bytes(m))
+    work = torch.empty(wbytes, dtype=torch.uint8, device=anchors.device)
+    with torch.cuda.device(anchors.device), timing.span("contrast_csr", m * k * 12):
+        _lib.check(lib.amc3d_contrast_csr(m, k, stride, nptr, _ptr(anchors), _ptr(rev), _ptr(work), wbytes,
+                                          _stream(anchors)), "contrast_csr")
+    return rev
+
+
 class ContrastStage(Function):
     """Stage loss of ContrastHead.point_contrast_margin (MarginContrast.py:250-257): mean over the
-    anchors with 0 < a <= 1 of the margin soft-NN loss on cosine similarities."""
+    anchors with 0 < a <= 1 of the margin soft-NN loss on cosine similarities.  anchors: select_anchors(a) of
+    the same a, or None (every anchor is then visited and tested)."""
 
     @staticmethod
-    def forward(ctx, features, neighbor_idx, posmask, a, mu, nu, temperature):
+    def forward(ctx, features, neighbor_idx, posmask, a, mu, nu, temperature, anchors=None, rev=None):
         _need_gpu(features, neighbor_idx, posmask, a)
         f = features.contiguous()
         assert f.dtype == torch.float32 and posmask.dtype == torch.bool and posmask.is_contiguous()
+        if anchors is not None:
+            _need_dtype(torch.int32, anchors=anchors)
+            assert anchors.is_contiguous() and anchors.numel() >= f.shape[0] + 1 and anchors.device == f.device
         nptr, k, stride, keep = _nbr_view(neighbor_idx)
         m, C = f.shape
         dev = f.device
@@ -492,28 +531,41 @@ class ContrastStage(Function):
         mean_cnt = torch.empty(2, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev), timing.span("contrast_forward", m * C * 4 * (1 + k) + m * k * 9 + m * 12):
             _lib.check(_lib.load().amc3d_contrast_forward(m, C, k, stride, _ptr(f), nptr, _ptr(posmask), _ptr(a),
+                                                          _ptr(anchors) if anchors is not None else None,
                                                           float(mu), float(nu), float(temperature), _ptr(norm),
                                                           _ptr(sim), _ptr(loss_pt), _ptr(mean_cnt), _stream(f)),
                        "contrast_forward")
-        ctx.save_for_backward(f, norm, keep, posmask, a, sim, mean_cnt)
+        if rev is not None:
+            _need_dtype(torch.int32, rev=rev)
+            assert anchors is not None and rev.is_contiguous() and rev.numel() == m + 1 + m * k and rev.device == dev
+        ctx.save_for_backward(f, norm, keep, posmask, a, sim, mean_cnt, anchors, rev)
         ctx.args = (float(mu), float(nu), float(temperature), k, stride)
         return mean_cnt[0].clone()
 
     @staticmethod
     def backward(ctx, grad_out):
-        f, norm, nbr, posmask, a, sim, mean_cnt = ctx.saved_tensors
+        f, norm, nbr, posmask, a, sim, mean_cnt, anchors, rev = ctx.saved_tensors
         mu, nu, temperature, k, stride = ctx.args
         m, C = f.shape
         g = grad_out.detach().to(torch.float32).reshape(1).contiguous()
+        nptr = _ptr(nbr)  # data_ptr includes the offset of an idx[:, 1:] view: the first used column
+        lib = _lib.load()
+        if rev is not None and lib.amc3d_contrast_backward_csr_supported(C):
+            grad_f = torch.empty_like(f)  # every row is written
+            gco = torch.empty(m * k, dtype=torch.float32, device=f.device)
+            with torch.cuda.device(f.device), timing.span("contrast_backward_csr", m * C * 4 * (2 + 2 * k) + m * k * 17):
+                _lib.check(lib.amc3d_contrast_backward_csr(m, C, k, stride, _ptr(f), _ptr(norm), nptr, _ptr(posmask),
+                                                           _ptr(a), _ptr(anchors), _ptr(rev), mu, nu, temperature,
+                                                           _ptr(sim), _ptr(mean_cnt), _ptr(g), _ptr(gco), _ptr(grad_f),
+                                                           _stream(f)), "contrast_backward_csr")
+            return grad_f, None, None, None, None, None, None, None, None
         grad_f = torch.zeros_like(f)
-        nptr = _ptr(nbr)
-        if nbr.storage_offset() and nbr.stride(1) == 1:
-            pass  # _ptr already points at the first used column (data_ptr includes the offset)
         with torch.cuda.device(f.device), timing.span("contrast_backward", m * C * 4 * (1 + 2 * k) + m * k * 9):
             _lib.check(_lib.load().amc3d_contrast_backward(m, C, k, stride, _ptr(f), _ptr(norm), nptr, _ptr(posmask),
-                                                           _ptr(a), mu, nu, temperature, _ptr(sim), _ptr(mean_cnt),
+                                                           _ptr(a), _ptr(anchors) if anchors is not None else None,
+                                                           mu, nu, temperature, _ptr(sim), _ptr(mean_cnt),
                                                            _ptr(g), _ptr(grad_f), _stream(f)), "contrast_backward")
-        return grad_f, None, None, None, None, None, None
+        return grad_f, None, None, None, None, None, None, None, None
 
 
 contrast_stage = ContrastStage.apply
@@ -1084,7 +1136,11 @@ class GroupedConvBN(Function):
         C = w_f.shape[0]
         dev = f.device
         lib = _lib.load()
-        dx1 = dx1.contiguous()
+        # SATailActivated hands the gradient over as position-major rows (a (B,C,M,K) view of a (B,M,K,C) buffer): the
+        # gather along the reverse lists reads those directly; any other layout is made channel-major and transposed
+        dx1_pm = ctx.csr is not None and dx1.dim() == 4 and dx1.permute(0, 2, 3, 1).is_contiguous() and C > 1
+        if not dx1_pm:
+            dx1 = dx1.contiguous()
         dg_cm = torch.empty(B, C, N, dtype=torch.float32, device=dev)
         dw_dp = torch.empty(C, 3, dtype=torch.float32, device=dev)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
@@ -1104,7 +1160,7 @@ class GroupedConvBN(Function):
         def call(phase):
             if csr is not None:
                 _lib.check(lib.amc3d_grouped_conv_bn_backward_csr(
-                    B, C, N, M, K, int(ctx.relu), _ptr(dx1), _ptr(g_pm), _ptr(csr[0]), _ptr(csr[1]), _ptr(dp), _ptr(w_dp),
+                    B, C, N, M, K, int(ctx.relu), _ptr(dx1), int(dx1_pm), _ptr(g_pm), _ptr(csr[0]), _ptr(csr[1]), _ptr(dp), _ptr(w_dp),
                     _ptr(moments), _ptr(gd), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dg_cm), _ptr(dw_dp),
                     _ptr(dgamma), _ptr(dbeta), phase, _ptr(dsums), count, _ptr(work), wb, _stream(f)),
                     "grouped_conv_bn_backward_csr")
@@ -1402,7 +1458,7 @@ class SATail(Function):
         with torch.cuda.device(dev), timing.span("sa_tail_backward", y1.numel() * 4 * 6 + dpooled.numel() * 10, flops):
             _lib.check(lib.amc3d_sa_tail_backward(B, C1, C2, M, K, _ptr(y1), _ptr(mean1), _ptr(invstd1), _ptr(g1), _ptr(b1),
                                                   _ptr(w2f), _ptr(mean2), _ptr(invstd2), _ptr(g2), _ptr(b2), int(ctx.relu2),
-                                                  _ptr(dpooled), _ptr(dx1), _ptr(dw2), _ptr(dg2), _ptr(db2),
+                                                  _ptr(dpooled), _ptr(dx1), 0, _ptr(dw2), _ptr(dg2), _ptr(db2),
                                                   _ptr(arg) if arg is not None else None,
                                                   _ptr(work), wb, _stream(y1)), "sa_tail_backward")
             # BN1 + ReLU backward on the raw y1 (csrc/bn.hip)
@@ -1459,7 +1515,15 @@ class SATailActivated(Function):
         dev = x1.device
         dpooled = dpooled.contiguous()
         lib = _lib.load()
-        dx1 = torch.empty_like(x1)
+        # x1 comes from GroupedConvBN, whose backward gathers position-major rows: the gradient is written as
+        # (B,M,K,C1) and returned as a (B,C1,M,K) view of it -- no transpose pass between the two (393 MB at SA1)
+        import os
+        pm = C1 % 4 == 0 and C1 > 1 and not os.environ.get("AMC3D_SAT_DX1_CM")
+        if pm:
+            dx1_buf = torch.empty(B, M, K, C1, dtype=torch.float32, device=dev)
+            dx1 = dx1_buf.permute(0, 3, 1, 2)
+        else:
+            dx1_buf = dx1 = torch.empty_like(x1)
         dw2 = torch.empty(C2, C1, dtype=torch.float32, device=dev)
         dg2, db2 = torch.empty_like(g2), torch.empty_like(b2)
         wb = int(lib.amc3d_sa_tail_workspace_bytes(B, C1, C2, M))
@@ -1471,7 +1535,7 @@ class SATailActivated(Function):
                                                  2.0 * B * M * K * C1 * C2 * 4):
             _lib.check(lib.amc3d_sa_tail_backward(B, C1, C2, M, K, _ptr(x1), _ptr(zeros), _ptr(ones), _ptr(ones), _ptr(zeros),
                                                   _ptr(w2f), _ptr(mean2), _ptr(invstd2), _ptr(g2), _ptr(b2), int(ctx.relu2),
-                                                  _ptr(dpooled), _ptr(dx1), _ptr(dw2), _ptr(dg2), _ptr(db2),
+                                                  _ptr(dpooled), _ptr(dx1_buf), int(pm), _ptr(dw2), _ptr(dg2), _ptr(db2),
                                                   _ptr(arg) if arg is not None else None,
                                                   _ptr(work), wb, _stream(x1)), "sa_tail_backward")
         return dx1, dw2.view(ctx.wshape), dg2, db2, None, None, None

@@ -172,20 +172,42 @@ int amc3d_ambiguity(int m, int k, int nbr_stride, int mode, float beta, const fl
                     const unsigned char *posmask, const int *nbr, float *a, void *workspace,
                     size_t workspace_bytes, void *stream);
 
+/* The anchors that enter the stage loss, 0 < a <= 1 (MarginContrast.py:250-252: the boolean-mask indexing
+ * features[mask], neighbor_feature[mask], ...), as a compact ascending list built once per stage plan:
+ * sel[0] = count, sel[1..count] = anchor ids; sel holds amc3d_select_anchors_ints(m) ints (the tail is scratch). */
+size_t amc3d_select_anchors_ints(int m);
+int amc3d_select_anchors(int m, const float *a, int *sel, size_t sel_ints, void *stream);
+
 /* Stage loss = mean over anchors with 0 < a <= 1 of
  *   -log( sum_+ e^{(s-m_i)/T} / (sum_+ e^{(s-m_i)/T} + sum_- e^{s/T}) + 1e-12 ),  m_i = mu*a_i + nu,
  * s = cosine similarity of the (m,C) embeddings f.  Outputs: norm (m) clamped row norms, sim (m,k),
- * loss_pt (m), mean_cnt[2] = {stage loss, number of anchors}; all kept for the backward. */
+ * loss_pt (m), mean_cnt[2] = {stage loss, number of anchors}; all kept for the backward.
+ * sel: the list of amc3d_select_anchors for this a (sim / loss_pt are then written for the listed anchors
+ * only), or NULL to visit and test every anchor. */
 int amc3d_contrast_forward(int m, int C, int k, int nbr_stride, const float *f, const int *nbr,
-                           const unsigned char *posmask, const float *a, float mu, float nu, float temperature,
-                           float *norm, float *sim, float *loss_pt, float *mean_cnt, void *stream);
+                           const unsigned char *posmask, const float *a, const int *sel, float mu, float nu,
+                           float temperature, float *norm, float *sim, float *loss_pt, float *mean_cnt, void *stream);
 
 /* grad_f (m,C) += grad_out[0] * d(stage loss)/d f; the caller zero-initialises grad_f.
- * grad_out is a DEVICE scalar (no host sync).  C <= 512. */
+ * grad_out is a DEVICE scalar (no host sync).  C <= 512.  sel as in the forward. */
 int amc3d_contrast_backward(int m, int C, int k, int nbr_stride, const float *f, const float *norm,
-                            const int *nbr, const unsigned char *posmask, const float *a, float mu, float nu,
-                            float temperature, const float *sim, const float *mean_cnt, const float *grad_out,
-                            float *grad_f, void *stream);
+                            const int *nbr, const unsigned char *posmask, const float *a, const int *sel, float mu,
+                            float nu, float temperature, const float *sim, const float *mean_cnt,
+                            const float *grad_out, float *grad_f, void *stream);
+
+/* The same gradient as a gather over reverse lists instead of float atomics (group_points_grad-style scatter,
+ * MarginContrast.py:250-257 through autograd's index_put backward): fixed summation order, every row of grad_f WRITTEN
+ * once (no zero-initialisation).  rev = [rev_start (m+1) | rev_edge (m*k)] int32 from amc3d_contrast_csr: the positions
+ * i*k + j, ascending, of the selected anchors i whose neighbour j is row n; built with the stage's plan (coordinates and
+ * labels only).  gco: m*k floats of scratch (dL/ds per edge).  C in {16, 32, 64, 128, 256}. */
+size_t amc3d_contrast_csr_workspace_bytes(int m);
+int amc3d_contrast_csr(int m, int k, int nbr_stride, const int *nbr, const int *sel, int *rev, void *workspace,
+                       size_t workspace_bytes, void *stream);
+int amc3d_contrast_backward_csr_supported(int C);
+int amc3d_contrast_backward_csr(int m, int C, int k, int nbr_stride, const float *f, const float *norm, const int *nbr,
+                                const unsigned char *posmask, const float *a, const int *sel, const int *rev, float mu,
+                                float nu, float temperature, const float *sim, const float *mean_cnt,
+                                const float *grad_out, float *gco, float *grad_f, void *stream);
 
 /* ---- grouped 1x1 convolution fused with its gather (fp32 MFMA) ------------------------------------
  * Replaces, for the first layer of a SetAbstraction / LocalAggregation MLP, the chain
@@ -333,10 +355,12 @@ int amc3d_group_csr(int b, int n, int npoints, int nsample, const int *idx, int 
 /* the moments buffer of amc3d_group_moments from the lists (no scattered atomics) */
 int amc3d_group_moments_csr(int b, int n, int npoints, int nsample, const int *rev_start, const int *rev_edge,
                             const float *dp, void *moments, size_t moments_bytes, void *stream);
-/* amc3d_grouped_conv_bn_backward as a gather over the lists (dx1 is transposed to position-major in the workspace) */
+/* amc3d_grouped_conv_bn_backward as a gather over the lists.  dx1 (b,cout,npoints,nsample) is transposed to position-major
+ * rows in the workspace first, or, with dx1_position_major, is already (b,npoints,nsample,cout) (amc3d_sa_tail_backward
+ * writes it that way) and is read in place. */
 size_t amc3d_grouped_conv_bn_csr_workspace_bytes(int b, int cout, int n, int npoints, int nsample);
 int amc3d_grouped_conv_bn_backward_csr(int b, int cout, int n, int npoints, int nsample, int relu, const float *dx1,
-                                       const float *g_pm, const int *rev_start, const int *rev_edge, const float *dp,
+                                       int dx1_position_major, const float *g_pm, const int *rev_start, const int *rev_edge, const float *dp,
                                        const float *w_dp, const void *moments, const double *gd, const float *mean,
                                        const float *invstd, const float *gamma, const float *beta, float *dg_cm, float *dw_dp,
                                        float *dgamma, float *dbeta, int phase, double *dsums, const double *count,
@@ -361,13 +385,14 @@ int amc3d_sa_tail_forward(int B, int C1, int C2, int M, int K, const float *y1, 
                           float *pooled, float *mean2, float *invstd2, float *var_unbiased2,
                           float *running_mean2, float *running_var2, long long *num_batches_tracked2,
                           void *workspace, size_t workspace_bytes, void *stream);
-/* dx1 (B,C1,M,32) = gradient w.r.t. relu(bn1(y1)); dw2 (C2,C1) deterministic; dgamma2, dbeta2 (C2);
+/* dx1 (B,C1,M,32) = gradient w.r.t. relu(bn1(y1)) -- written as (B,M,32,C1) rows when dx1_position_major
+ * (C1 % 4 == 0), the layout amc3d_grouped_conv_bn_backward_csr gathers from; dw2 (C2,C1) deterministic; dgamma2, dbeta2 (C2);
  * arg_out (B,C2,M) bytes or NULL: the neighbour each pooled gradient was routed to (what torch.max returns as
  * indices, pointnext_AA.py:166) -- the parity tests hold the routing fixed with it */
 int amc3d_sa_tail_backward(int B, int C1, int C2, int M, int K, const float *y1, const float *mean1,
                            const float *invstd1, const float *gamma1, const float *beta1, const float *w2,
                            const float *mean2, const float *invstd2, const float *gamma2, const float *beta2,
-                           int relu2, const float *dpooled, float *dx1, float *dw2,
+                           int relu2, const float *dpooled, float *dx1, int dx1_position_major, float *dw2,
                            float *dgamma2, float *dbeta2, unsigned char *arg_out, void *workspace,
                            size_t workspace_bytes, void *stream);
 

@@ -155,7 +155,7 @@ def test_reverse_lists_moments_and_gather_backward():
     """csrc/csr.hip: the reverse adjacency of a ball query (every position exactly once, under its target, ascending), the
     geometry moments derived from it (identical in-degree, dp sums equal to the fixed-point atomics' up to the double
     summation order), and GroupedConvBN's backward as a gather over the lists against its float-atomic form."""
-    from amcontrast3d_amd import ops
+    from amcontrast3d_amd import ops, timing
     B, Cin, C, N, M, K = 3, 32, 64, 1500, 375, 32
     p, idx, dp, f, w, gamma, beta, _ = _case(B, Cin, C, N, M, K, 77, True)
     start, edge = ops.group_csr(idx, N)
@@ -192,4 +192,12 @@ def test_reverse_lists_moments_and_gather_backward():
     fr, wr, gr, br = (t.clone().requires_grad_(True) for t in (f, w, gamma, beta))
     x1 = ops.GroupedConvBN.apply(fr, dp, idx, ops.group_moments(idx, dp, N), wr, gr, br, 1e-5, True, None, (start, edge))
     x1.backward(go)
+    assert all(torch.equal(a, t.grad) for a, t in zip(grads[1], (fr, wr, gr, br)))
+    # ... and reads a gradient that arrives as position-major rows (the layout SATailActivated writes) in place
+    fr, wr, gr, br = (t.clone().requires_grad_(True) for t in (f, w, gamma, beta))
+    x1 = ops.GroupedConvBN.apply(fr, dp, idx, ops.group_moments(idx, dp, N), wr, gr, br, 1e-5, True, None, (start, edge))
+    go_pm = go.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    assert not go_pm.is_contiguous() and torch.equal(go_pm, go)
+    with timing.count_calls() as calls:
+        x1.backward(go_pm)
     assert all(torch.equal(a, t.grad) for a, t in zip(grads[1], (fr, wr, gr, br)))

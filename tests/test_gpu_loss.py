@@ -75,12 +75,39 @@ def test_vote_labels(kr, ncls):
     assert torch.equal(got.cpu().long(), want)
 
 
-@pytest.mark.parametrize("m,C,seed", [(3000, 32, 0), (1500, 64, 1), (800, 128, 2), (300, 256, 3), (200, 20, 4)])
-def test_contrast_stage_forward_backward(m, C, seed):
+@pytest.mark.parametrize("m", [1, 63, 256, 257, 5000])
+@pytest.mark.parametrize("frac", [0.0, 0.3, 1.0])
+def test_select_anchors(m, frac):
+    """the compact list of the anchors with 0 < a <= 1 (MarginContrast.py:250-252) == torch.nonzero of the mask"""
+    from amcontrast3d_amd import ops
+    g = torch.Generator().manual_seed(m)
+    a = torch.rand(m, generator=g) * 1.2  # some above 1: excluded
+    a[torch.rand(m, generator=g) >= frac] = 0.0
+    want = torch.nonzero((0 < a) & (a <= 1)).flatten()
+    sel = ops.select_anchors(a.to(DEV)).cpu()
+    assert int(sel[0]) == want.numel()
+    assert torch.equal(sel[1:1 + want.numel()].long(), want)
+
+
+@pytest.mark.parametrize("listed", [True, False, "rev"])
+@pytest.mark.parametrize("m,C,seed", [(3000, 32, 0), (1500, 64, 1), (800, 128, 2), (300, 256, 3), (200, 20, 4),
+                                      (400, 16, 5), (100, 512, 6)])
+def test_contrast_stage_forward_backward(m, C, seed, listed):
+    _contrast_case(m, C, seed, listed, 24)
+
+
+@pytest.mark.parametrize("m,C,K", [(500, 32, 41), (300, 64, 70), (300, 128, 5), (200, 24, 37)])
+def test_contrast_stage_other_neighbourhood_sizes(m, C, K):
+    """k beyond one group of lanes (the backward walks the neighbours in chunks), and very small k"""
+    _contrast_case(m, C, K, True, K)
+    _contrast_case(m, C, K + 1, "rev", K)
+
+
+def _contrast_case(m, C, seed, listed, K):
     from amcontrast3d_amd import ops
     g = torch.Generator().manual_seed(seed)
     f = torch.randn(m, C, generator=g)
-    idx24 = torch.randint(0, m, (m, 24), generator=g, dtype=torch.int32)
+    idx24 = torch.randint(0, m, (m, K), generator=g, dtype=torch.int32)
     lab = torch.randint(0, 4, (m,), generator=g)
     a = torch.rand(m, generator=g)
     a[torch.rand(m, generator=g) < 0.5] = 0.0  # consistent points: excluded
@@ -92,7 +119,7 @@ def test_contrast_stage_forward_backward(m, C, seed):
     # reference composition (MarginContrast.py:250-257, 117-174) in torch on the CPU
     fr = f.clone().requires_grad_(True)
     keep = (0 < a) & (a <= 1)
-    nf = fr[nidx.reshape(-1).long()].view(m, 23, C)
+    nf = fr[nidx.reshape(-1).long()].view(m, K - 1, C)
     sim = F.cosine_similarity(fr[keep].unsqueeze(-2), nf[keep], dim=2)
     pm = posmask[keep]
     margin = mu * a[keep].unsqueeze(-1) + nu
@@ -103,7 +130,17 @@ def test_contrast_stage_forward_backward(m, C, seed):
 
     fg = f.to(DEV).requires_grad_(True)
     idx_dev = idx24.to(DEV)
-    got = ops.contrast_stage(fg, idx_dev[:, 1:], posmask.to(DEV).contiguous(), a.to(DEV), mu, nu, T)
+    anchors = ops.select_anchors(a.to(DEV)) if listed else None
+    rev = ops.contrast_csr(idx_dev[:, 1:], anchors) if listed == "rev" else None
+    if rev is not None:  # the lists against a plain enumeration of the selected anchors' edges
+        start, edge = rev[:m + 1].cpu().long(), rev[m + 1:].cpu().long()
+        sel_rows = torch.nonzero(keep).flatten()
+        pos = (sel_rows[:, None] * (K - 1) + torch.arange(K - 1)[None, :]).flatten()
+        tgt = nidx[sel_rows].long().flatten()
+        order = torch.argsort(tgt * (m * K) + pos)
+        assert torch.equal(start, torch.searchsorted(tgt[order], torch.arange(m + 1)))
+        assert torch.equal(edge[:pos.numel()], pos[order])
+    got = ops.contrast_stage(fg, idx_dev[:, 1:], posmask.to(DEV).contiguous(), a.to(DEV), mu, nu, T, anchors, rev)
     assert abs(float(got) - float(want)) <= 1e-5 * max(1.0, abs(float(want)))
     (got * 0.9).backward()
     err = float((fg.grad.cpu() - fr.grad).norm() / fr.grad.norm())

@@ -76,3 +76,31 @@ def test_sa_blocks_route_through_the_tail_and_match_the_module_stack():
     assert float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
     for (k, a), (_, b) in zip(blocks.state_dict().items(), ref.state_dict().items()):
         assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6), k  # running stats of both BatchNorms
+
+
+@pytest.mark.parametrize("B,C1,C2,M", [(2, 32, 64, 257), (1, 64, 128, 100), (2, 16, 32, 33)])
+def test_activated_tail_hands_its_gradient_over_position_major(B, C1, C2, M, monkeypatch):
+    """ops.SATailActivated writes d/dx1 as (B,M,32,C1) rows behind a (B,C1,M,32) view -- the layout the first layer's
+    gathering backward reads -- with the same values as the channel-major store"""
+    from amcontrast3d_amd import ops
+    g = torch.Generator().manual_seed(C1 + C2 + M)
+    x1 = torch.relu(torch.randn(B, C1, M, 32, generator=g)).to(DEV)
+    w2 = (torch.randn(C2, C1, 1, 1, generator=g) * 0.2).to(DEV)
+    g2, b2 = (torch.rand(C2, generator=g) + 0.5).to(DEV), (torch.randn(C2, generator=g) * 0.2).to(DEV)
+    gout = torch.randn(B, C2, M, generator=g).to(DEV)
+    res = []
+    for cm in (True, False):
+        if cm:
+            monkeypatch.setenv("AMC3D_SAT_DX1_CM", "1")
+        else:
+            monkeypatch.delenv("AMC3D_SAT_DX1_CM")
+        leaves = [t.clone().requires_grad_(True) for t in (x1, w2, g2, b2)]
+        seen = []
+        leaves[0].register_hook(lambda gr: seen.append(gr))  # the gradient tensor as the producer of x1 receives it
+        out = ops.SATailActivated.apply(leaves[0], leaves[1], leaves[2], leaves[3], 1e-5, True, None)
+        out.backward(gout)
+        res.append((seen[0], [t.grad for t in leaves[1:]], out.detach()))
+    (d_cm, r_cm, o_cm), (d_pm, r_pm, o_pm) = res
+    assert d_cm.is_contiguous() and d_pm.permute(0, 2, 3, 1).is_contiguous() and d_pm.shape == d_cm.shape
+    assert torch.equal(d_pm, d_cm) and torch.equal(o_cm, o_pm)
+    assert all(torch.equal(a, b) for a, b in zip(r_cm, r_pm))
