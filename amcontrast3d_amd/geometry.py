@@ -145,6 +145,15 @@ def split(plan):
     return fps, rest
 
 
+def join(fps, rest):
+    """Inverse of split(): a full plan whose dicts reference the tensors of `fps` and `rest` (no copies)."""
+    plan = {"encoder": [[dict(f, **b[0])] + list(b[1:]) for f, b in zip(fps, rest["encoder"])],
+            "decoder": rest["decoder"], "loss": rest["loss"]}
+    if "refine" in rest:
+        plan["refine"] = rest["refine"]
+    return plan
+
+
 def stage_points(plan):
     """The flattened clouds of the loss stages of a sampling plan: [{'p_out' (B*n,3), 'offset'}] x 4
     (what pointnext_AA.py:458-462 puts into stageACE_list)."""

@@ -35,6 +35,7 @@ class SegmentedGraph:
         self.items = []      # torch.cuda.CUDAGraph | callable, in replay order
         self.pool = None
         self._cur = None
+        self._side = None
 
     # -- capture ---------------------------------------------------------------------------------
     def _begin(self):
@@ -49,7 +50,15 @@ class SegmentedGraph:
     def _cut(self, fn):
         self._end()
         self.items.append(fn)
-        out = fn()  # keeps the ranks' collective sequences aligned during the capturing pass
+        # Keeps the ranks' collective sequences aligned during the capturing pass -- on a SIDE stream: c10d runs a blocking
+        # collective on the caller's stream and records the work's completion event there, its watchdog thread polls that
+        # event, and polling an event of a stream that has meanwhile begun capturing again fails with
+        # hipErrorCapturedEvent and invalidates the capture (seen as an intermittent abort, once in a few runs).
+        cur = torch.cuda.current_stream()
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            out = fn()
+        cur.wait_stream(self._side)
         self._begin()
         return out
 
@@ -60,6 +69,7 @@ class SegmentedGraph:
         assert _active is None and not self.items, "one capture per SegmentedGraph"
         stream = stream if stream is not None else torch.cuda.current_stream()
         self.pool = torch.cuda.graph_pool_handle()
+        self._side = torch.cuda.Stream()
         torch.cuda.synchronize()
         with torch.cuda.stream(stream), torch.autograd.set_multithreading_enabled(False):
             _active = self

@@ -429,6 +429,14 @@ def main():
     # the pipeline's period: lane and pool index of step s are s % lanes and (s + lanes + 3) % npool
     import math
     period = lanes * npool // math.gcd(lanes, npool) if overlap else npool
+    # Hand-over of the neighbourhood / loss geometry (~100 MB per batch) from stream B to the feature half: with graphs the
+    # two never meet in a copy.  Stream B has two captured variants that write their results into two result sets R[0], R[1]
+    # (the graphs' own output tensors), the feature half two variants that read them: step n reads R[n % 2] while B fills
+    # R[(n + 1) % 2] for the next batch.  (Eager mode, and AMC3D_NO_PINGPONG=1, copy b_out -> cur_rest on the main stream
+    # instead: 0.26 ms of multi-tensor copies per step, and as much again on stream B.)
+    pingpong = overlap and use_graph and not os.environ.get("AMC3D_NO_PINGPONG")
+    if pingpong and period % 2:
+        period *= 2
     if overlap:
         # every in-flight batch has its own static input buffers, handed down the pipeline by rotate():
         #   in_a[lane] (first FPS level, batches t+3..) -> in_a1s (FPS levels 2-4, t+2) -> in_b (neighbourhoods, t+1) -> data (t)
@@ -447,13 +455,16 @@ def main():
         data["_geometry"] = cur
         torch.cuda.synchronize()
 
+    handover = {"direct": False}  # set once the ping-pong variants are captured
+
     def rotate(s=0):  # main stream, between steps: advance every pipeline buffer by one batch
         if not overlap:
             copy_batch(data, pool[s % npool])
             return
         lane = s % lanes
         geometry.copy_into(cur_fps, a_stable)
-        geometry.copy_into(cur_rest, b_out)
+        if not handover["direct"]:
+            geometry.copy_into(cur_rest, b_out)
         copy_batch(data, in_b)
         geometry.copy_into(a_stable, a1_stable + a2_out)
         copy_batch(in_b, in_a1s)
@@ -503,9 +514,9 @@ def main():
             with torch.cuda.stream(s_b):
                 s_b.wait_event(ev_main)
                 if "geo" not in skip:
-                    f_b()
+                    (f_b[(sidx + 1) % 2] if isinstance(f_b, list) else f_b)()
                 ev_b.record(s_b)
-        f_feat()
+        (f_feat[sidx % 2] if isinstance(f_feat, list) else f_feat)()
         if flatg is not None:
             flatg.allreduce()
         f_update()
@@ -531,14 +542,39 @@ def main():
         # with a process group alive, RCCL's watchdog thread polls events while we capture: only this thread's calls
         # may be policed by the capture (the default "global" mode turns that poll into a fatal error)
         cap_mode = os.environ.get("AMC3D_CAPTURE_MODE") or ("thread_local" if world > 1 or sync_bn else "global")
-        if sync_bn:
-            # the SyncBatchNorm statistics all-reduces are NOT captured: the feature half becomes a chain of graphs with
-            # the collectives issued eagerly between them (amcontrast3d_amd/graphs.py)
-            from amcontrast3d_amd.graphs import SegmentedGraph
-            graphs["feat"] = SegmentedGraph(cap_mode).capture(fwd_bwd, stream=cap)
+        outs = []
+
+        def capture_feat(key, pool_of=None):
+            if sync_bn:
+                # the SyncBatchNorm statistics all-reduces are NOT captured: the feature half becomes a chain of graphs with
+                # the collectives issued eagerly between them (amcontrast3d_amd/graphs.py)
+                from amcontrast3d_amd.graphs import SegmentedGraph
+                graphs[key] = SegmentedGraph(cap_mode).capture(fwd_bwd, stream=cap)
+            else:
+                kw = {"pool": graphs[pool_of].pool()} if pool_of else {}  # the variants never run at the same time
+                with torch.cuda.graph(graphs[key], stream=cap, capture_error_mode=cap_mode, **kw):
+                    fwd_bwd()
+            outs.append(out["loss"])
+
+        if pingpong:
+            graphs["b1"], graphs["feat1"] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            rest = []
+            for key in ("b", "b1"):
+                with torch.cuda.graph(graphs[key], stream=s_b, capture_error_mode=cap_mode):
+                    rest.append(geometry.split(geo_rest(in_b, a_stable))[1])  # the graph's own outputs: R[0], R[1]
+            # nothing in a result set may be a view of stream B's INPUTS (those already belong to the next batch when the
+            # feature half reads the set)
+            inputs = set()
+            geometry._walk([a_stable, in_b], lambda t: inputs.add(t.untyped_storage().data_ptr()))
+            for r in rest:
+                geometry._walk(r, lambda t: None if t.untyped_storage().data_ptr() not in inputs else
+                               sys.exit("bench.py: the geometry plan aliases its inputs; run with AMC3D_NO_PINGPONG=1"))
+            handover["direct"] = True
+            for v, key in enumerate(("feat", "feat1")):
+                data["_geometry"] = geometry.join(cur_fps, rest[v])
+                capture_feat(key, "feat" if v else None)
         else:
-            with torch.cuda.graph(graphs["feat"], stream=cap, capture_error_mode=cap_mode):
-                fwd_bwd()
+            capture_feat("feat")
         with torch.cuda.graph(graphs["update"], stream=cap, capture_error_mode=cap_mode):
             update()
         for j in range(period):
@@ -550,13 +586,22 @@ def main():
                     body_a(l)
             with torch.cuda.graph(graphs["a2"], stream=s_a2, capture_error_mode=cap_mode):
                 body_a2()
-            with torch.cuda.graph(graphs["b"], stream=s_b, capture_error_mode=cap_mode):
-                body_b()
+            if not pingpong:
+                with torch.cuda.graph(graphs["b"], stream=s_b, capture_error_mode=cap_mode):
+                    body_b()
         torch.cuda.synchronize()
+        if pingpong:
+            # in_b / a_stable still hold the batch the next rotate makes current: its geometry goes into the result set the
+            # next step's feature variant reads
+            with torch.cuda.stream(s_b):
+                graphs["b1" if (step_no[0] % period) % 2 else "b"].replay()
+            torch.cuda.synchronize()
 
         def step():
             run_step([graphs[f"rotate{j}"].replay for j in range(period)], [graphs[f"fps{l}"].replay for l in range(lanes)],
-                     graphs["a2"].replay, graphs["b"].replay, graphs["feat"].replay, graphs["update"].replay)
+                     graphs["a2"].replay, [graphs["b"].replay, graphs["b1"].replay] if pingpong else graphs["b"].replay,
+                     [graphs["feat"].replay, graphs["feat1"].replay] if pingpong else graphs["feat"].replay,
+                     graphs["update"].replay)
 
     for _ in range(args.warmup):
         step()
@@ -571,6 +616,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dt = adist.max_over_ranks(dt, dev)
+    if use_graph and len(outs) == 2:  # the variant the last step replayed
+        out["loss"] = outs[(step_no[0] - 1) % period % 2]
     final_loss = float(out["loss"].detach())
     assert flatg is None or flatg.intact(), "a parameter gradient left the flat all-reduce buffer"
     # data-parallel sanity: after the timed steps every rank must hold the same weights (the gradient exchange is the
@@ -634,18 +681,27 @@ def main():
         # the same step with nothing overlapped: every part replayed on the stream it was captured on, one after the other
         # (a host wait between parts: ~6 x 20 us of the figure)
         def serial(reps=5):
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            for r in range(reps):
-                for fn, st in ((graphs[f"rotate{r % period}"].replay, main_s), (graphs[f"fps{r % lanes}"].replay, s_a[r % lanes]),
-                               (graphs["a2"].replay, s_a2), (graphs["b"].replay, s_b), (graphs["feat"].replay, main_s)):
+            per = {}
+            for r in range(-1, reps):  # pass -1: untimed (first replays after the per-part measurements above)
+                if r == 0:
+                    torch.cuda.synchronize()
+                    per = {}
+                    t = time.perf_counter()
+                for tag, fn, st in (("rotate", graphs[f"rotate{r % period}"].replay, main_s),
+                                    ("fps1", graphs[f"fps{r % lanes}"].replay, s_a[r % lanes]),
+                                    ("fps2to4", graphs["a2"].replay, s_a2), ("geometry", graphs["b"].replay, s_b),
+                                    ("features", graphs["feat"].replay, main_s)):
+                    h = time.perf_counter()
                     with torch.cuda.stream(st):
                         fn()
                     st.synchronize()
+                    per[tag] = per.get(tag, 0.0) + (time.perf_counter() - h) / reps * 1e3
                 if flatg is not None:
                     flatg.allreduce()
                 graphs["update"].replay()
                 main_s.synchronize()
+            if os.environ.get("AMC3D_SERIAL_PARTS"):
+                print("serial parts (ms): " + json.dumps({k: round(v, 3) for k, v in per.items()}), file=sys.stderr)
             return round((time.perf_counter() - t) / reps * 1e3, 3)
         no_overlap_ms = serial()
 
