@@ -36,24 +36,29 @@ AMC_API const char *amc3d_last_error(void) { return amc::g_err; }
 // workgroups) then stalls whatever stream happens to share its queue -- the training stream, a graph's internal
 // branch, RCCL -- and which one that is changes with every stream anybody creates.  Streams created with a CU mask get
 // a dedicated queue; the mask here enables every CU, so nothing else about the stream is special.
-AMC_API int amc3d_stream_create_dedicated(void **stream)
+// first_cu / n_cus select the enabled bits [first_cu, first_cu + n_cus) of the CU mask (n_cus <= 0: every CU) -- a way to
+// keep a background stream (neighbourhood geometry of the next batch) from spreading over the whole chip.
+AMC_API int amc3d_stream_create_masked(void **stream, int first_cu, int n_cus)
 {
-    if (!stream) return amc::bad_arg("amc3d_stream_create_dedicated: null pointer");
+    if (!stream) return amc::bad_arg("amc3d_stream_create_masked: null pointer");
     int dev = 0, cus = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess || cus <= 0) { amc::set_error("amc3d_stream_create_dedicated: %s", hipGetErrorString(e)); return (int)(e ? e : hipErrorUnknown); }
-    uint32_t mask[32];
+    if (e != hipSuccess || cus <= 0) { amc::set_error("amc3d_stream_create_masked: %s", hipGetErrorString(e)); return (int)(e ? e : hipErrorUnknown); }
+    if (n_cus <= 0) { first_cu = 0; n_cus = cus; }
+    if (first_cu < 0 || first_cu + n_cus > cus) return amc::bad_arg("amc3d_stream_create_masked: CU range outside the device");
+    uint32_t mask[32] = {0};
     const int words = (cus + 31) / 32;
-    if (words > 32) return amc::bad_arg("amc3d_stream_create_dedicated: more than 1024 CUs");
-    for (int i = 0; i < words; ++i) mask[i] = 0xffffffffu;
-    if (cus % 32) mask[words - 1] = (1u << (cus % 32)) - 1u;
+    if (words > 32) return amc::bad_arg("amc3d_stream_create_masked: more than 1024 CUs");
+    for (int c = first_cu; c < first_cu + n_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
     hipStream_t s = nullptr;
     e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
     if (e != hipSuccess) { amc::set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e)); return (int)e; }
     *stream = (void *)s;
     return 0;
 }
+
+AMC_API int amc3d_stream_create_dedicated(void **stream) { return amc3d_stream_create_masked(stream, 0, 0); }
 
 AMC_API int amc3d_stream_destroy(void *stream)
 {

@@ -38,13 +38,15 @@ def _destroy_dedicated():
         _dedicated.clear()
 
 
-def dedicated_stream(device=None):
+def dedicated_stream(device=None, first_cu=0, n_cus=0):
     """A torch stream with a hardware queue of its own (amc3d_stream_create_dedicated): for the FPS launches of a
-    pipelined loop, which otherwise stall whichever stream shares their queue for milliseconds."""
+    pipelined loop, which otherwise stall whichever stream shares their queue for milliseconds.  n_cus > 0 restricts
+    the stream's kernels to the CUs [first_cu, first_cu + n_cus) of the mask."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     handle = ctypes.c_void_p()
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().amc3d_stream_create_dedicated(ctypes.byref(handle)), "stream_create_dedicated")
+        _lib.check(_lib.load().amc3d_stream_create_masked(ctypes.byref(handle), int(first_cu), int(n_cus)),
+                   "stream_create_masked")
     s = torch.cuda.ExternalStream(handle.value, device=dev)
     if not _dedicated:
         import atexit

@@ -403,7 +403,14 @@ def main():
         s_a = [torch.cuda.Stream(priority=prio[1]) for _ in range(lanes)]
         s_a2, s_b = torch.cuda.Stream(priority=prio[2]), torch.cuda.Stream(priority=prio[3])
     else:
-        q = {k: _ops.dedicated_stream(dev) for k in qplan.split(",")}
+        # CU masks of the side queues, "queue:first:count,...".  Default: the neighbourhood-geometry queue runs on 3/4 of the
+        # CUs.  Its kernels are background work with slack (they finish ~1 ms before the feature half does), and when they
+        # may spread over the whole chip they slow the feature half more than they gain: measured 8.98 -> 8.75 ms/step
+        # (S, B=8 x 24000; 1/2 of the CUs: 9.16, 7/8: 8.92).  AMC3D_CU_MASK="" turns the masks off.
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        cum = {k: (int(a), int(b)) for k, a, b in
+               (v.split(":") for v in os.environ.get("AMC3D_CU_MASK", f"geo:0:{3 * ncu // 4}").split(",") if v)}
+        q = {k: _ops.dedicated_stream(dev, *cum.get(k, (0, 0))) for k in qplan.split(",")}
         s_a = [q.get(f"fps{l}", q.get("fps")) or torch.cuda.Stream() for l in range(lanes)]
         s_a2 = q.get("a2", q.get("geo")) or torch.cuda.Stream()
         s_b = q.get("b", q.get("geo")) or torch.cuda.Stream()
@@ -646,8 +653,12 @@ def main():
             h0 = time.perf_counter()
             run_step([timed(graphs[f"rotate{j}"].replay, main_s, "rotate", log) for j in range(period)],
                      [timed(graphs[f"fps{l}"].replay, s_a[l], f"fps{l}", log) for l in range(lanes)],
-                     timed(graphs["a2"].replay, s_a2, "a2", log), timed(graphs["b"].replay, s_b, "b", log),
-                     timed(graphs["feat"].replay, main_s, "feat", log), timed(graphs["update"].replay, main_s, "update", log))
+                     timed(graphs["a2"].replay, s_a2, "a2", log),
+                     # ping-pong: the variants in the order run_step picks them (a feature variant must never run beside
+                     # the B variant that writes the result set it reads)
+                     [timed(graphs[k].replay, s_b, "b", log) for k in (("b", "b1") if pingpong else ("b", "b"))],
+                     [timed(graphs[k].replay, main_s, "feat", log) for k in (("feat", "feat1") if pingpong else ("feat", "feat"))],
+                     timed(graphs["update"].replay, main_s, "update", log))
             h1 = time.perf_counter()
             if it >= 3:
                 torch.cuda.synchronize()

@@ -45,6 +45,8 @@ const char *amc3d_last_error(void);
  * shares the queue of a running FPS kernel waits milliseconds for it.  (The reference launches everything on the
  * legacy default stream; this is the hook its trainer would use to overlap batches.) */
 int amc3d_stream_create_dedicated(void **stream);
+/* the same with a CU mask that enables bits [first_cu, first_cu + n_cus) only (n_cus <= 0: every CU) */
+int amc3d_stream_create_masked(void **stream, int first_cu, int n_cus);
 int amc3d_stream_destroy(void *stream);
 
 /* ---- pointnet2_batch surface ------------------------------------------------ */
