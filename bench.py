@@ -382,7 +382,10 @@ def main():
         del plan0
         if flatg is None:
             opt.zero_grad(set_to_none=True)
-        lanes = 2 if t_fps <= 1.2 * t_feat else int(min(6, max(2, -(-t_fps // max(0.6 * t_feat, 1e-3)))))
+        # two lanes on ONE queue deliver a sampling every t_fps: enough while t_fps stays below the step time (~1.25 x the
+        # eager feature half).  The margin is wide on purpose: a third lane means a fourth dedicated queue, and with more
+        # hardware queues than the 4 the runtime schedules natively the S step takes 17 ms instead of 8.7 (measured).
+        lanes = 2 if t_fps <= 1.5 * t_feat else int(min(6, max(2, -(-t_fps // max(0.6 * t_feat, 1e-3)))))
     lanes = max(1, lanes)
     # Hardware queues.  Ordinary HIP streams of a process share GPU_MAX_HW_QUEUES (default 4) queues round-robin, and
     # whatever shares a queue with a running FPS kernel (8 ms on 8 workgroups) waits for it; which stream that is
@@ -464,15 +467,17 @@ def main():
 
     handover = {"direct": False}  # set once the ping-pong variants are captured
 
-    def rotate(s=0):  # main stream, between steps: advance every pipeline buffer by one batch
+    def rotate(s=0):  # main stream, between steps: what the feature half of the new step reads
         if not overlap:
             copy_batch(data, pool[s % npool])
             return
-        lane = s % lanes
         geometry.copy_into(cur_fps, a_stable)
         if not handover["direct"]:
             geometry.copy_into(cur_rest, b_out)
         copy_batch(data, in_b)
+
+    def rotate_side(s=0):  # geometry queue, after rotate(): advance the side streams' buffers by one batch
+        lane = s % lanes
         geometry.copy_into(a_stable, a1_stable + a2_out)
         copy_batch(in_b, in_a1s)
         geometry.copy_into(a1_stable, a1_out[lane])
@@ -494,32 +499,39 @@ def main():
 
     step_no = [0]
 
-    def run_step(f_rotate, f_a, f_a2, f_b, f_feat, f_update):
+    ev_rot = torch.cuda.Event()
+
+    def run_step(f_rotate, f_side, f_a, f_a2, f_b, f_feat, f_update):
         sidx = step_no[0] % period
         step_no[0] += 1
         if not overlap:
             f_rotate[sidx]()
         if overlap:
             lane = sidx % lanes  # the FPS lane launched `lanes` steps ago delivers now and is relaunched
-            # events, not stream waits: several parts may share a queue (the other lane's FPS is still running)
-            main_s.wait_event(ev_lane[lane])
-            main_s.wait_event(ev_a2)
+            # The main stream only moves what the feature half reads (the batch and its FPS picks); everything else of the
+            # hand-down -- five groups of small copies between the side streams' buffers -- runs on the geometry queue, off
+            # the critical path.  ev_b also orders this step's rotate() after the previous step's rotate_side() (same queue).
             main_s.wait_event(ev_b)
             f_rotate[sidx]()
             ev_main.record(main_s)
             skip = os.environ.get("AMC3D_SKIP", "")  # diagnostic: leave pipeline parts out (results go stale, timing only)
+            with torch.cuda.stream(s_b):
+                s_b.wait_event(ev_main)        # rotate() has read in_b / a_stable
+                s_b.wait_event(ev_lane[lane])  # events, not stream waits: several parts may share a queue
+                s_b.wait_event(ev_a2)
+                f_side[sidx]()
+                ev_rot.record(s_b)
             with torch.cuda.stream(s_a[lane]):
-                s_a[lane].wait_event(ev_main)
+                s_a[lane].wait_event(ev_rot)
                 if "fps" not in skip:
                     f_a[lane]()
                 ev_lane[lane].record(s_a[lane])
             with torch.cuda.stream(s_a2):
-                s_a2.wait_event(ev_main)
+                s_a2.wait_event(ev_rot)
                 if "a2" not in skip:
                     f_a2()
                 ev_a2.record(s_a2)
             with torch.cuda.stream(s_b):
-                s_b.wait_event(ev_main)
                 if "geo" not in skip:
                     (f_b[(sidx + 1) % 2] if isinstance(f_b, list) else f_b)()
                 ev_b.record(s_b)
@@ -531,7 +543,8 @@ def main():
     def eager_step():
         if flatg is None:
             opt.zero_grad(set_to_none=True)
-        run_step([lambda j=j: rotate(j) for j in range(period)], [lambda l=l: body_a(l) for l in range(lanes)], body_a2,
+        run_step([lambda j=j: rotate(j) for j in range(period)], [lambda j=j: rotate_side(j) for j in range(period)],
+                 [lambda l=l: body_a(l) for l in range(lanes)], body_a2,
                  body_b, fwd_bwd, update)
 
     step = eager_step
@@ -543,7 +556,8 @@ def main():
         torch.cuda.synchronize()
         if flatg is None:
             opt.zero_grad(set_to_none=True)
-        names = ["a2", "b", "feat", "update"] + [f"rotate{j}" for j in range(period)] + [f"fps{l}" for l in range(lanes)]
+        names = (["a2", "b", "feat", "update"] + [f"rotate{j}" for j in range(period)] + [f"side{j}" for j in range(period)]
+                 + [f"fps{l}" for l in range(lanes)])
         graphs = {k: torch.cuda.CUDAGraph() for k in names}
         cap = main_s if not os.environ.get("AMC3D_CAPTURE_SIDE") else torch.cuda.Stream()
         # with a process group alive, RCCL's watchdog thread polls events while we capture: only this thread's calls
@@ -587,6 +601,9 @@ def main():
         for j in range(period):
             with torch.cuda.graph(graphs[f"rotate{j}"], stream=cap, capture_error_mode=cap_mode):
                 rotate(j)
+            if overlap:
+                with torch.cuda.graph(graphs[f"side{j}"], stream=s_b, capture_error_mode=cap_mode):
+                    rotate_side(j)
         if overlap:
             for l in range(lanes):
                 with torch.cuda.graph(graphs[f"fps{l}"], stream=s_a[l], capture_error_mode=cap_mode):
@@ -605,7 +622,8 @@ def main():
             torch.cuda.synchronize()
 
         def step():
-            run_step([graphs[f"rotate{j}"].replay for j in range(period)], [graphs[f"fps{l}"].replay for l in range(lanes)],
+            run_step([graphs[f"rotate{j}"].replay for j in range(period)], [graphs[f"side{j}"].replay for j in range(period)],
+                     [graphs[f"fps{l}"].replay for l in range(lanes)],
                      graphs["a2"].replay, [graphs["b"].replay, graphs["b1"].replay] if pingpong else graphs["b"].replay,
                      [graphs["feat"].replay, graphs["feat1"].replay] if pingpong else graphs["feat"].replay,
                      graphs["update"].replay)
@@ -652,6 +670,7 @@ def main():
             ref.record(main_s)
             h0 = time.perf_counter()
             run_step([timed(graphs[f"rotate{j}"].replay, main_s, "rotate", log) for j in range(period)],
+                     [timed(graphs[f"side{j}"].replay, s_b, "side", log) for j in range(period)],
                      [timed(graphs[f"fps{l}"].replay, s_a[l], f"fps{l}", log) for l in range(lanes)],
                      timed(graphs["a2"].replay, s_a2, "a2", log),
                      # ping-pong: the variants in the order run_step picks them (a feature variant must never run beside
@@ -687,7 +706,8 @@ def main():
         parts = {"features_ms": alone(graphs["feat"].replay, main_s), "update_ms": alone(graphs["update"].replay, main_s),
                  "fps_level1_ms": alone(graphs["fps0"].replay, s_a[0]), "fps_levels2to4_ms": alone(graphs["a2"].replay, s_a2),
                  "neighbourhood_geometry_ms": alone(graphs["b"].replay, s_b),
-                 "rotate_ms": alone(graphs["rotate0"].replay, main_s)}
+                 "rotate_ms": alone(graphs["rotate0"].replay, main_s),
+                 "rotate_side_ms": alone(graphs["side0"].replay, s_b)}
 
         # the same step with nothing overlapped: every part replayed on the stream it was captured on, one after the other
         # (a host wait between parts: ~6 x 20 us of the figure)
@@ -699,6 +719,7 @@ def main():
                     per = {}
                     t = time.perf_counter()
                 for tag, fn, st in (("rotate", graphs[f"rotate{r % period}"].replay, main_s),
+                                    ("rotate_side", graphs[f"side{r % period}"].replay, s_b),
                                     ("fps1", graphs[f"fps{r % lanes}"].replay, s_a[r % lanes]),
                                     ("fps2to4", graphs["a2"].replay, s_a2), ("geometry", graphs["b"].replay, s_b),
                                     ("features", graphs["feat"].replay, main_s)):
