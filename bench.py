@@ -447,6 +447,13 @@ def main():
     pingpong = overlap and use_graph and not os.environ.get("AMC3D_NO_PINGPONG")
     if pingpong and period % 2:
         period *= 2
+    # First-level FPS of TWO future batches as one launch every second step (16 workgroups instead of 8: the kernel is a
+    # latency chain, more clouds cost nothing) instead of one launch per step: the sampling queue then delivers a batch
+    # every t_fps / 2.  With one launch per step on one queue the step cannot be shorter than t_fps (8.1-8.3 ms alone),
+    # which the feature half has reached; a queue per lane costs a fourth hardware queue (slower, measured above).
+    joint = overlap and lanes == 2 and not os.environ.get("AMC3D_NO_FPS_JOINT")
+    if joint:
+        period = period * 4 // math.gcd(period, 4)
     if overlap:
         # every in-flight batch has its own static input buffers, handed down the pipeline by rotate():
         #   in_a[lane] (first FPS level, batches t+3..) -> in_a1s (FPS levels 2-4, t+2) -> in_b (neighbourhoods, t+1) -> data (t)
@@ -454,6 +461,16 @@ def main():
         in_a1s = {k: v.clone() for k, v in pool[2 % npool].items()}
         in_a = [{k: v.clone() for k, v in pool[(3 + l) % npool].items()} for l in range(lanes)]
         a1_out = [geo_fps_first(in_a[l]) for l in range(lanes)]  # written by streams A1[lane]: first FPS level
+        if joint:
+            # two double-batch buffers J[0], J[1], launched alternately at even steps; lane l of a launch is consumed 2 + l
+            # steps later, through per-lane views of the joint input / output tensors
+            nbat = args.batch
+            in_aJ = [{k: torch.cat([pool[(3 + 2 * j) % npool][k], pool[(4 + 2 * j) % npool][k]]) for k in pool[0]}
+                     for j in range(2)]
+            a1_outJ = [geo_fps_first(in_aJ[j]) for j in range(2)]
+            in_a = [[{k: v[l * nbat:(l + 1) * nbat] for k, v in in_aJ[j].items()} for l in range(2)] for j in range(2)]
+            a1_out = [[geometry._walk(a1_outJ[j], lambda t, l=l: t[l * nbat:(l + 1) * nbat]) for l in range(2)]
+                      for j in range(2)]
         a1_stable = geometry.clone(geo_fps_first(in_a1s))  # batch t+2: read by stream A2
         a2_out = geo_fps_tail(a1_stable)       # written by stream A2 (batch t+2): FPS levels 2..4
         fb = geo_fps_first(in_b)
@@ -480,12 +497,23 @@ def main():
         lane = s % lanes
         geometry.copy_into(a_stable, a1_stable + a2_out)
         copy_batch(in_b, in_a1s)
+        if joint:
+            jc, jl = 1 - (s // 2) % 2, (s // 2) % 2  # the joint launch consumed now / the one (re)launched at even steps
+            geometry.copy_into(a1_stable, a1_out[jc][lane])
+            copy_batch(in_a1s, in_a[jc][lane])
+            if lane == 0:
+                for t in range(2):
+                    copy_batch(in_a[jl][t], pool[(s + 5 + t) % npool])
+            return
         geometry.copy_into(a1_stable, a1_out[lane])
         copy_batch(in_a1s, in_a[lane])
         copy_batch(in_a[lane], pool[(s + lanes + 3) % npool])
 
-    def body_a(lane=0):
-        geometry.copy_into(a1_out[lane], geo_fps_first(in_a[lane]))
+    def body_a(lane=0):  # joint mode: `lane` is the index of the double-batch buffer
+        if joint:
+            geometry.copy_into(a1_outJ[lane], geo_fps_first(in_aJ[lane]))
+        else:
+            geometry.copy_into(a1_out[lane], geo_fps_first(in_a[lane]))
 
     def body_a2():
         geometry.copy_into(a2_out, geo_fps_tail(a1_stable))
@@ -515,17 +543,20 @@ def main():
             f_rotate[sidx]()
             ev_main.record(main_s)
             skip = os.environ.get("AMC3D_SKIP", "")  # diagnostic: leave pipeline parts out (results go stale, timing only)
+            # joint FPS: the double-batch launch whose lane is consumed now / the one relaunched (even steps only)
+            took, go = (1 - (sidx // 2) % 2, (sidx // 2) % 2 if lane == 0 else None) if joint else (lane, lane)
             with torch.cuda.stream(s_b):
                 s_b.wait_event(ev_main)        # rotate() has read in_b / a_stable
-                s_b.wait_event(ev_lane[lane])  # events, not stream waits: several parts may share a queue
+                s_b.wait_event(ev_lane[took])  # events, not stream waits: several parts may share a queue
                 s_b.wait_event(ev_a2)
                 f_side[sidx]()
                 ev_rot.record(s_b)
-            with torch.cuda.stream(s_a[lane]):
-                s_a[lane].wait_event(ev_rot)
-                if "fps" not in skip:
-                    f_a[lane]()
-                ev_lane[lane].record(s_a[lane])
+            if go is not None:
+                with torch.cuda.stream(s_a[go]):
+                    s_a[go].wait_event(ev_rot)
+                    if "fps" not in skip:
+                        f_a[go]()
+                    ev_lane[go].record(s_a[go])
             with torch.cuda.stream(s_a2):
                 s_a2.wait_event(ev_rot)
                 if "a2" not in skip:
@@ -720,7 +751,8 @@ def main():
                     t = time.perf_counter()
                 for tag, fn, st in (("rotate", graphs[f"rotate{r % period}"].replay, main_s),
                                     ("rotate_side", graphs[f"side{r % period}"].replay, s_b),
-                                    ("fps1", graphs[f"fps{r % lanes}"].replay, s_a[r % lanes]),
+                                    ("fps1", graphs[f"fps{(r // 2 if joint else r) % lanes}"].replay if not (joint and r % 2)
+                                     else (lambda: None), s_a[r % lanes]),
                                     ("fps2to4", graphs["a2"].replay, s_a2), ("geometry", graphs["b"].replay, s_b),
                                     ("features", graphs["feat"].replay, main_s)):
                     h = time.perf_counter()
