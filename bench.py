@@ -409,14 +409,24 @@ def main():
         # CU masks of the side queues, "queue:first:count,...".  Default: the neighbourhood-geometry queue runs on 3/4 of the
         # CUs.  Its kernels are background work with slack (they finish ~1 ms before the feature half does), and when they
         # may spread over the whole chip they slow the feature half more than they gain: measured 8.98 -> 8.75 ms/step
-        # (S, B=8 x 24000; 1/2 of the CUs: 9.16, 7/8: 8.92).  AMC3D_CU_MASK="" turns the masks off.
+        # (S, B=8 x 24000; 1/2 of the CUs: 9.16, 7/8: 8.92).  With FPS levels 2-4 moved to the sampling queue (below) the
+        # searches have the whole step and 9/16 of the CUs is the best split (7/16: 8.65, 8/16 and 9/16: 8.35, 12/16: 8.47).
+        # AMC3D_CU_MASK="" turns the masks off.
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        geo_cus = 9 * ncu // 16 if (lanes == 2 and os.environ.get("AMC3D_A2_ON_FPS", "1") != "0") else 3 * ncu // 4
         cum = {k: (int(a), int(b)) for k, a, b in
-               (v.split(":") for v in os.environ.get("AMC3D_CU_MASK", f"geo:0:{3 * ncu // 4}").split(",") if v)}
+               (v.split(":") for v in os.environ.get("AMC3D_CU_MASK", f"geo:0:{geo_cus}").split(",") if v)}
         q = {k: _ops.dedicated_stream(dev, *cum.get(k, (0, 0))) for k in qplan.split(",")}
         s_a = [q.get(f"fps{l}", q.get("fps")) or torch.cuda.Stream() for l in range(lanes)]
         s_a2 = q.get("a2", q.get("geo")) or torch.cuda.Stream()
         s_b = q.get("b", q.get("geo")) or torch.cuda.Stream()
+    # FPS levels 2-4 (a 2.3 ms latency chain on a few workgroups) share the first level's queue and are launched ahead of
+    # it: the queue is busy 2 x 2.3 + 8.3 ms in every two steps, and the geometry queue is left to the neighbourhood
+    # searches, which then start 2.3 ms earlier in the step and can be held to fewer CUs (see AMC3D_CU_MASK below):
+    # 8.53 -> 8.35 ms/step.  AMC3D_A2_ON_FPS=0: levels 2-4 on the geometry queue, as before.
+    a2_first = False
+    if os.environ.get("AMC3D_A2_ON_FPS", "1") != "0" and lanes == 2 and s_a[0] is s_a[1] and s_a2 is s_b:
+        s_a2, a2_first = s_a[0], True
     ev_lane = [torch.cuda.Event() for _ in range(lanes)]
     ev_a2, ev_b, ev_main = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
     head = criterion.contrast_head
@@ -551,17 +561,22 @@ def main():
                 s_b.wait_event(ev_a2)
                 f_side[sidx]()
                 ev_rot.record(s_b)
-            if go is not None:
-                with torch.cuda.stream(s_a[go]):
-                    s_a[go].wait_event(ev_rot)
-                    if "fps" not in skip:
-                        f_a[go]()
-                    ev_lane[go].record(s_a[go])
+            def launch_fps():
+                if go is not None:
+                    with torch.cuda.stream(s_a[go]):
+                        s_a[go].wait_event(ev_rot)
+                        if "fps" not in skip:
+                            f_a[go]()
+                        ev_lane[go].record(s_a[go])
+            if not a2_first:
+                launch_fps()
             with torch.cuda.stream(s_a2):
                 s_a2.wait_event(ev_rot)
                 if "a2" not in skip:
                     f_a2()
                 ev_a2.record(s_a2)
+            if a2_first:
+                launch_fps()
             with torch.cuda.stream(s_b):
                 if "geo" not in skip:
                     (f_b[(sidx + 1) % 2] if isinstance(f_b, list) else f_b)()
