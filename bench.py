@@ -864,7 +864,8 @@ def main():
                              "level1_ms": lvl1, "us_per_iteration": round(lvl1 * 1e3 / its, 3) if lvl1 else None,
                              "all_levels_ms_per_step": round(fv["total_ms"] / args.steps, 3),
                              "cus_busy": args.batch, "hbm_bytes_per_launch": traffic.get("furthest_point_sampling", {}).get("bytes_per_launch"),
-                             "note": "serial arg-max chain, hidden by running 2 batches ahead on its own hardware queue"}
+                             "note": "serial arg-max chain, off the critical path: the first level of two future batches runs as one launch every "
+                                     "second step on the sampling queue, levels 2-4 every step ahead of it"}
         # the whole step against both roofs (SURVEY 8(d) algorithmic work)
         roofline_step = None
         if args.variant in ALGORITHMIC_PER_POINT and not args.mm:
