@@ -612,15 +612,32 @@ def main():
         outs = []
 
         def capture_feat(key, pool_of=None):
+            # A second variant must deliver its gradients in the FIRST variant's .grad tensors (the update graph reads
+            # those): captured with .grad still set, autograd would ACCUMULATE into them -- last step's gradient plus
+            # this one's.  So it runs with .grad = None and ends with one multi-tensor copy into the first variant's buffers.
+            keep = [p.grad for p in params] if pool_of else None
+
+            def body():
+                if keep is not None and flatg is None:
+                    for p in params:
+                        p.grad = None
+                fwd_bwd()
+                if keep is not None and flatg is None:
+                    pairs = [(g0, p.grad) for g0, p in zip(keep, params) if g0 is not None and p.grad is not None]
+                    torch._foreach_copy_([a for a, _ in pairs], [b for _, b in pairs])
             if sync_bn:
                 # the SyncBatchNorm statistics all-reduces are NOT captured: the feature half becomes a chain of graphs with
                 # the collectives issued eagerly between them (amcontrast3d_amd/graphs.py)
                 from amcontrast3d_amd.graphs import SegmentedGraph
-                graphs[key] = SegmentedGraph(cap_mode).capture(fwd_bwd, stream=cap)
+                graphs[key] = SegmentedGraph(cap_mode).capture(body, stream=cap)
             else:
                 kw = {"pool": graphs[pool_of].pool()} if pool_of else {}  # the variants never run at the same time
                 with torch.cuda.graph(graphs[key], stream=cap, capture_error_mode=cap_mode, **kw):
-                    fwd_bwd()
+                    body()
+            if keep is not None and flatg is None:
+                assert all((g0 is None) == (p.grad is None) for g0, p in zip(keep, params)), "variants disagree on which parameters get gradients"
+                for p, g0 in zip(params, keep):
+                    p.grad = g0
             outs.append(out["loss"])
 
         if pingpong:
@@ -674,6 +691,15 @@ def main():
                      [graphs["feat"].replay, graphs["feat1"].replay] if pingpong else graphs["feat"].replay,
                      graphs["update"].replay)
 
+    if os.environ.get("AMC3D_CHECK_VARIANTS") and rank == 0:
+        # diagnostic: total gradient norm after each of 8 steps (a variant that accumulated onto the other's gradients
+        # would show as alternating norms)
+        norms = []
+        for _ in range(8):
+            step()
+            torch.cuda.synchronize()
+            norms.append(round(float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params if p.grad is not None))), 4))
+        print("gradient norms per step:", norms, file=sys.stderr)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
