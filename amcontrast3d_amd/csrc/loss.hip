@@ -15,6 +15,10 @@
 //    torch 2.x's F.cosine_similarity evaluates (MarginContrast.py:77-79).
 #include "common.h"
 
+#ifndef AMC_CONTRAST_DIAG
+#define AMC_CONTRAST_DIAG 0  // 1 / 2: timing-only builds of contrast_backward_kernel (scratch/contrast_diag.sh), never shipped
+#endif
+
 namespace amc {
 
 // ---------------------------------------------------------------------------------------------
@@ -131,7 +135,8 @@ __global__ __launch_bounds__(256) void row_norm_kernel(int m, int C, const float
 // The anchors that enter the loss, 0 < a <= 1 (MarginContrast.py:250-252), as a compact ascending list:
 // sel[0] = count, sel[1..count] = anchor ids, sel[m+1..] = per-256-block counts (scratch).  The list depends on
 // coordinates and labels only, so it is built with the stage's plan; the contrast kernels then run one full
-// wave per SELECTED anchor instead of testing a_i per anchor (about a quarter are selected on S3DIS-like rooms).
+// wave per SELECTED anchor instead of testing a_i per anchor (two thirds of the full-resolution points on the synthetic
+// rooms, nearly all at the coarse stages).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void select_count_kernel(int m, const float *__restrict__ a, int *__restrict__ sel)
 {
@@ -352,6 +357,11 @@ __global__ __launch_bounds__(1024) void masked_mean_kernel(int m, const float *_
 // of one row (the shape global float atomics run at full rate for).
 //   l = -log(r + eps), r = P/S, e_j = exp(s'_j / T):  dl/ds_j = -(e_j (pos_j S - P)) / ((r+eps) S^2 T)
 //   ds_j/df_i = (fhat_j - s_j fhat_i)/|f_i|,  ds_j/df_j = (fhat_i - s_j fhat_j)/|f_j|
+// Where the time goes (scratch/contrast_diag.sh + contrast_bench.py, S3DIS-like batch, 66-99 % of the anchors listed): the
+// kernel adds 387 / 229 / 134 / 73 MB of rows at the four stages in 0.33 / 0.20 / 0.12 / 0.06 ms = 1.15-1.17 TB/s, the
+// chip-wide float-atomic rate (MI355X_MICROARCH.md: 1.26-1.36 TB/s); without the neighbour-row atomics it takes a third
+// of that, without the gathers the same.  Splitting an anchor's neighbours over several lane groups (tried for the deep
+// stages) only adds prologues: +15-25 %.
 // Memory-level parallelism: lane j of the group first loads everything neighbour j needs that is not a row
 // (its index, norm, similarity, mask -- one round trip for all k), the walk then broadcasts those by shuffle and
 // keeps U neighbour rows in flight ahead of the atomics.  sel as in the forward.
@@ -430,7 +440,11 @@ __global__ __launch_bounds__(256) void contrast_backward_kernel(
 #pragma unroll
                 for (int v = 0; v < VPT; ++v) {
                     const int c = sub + v * LPA;
+#if AMC_CONTRAST_DIAG == 2  // diagnostic build 2: no neighbour-row gathers (timing only)
+                    fj[u][v] = (float)nb[u];
+#else
                     fj[u][v] = (nb[u] >= 0 && c < C) ? f[(size_t)nb[u] * C + c] : 0.f;
+#endif
                 }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -444,7 +458,9 @@ __global__ __launch_bounds__(256) void contrast_backward_kernel(
                     if (c < C) {
                         const float fhj = __fdiv_rn(fj[u][v], nj);
                         gi[v] += gin * (fhj - sj * fhi[v]);
+#if AMC_CONTRAST_DIAG != 1  // diagnostic build 1: no neighbour-row atomics (timing only)
                         atomicAdd(grad_f + (size_t)nb[u] * C + c, gjn * (fhi[v] - sj * fhj));
+#endif
                     }
                 }
             }

@@ -91,7 +91,10 @@ def test_select_anchors(m, frac):
 
 @pytest.mark.parametrize("listed", [True, False, "rev"])
 @pytest.mark.parametrize("m,C,seed", [(3000, 32, 0), (1500, 64, 1), (800, 128, 2), (300, 256, 3), (200, 20, 4),
-                                      (400, 16, 5), (100, 512, 6)])
+                                      (400, 16, 5), (100, 512, 6),
+                                      # >= 16384 anchors: one wave per anchor forward, one lane group per anchor backward
+                                      # (below: the whole workgroup / several groups share an anchor)
+                                      (40000, 32, 7), (17000, 64, 8)])
 def test_contrast_stage_forward_backward(m, C, seed, listed):
     _contrast_case(m, C, seed, listed, 24)
 
