@@ -387,6 +387,12 @@ def main():
         # hardware queues than the 4 the runtime schedules natively the S step takes 17 ms instead of 8.7 (measured).
         lanes = 2 if t_fps <= 1.5 * t_feat else int(min(6, max(2, -(-t_fps // max(0.6 * t_feat, 1e-3)))))
     lanes = max(1, lanes)
+    # First-level FPS of TWO future batches as one launch every second step (16 workgroups instead of 8: the kernel is a
+    # latency chain, more clouds cost nothing) instead of one launch per step: the sampling queue then delivers a batch
+    # every t_fps / 2.  With one launch per step on one queue the step cannot be shorter than t_fps (8.1-8.3 ms alone),
+    # which the feature half has reached; a queue per lane costs a fourth hardware queue (slower, measured below).
+    joint = overlap and lanes == 2 and not os.environ.get("AMC3D_NO_FPS_JOINT")
+    a2_rides = joint and os.environ.get("AMC3D_A2_ON_FPS", "1") != "0"  # FPS levels 2-4 on the sampling queue (see below)
     # Hardware queues.  Ordinary HIP streams of a process share GPU_MAX_HW_QUEUES (default 4) queues round-robin, and
     # whatever shares a queue with a running FPS kernel (8 ms on 8 workgroups) waits for it; which stream that is
     # changes with every stream anybody creates (graph-internal branches, RCCL).  So the two long-latency chains get
@@ -413,7 +419,8 @@ def main():
         # searches have the whole step and 9/16 of the CUs is the best split (7/16: 8.65, 8/16 and 9/16: 8.35, 12/16: 8.47).
         # AMC3D_CU_MASK="" turns the masks off.
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
-        geo_cus = 9 * ncu // 16 if (lanes == 2 and os.environ.get("AMC3D_A2_ON_FPS", "1") != "0") else 3 * ncu // 4
+        # (measured for the two-lane configuration only: with more lanes -- 64k / 120k-point clouds -- no mask by default)
+        geo_cus = (9 * ncu // 16 if a2_rides else 3 * ncu // 4) if lanes == 2 else 0
         cum = {k: (int(a), int(b)) for k, a, b in
                (v.split(":") for v in os.environ.get("AMC3D_CU_MASK", f"geo:0:{geo_cus}").split(",") if v)}
         q = {k: _ops.dedicated_stream(dev, *cum.get(k, (0, 0))) for k in qplan.split(",")}
@@ -425,7 +432,7 @@ def main():
     # searches, which then start 2.3 ms earlier in the step and can be held to fewer CUs (see AMC3D_CU_MASK below):
     # 8.53 -> 8.35 ms/step.  AMC3D_A2_ON_FPS=0: levels 2-4 on the geometry queue, as before.
     a2_first = False
-    if os.environ.get("AMC3D_A2_ON_FPS", "1") != "0" and lanes == 2 and s_a[0] is s_a[1] and s_a2 is s_b:
+    if a2_rides and s_a[0] is s_a[1] and s_a2 is s_b:
         s_a2, a2_first = s_a[0], True
     ev_lane = [torch.cuda.Event() for _ in range(lanes)]
     ev_a2, ev_b, ev_main = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
@@ -448,22 +455,16 @@ def main():
 
     # the pipeline's period: lane and pool index of step s are s % lanes and (s + lanes + 3) % npool
     import math
-    period = lanes * npool // math.gcd(lanes, npool) if overlap else npool
+    from amcontrast3d_amd import schedule
+    period = npool  # (set below for the overlapped pipeline)
     # Hand-over of the neighbourhood / loss geometry (~100 MB per batch) from stream B to the feature half: with graphs the
     # two never meet in a copy.  Stream B has two captured variants that write their results into two result sets R[0], R[1]
     # (the graphs' own output tensors), the feature half two variants that read them: step n reads R[n % 2] while B fills
     # R[(n + 1) % 2] for the next batch.  (Eager mode, and AMC3D_NO_PINGPONG=1, copy b_out -> cur_rest on the main stream
     # instead: 0.26 ms of multi-tensor copies per step, and as much again on stream B.)
     pingpong = overlap and use_graph and not os.environ.get("AMC3D_NO_PINGPONG")
-    if pingpong and period % 2:
-        period *= 2
-    # First-level FPS of TWO future batches as one launch every second step (16 workgroups instead of 8: the kernel is a
-    # latency chain, more clouds cost nothing) instead of one launch per step: the sampling queue then delivers a batch
-    # every t_fps / 2.  With one launch per step on one queue the step cannot be shorter than t_fps (8.1-8.3 ms alone),
-    # which the feature half has reached; a queue per lane costs a fourth hardware queue (slower, measured above).
-    joint = overlap and lanes == 2 and not os.environ.get("AMC3D_NO_FPS_JOINT")
-    if joint:
-        period = period * 4 // math.gcd(period, 4)
+    if overlap:
+        period = schedule.period(lanes, npool, pingpong, joint)
     if overlap:
         # every in-flight batch has its own static input buffers, handed down the pipeline by rotate():
         #   in_a[lane] (first FPS level, batches t+3..) -> in_a1s (FPS levels 2-4, t+2) -> in_b (neighbourhoods, t+1) -> data (t)
@@ -503,21 +504,19 @@ def main():
             geometry.copy_into(cur_rest, b_out)
         copy_batch(data, in_b)
 
+    def first_level(buf, what):  # what: in_a / a1_out; buf: (lane,) or (joint buffer, lane) from schedule.side_step
+        for i in buf:
+            what = what[i]
+        return what
+
     def rotate_side(s=0):  # geometry queue, after rotate(): advance the side streams' buffers by one batch
-        lane = s % lanes
+        plan = schedule.side_step(s, lanes, joint, npool)
         geometry.copy_into(a_stable, a1_stable + a2_out)
         copy_batch(in_b, in_a1s)
-        if joint:
-            jc, jl = 1 - (s // 2) % 2, (s // 2) % 2  # the joint launch consumed now / the one (re)launched at even steps
-            geometry.copy_into(a1_stable, a1_out[jc][lane])
-            copy_batch(in_a1s, in_a[jc][lane])
-            if lane == 0:
-                for t in range(2):
-                    copy_batch(in_a[jl][t], pool[(s + 5 + t) % npool])
-            return
-        geometry.copy_into(a1_stable, a1_out[lane])
-        copy_batch(in_a1s, in_a[lane])
-        copy_batch(in_a[lane], pool[(s + lanes + 3) % npool])
+        geometry.copy_into(a1_stable, first_level(plan["consume"], a1_out))
+        copy_batch(in_a1s, first_level(plan["consume"], in_a))
+        for buf, pi in plan["load"]:
+            copy_batch(first_level(buf, in_a), pool[pi])
 
     def body_a(lane=0):  # joint mode: `lane` is the index of the double-batch buffer
         if joint:
@@ -553,8 +552,9 @@ def main():
             f_rotate[sidx]()
             ev_main.record(main_s)
             skip = os.environ.get("AMC3D_SKIP", "")  # diagnostic: leave pipeline parts out (results go stale, timing only)
-            # joint FPS: the double-batch launch whose lane is consumed now / the one relaunched (even steps only)
-            took, go = (1 - (sidx // 2) % 2, (sidx // 2) % 2 if lane == 0 else None) if joint else (lane, lane)
+            # the first-level launch whose result is consumed now / the one (re)launched (joint: even steps only)
+            plan = schedule.side_step(sidx, lanes, joint, npool)
+            took, go = plan["wait"], plan["launch"]
             with torch.cuda.stream(s_b):
                 s_b.wait_event(ev_main)        # rotate() has read in_b / a_stable
                 s_b.wait_event(ev_lane[took])  # events, not stream waits: several parts may share a queue
@@ -579,9 +579,9 @@ def main():
                 launch_fps()
             with torch.cuda.stream(s_b):
                 if "geo" not in skip:
-                    (f_b[(sidx + 1) % 2] if isinstance(f_b, list) else f_b)()
+                    (f_b[schedule.variants(sidx, True)[1]] if isinstance(f_b, list) else f_b)()
                 ev_b.record(s_b)
-        (f_feat[sidx % 2] if isinstance(f_feat, list) else f_feat)()
+        (f_feat[schedule.variants(sidx, True)[0]] if isinstance(f_feat, list) else f_feat)()
         if flatg is not None:
             flatg.allreduce()
         f_update()

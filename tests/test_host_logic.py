@@ -346,3 +346,78 @@ def test_reference_overlay_and_native_module_registration():
                  "three_interpolate_wrapper", "three_interpolate_grad_wrapper"):
         assert callable(getattr(pointnet2_batch_cuda, name))
     sys.modules.pop("pointnet2_batch_cuda"); sys.modules.pop("pointops_cuda")
+
+
+@pytest.mark.parametrize("lanes,joint,npool", [(2, True, 4), (2, False, 4), (2, True, 3), (3, False, 4), (2, True, 5), (1, False, 4)])
+def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, joint, npool):
+    """bench.py's pipelined loop replayed with batch ids instead of tensors (amcontrast3d_amd/schedule.py holds its index
+    arithmetic): at every step the feature half must see ONE batch -- its points, its four FPS levels and its neighbourhood /
+    loss geometry -- a first-level FPS result must be `lanes` (joint: 2-3) steps old when it is consumed (it takes about a step),
+    no first-level input may be overwritten between launch and consumption, and the batches come round-robin from the pool."""
+    from amcontrast3d_amd import schedule
+    pingpong = True
+    period = schedule.period(lanes, npool, pingpong, joint)
+    assert period % lanes == 0 and period % npool == 0 and period % 2 == 0 and (not joint or period % 4 == 0)
+    fps1 = lambda b: ("fps1", b)            # noqa: E731  first FPS level of batch b
+    fps2 = lambda f: ("fps2", f[1])         # noqa: E731  levels 2-4, from the first level
+    geo = lambda b, f: ("geo", b, f)        # noqa: E731  neighbourhoods of batch b computed with the sampling f
+    # bench.py's initial buffers
+    data, in_b, in_a1s = 0, 1 % npool, 2 % npool
+    if joint:
+        in_a = [[(3 + 2 * j) % npool, (4 + 2 * j) % npool] for j in range(2)]
+        a1_out = [[fps1(b) for b in row] for row in in_a]
+        launched = [[-10, -10], [-10, -10]]
+    else:
+        in_a = [(3 + l) % npool for l in range(lanes)]
+        a1_out = [fps1(b) for b in in_a]
+        launched = [-10] * lanes
+    a1_stable = fps1(in_a1s)
+    a2_out = fps2(a1_stable)
+    a_stable = (fps1(in_b), fps2(fps1(in_b)))
+    cur_fps = (fps1(data), fps2(fps1(data)))
+
+    def at(what, buf):
+        for i in buf:
+            what = what[i]
+        return what
+
+    def put(what, buf, v):
+        for i in buf[:-1]:
+            what = what[i]
+        what[buf[-1]] = v
+
+    n0 = 0
+    R = [None, None]
+    R[schedule.variants(n0 % period, pingpong)[0]] = geo(in_b, a_stable)   # the priming replay of stream B
+    seen = []
+    for n in range(n0, n0 + 6 * period):
+        s = n % period
+        # rotate (main stream)
+        cur_fps, data = a_stable, in_b
+        # rotate_side (geometry queue)
+        plan = schedule.side_step(s, lanes, joint, npool)
+        a_stable, in_b = (a1_stable, a2_out), in_a1s
+        assert n - at(launched, plan["consume"]) >= (2 if joint else lanes), "first-level FPS consumed before it can have finished"
+        a1_stable, in_a1s = at(a1_out, plan["consume"]), at(in_a, plan["consume"])
+        assert a1_stable == fps1(in_a1s), "an input buffer was overwritten between its FPS launch and its consumption"
+        for buf, pi in plan["load"]:
+            put(in_a, buf, pi)
+        # first-level FPS launch (finishes about a step later; modelled as reading its inputs now)
+        if plan["launch"] is not None:
+            if joint:
+                j = plan["launch"]
+                a1_out[j] = [fps1(b) for b in in_a[j]]
+                launched[j] = [n, n]
+            else:
+                a1_out[plan["launch"]] = fps1(in_a[plan["launch"]])
+                launched[plan["launch"]] = n
+        a2_out = fps2(a1_stable)                                   # stream A2
+        reads, fills = schedule.variants(s, pingpong)
+        R[fills] = geo(in_b, a_stable)                             # stream B
+        # the feature half
+        assert cur_fps == (fps1(data), fps2(fps1(data))), (n, data, cur_fps)
+        assert R[reads] == geo(data, cur_fps), (n, data, R[reads])
+        assert reads != fills
+        seen.append(data)
+    seen = seen[8:]                          # the initial contents of the buffers drain first
+    assert all(seen[i + 1] == (seen[i] + 1) % npool for i in range(len(seen) - 1)), seen
