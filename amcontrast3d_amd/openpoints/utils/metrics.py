@@ -6,8 +6,11 @@
 
 Integer work on the GPU (a scatter-add histogram of true * C + pred, no host read-back); the matrix stays an int64 device tensor so that
 `dist.all_reduce(cm.tp)` etc. keep working as in examples/segmentation/main_AA.py:460-462.
-One deliberate difference: `update` does not overwrite the caller's `pred` / `true` tensors where
-true == ignore_index (the reference's flatten() views make its in-place writes visible outside).
+Deliberate differences: `update` does not overwrite the caller's `pred` / `true` tensors where
+true == ignore_index (the reference's flatten() views make its in-place writes visible outside); a label or prediction
+outside [0, num_classes) that is not ignore_index makes the reference's bincount / view raise at once -- here such entries are
+left out of the histogram (an out-of-range scatter index would fault the GPU), counted on the device, and the error is raised
+by the first summary that reads the matrix back (all_acc / all_metrics / check()): update() never waits for the GPU.
 """
 import torch
 
@@ -34,6 +37,7 @@ class ConfusionMatrix:
 
     def __init__(self, num_classes, ignore_index=None):
         self.value = 0
+        self.invalid = 0  # entries outside the class range seen so far (device scalar once update() has run)
         self.num_classes = num_classes
         self.virtual_num_classes = num_classes + (1 if ignore_index is not None else 0)
         self.ignore_index = ignore_index
@@ -48,13 +52,23 @@ class ConfusionMatrix:
             pred = torch.where(ignored, v - 1, pred)
         # a histogram by scatter-add rather than torch.bincount: bincount reads its maximum back to the host, which
         # would drain the GPU once per training step (train_one_epoch updates the matrix every iteration)
-        key = true * v + pred
+        valid = (true >= 0) & (true < v) & (pred >= 0) & (pred < v)
+        key = torch.where(valid, true * v + pred, 0)
         bins = torch.zeros(v * v, dtype=torch.int64, device=key.device)
-        bins.scatter_add_(0, key, torch.ones_like(key, dtype=torch.int64))
+        bins.scatter_add_(0, key, valid.to(torch.int64))
         self.value = self.value + bins.view(v, v)[:self.num_classes, :self.num_classes]
+        self.invalid = self.invalid + (~valid).sum()
+
+    def check(self):
+        """raise if update() met a label / prediction outside the class range (reads one scalar back)"""
+        n = int(self.invalid)
+        if n:
+            raise ValueError(f"ConfusionMatrix: {n} entries with a label or prediction outside [0, {self.num_classes})"
+                             + (f" other than ignore_index = {self.ignore_index}" if self.ignore_index is not None else ""))
 
     def reset(self):
         self.value = 0
+        self.invalid = 0
 
     # ---- per-class vectors --------------------------------------------------------------------
     @property
@@ -110,9 +124,11 @@ class ConfusionMatrix:
         return torch.mean(per_class).item(), overall.item(), per_class.cpu().numpy()
 
     def all_acc(self):
+        self.check()
         return self.cal_acc(self.tp, self.count)
 
     def all_metrics(self):
+        self.check()
         tp = self.tp
         iou = tp / self.union.clamp(min=1) * 100
         acc = tp / self.count.clamp(min=1) * 100

@@ -421,3 +421,31 @@ def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, joint
         seen.append(data)
     seen = seen[8:]                          # the initial contents of the buffers drain first
     assert all(seen[i + 1] == (seen[i] + 1) % npool for i in range(len(seen) - 1)), seen
+
+
+def test_confusion_matrix_counts_and_rejects_out_of_range_labels():
+    """openpoints/utils/metrics.py:50-170 (CPU tensors here): the matrix, ignore_index, and labels outside the class range --
+    left out of the histogram, reported by the first summary that reads the matrix back"""
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    import torch
+    from openpoints.utils import ConfusionMatrix
+    true = torch.tensor([0, 1, 2, 2, 255, 1])
+    pred = torch.tensor([0, 2, 2, 1, 0, 1])
+    cm = ConfusionMatrix(3, ignore_index=255)
+    cm.update(pred, true)
+    assert cm.value.tolist() == [[1, 0, 0], [0, 1, 1], [0, 1, 1]]
+    assert int(true[4]) == 255 and int(pred[4]) == 0  # the caller's tensors are left alone
+    miou, macc, oa, ious, accs = cm.all_metrics()
+    assert abs(oa - 60.0) < 1e-4
+    cm.update(torch.tensor([0, 7, -1]), torch.tensor([0, 1, 2]))  # prediction 7 and -1: not classes, not ignore_index
+    assert cm.value.tolist() == [[2, 0, 0], [0, 1, 1], [0, 1, 1]]
+    with pytest.raises(ValueError, match="2 entries"):
+        cm.all_metrics()
+    cm.reset()
+    cm.update(pred[:4], true[:4])
+    cm.all_acc()
+    with pytest.raises(ValueError):
+        bad = ConfusionMatrix(3)  # no ignore_index: 255 is out of range
+        bad.update(pred, true)
+        bad.check()
