@@ -2,8 +2,10 @@
 ``build_optimizer_from_cfg(model, **cfg.optimizer)``.
 
 What the shipped configs use -- ``NAME: 'adamw'``, lr 0.01, weight_decay 1e-4 (cfgs/s3dis/default.yaml:64-69) -- and the
-plain torch optimizers (sgd / nesterov / momentum / adam / adamw) are built here; on the GPU AdamW / Adam are created
-``fused=True, capturable=True`` so that the update is one multi-tensor launch that a hipGraph can replay.  The reference's
+plain torch optimizers (sgd / nesterov / momentum / adam / adamw) are built here.  On the GPU 'adamw' is this library's
+``FusedAdamW`` (amcontrast3d_amd/fused_optim.py: same arguments, groups and state_dict as torch.optim.AdamW, two launches per step,
+``step(max_grad_norm=...)`` folds clip_grad_norm_ in; AMC3D_TORCH_ADAMW=1 keeps torch's), Adam is created
+``fused=True, capturable=True`` so that the update is a few multi-tensor launches that a hipGraph can replay.  The reference's
 collection of third-party optimizers (AdaBelief, Lamb, MADGRAD, ...) is outside the hot path: ask for one and the error
 names it (with AMC3D_REFERENCE_ROOT set, ``openpoints.optim`` of the reference tree can be imported instead).
 """
@@ -92,6 +94,14 @@ def build_optimizer_from_cfg(model, NAME='sgd', lr=None, weight_decay=0., moment
         args.pop('eps', None)
         return optim.SGD(parameters, momentum=momentum, nesterov=False, **args)
     if opt in ('adam', 'adamw'):
+        import os
+        plist = [p for g in parameters for p in g['params']] if parameters and isinstance(parameters[0], dict) else parameters
+        if (opt == 'adamw' and on_gpu and not os.environ.get("AMC3D_TORCH_ADAMW") and set(args) <= {'lr', 'weight_decay', 'betas', 'eps'}
+                and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in plist)):
+            # this library's AdamW: one table-driven launch over all parameter tensors, gradient-norm clipping folded into
+            # step(max_grad_norm=...) (amcontrast3d_amd/fused_optim.py); a torch.optim.Optimizer with torch's state_dict layout
+            from amcontrast3d_amd.fused_optim import FusedAdamW
+            return FusedAdamW(parameters, **args)
         if on_gpu:
             args.setdefault('fused', True)
             args.setdefault('capturable', True)

@@ -98,12 +98,16 @@ def _run_epoch(model, train_loader, criterion, optimizer, scheduler, scaler, epo
             loss.backward()
         if num_iter == cfg.step_per_update:
             # (with use_amp the reference clips the still-scaled gradients, main_AA.py:402-409; kept as it is)
-            if clip is not None and clip > 0.:
+            clipping = clip is not None and clip > 0.
+            folded = clipping and not use_amp and type(optimizer).__name__ == "FusedAdamW"  # clip inside the optimizer's launch
+            if clipping and not folded:
                 torch.nn.utils.clip_grad_norm_(model.parameters(), clip, norm_type=2)
             num_iter = 0
             if use_amp:
                 scaler.step(optimizer)
                 scaler.update()
+            elif folded:
+                optimizer.step(max_grad_norm=clip)
             else:
                 optimizer.step()
             optimizer.zero_grad()

@@ -530,9 +530,14 @@ def main():
     def body_b():
         geometry.copy_into(b_out, geometry.split(geo_rest(in_b, a_stable))[1])
 
+    fused_update = hasattr(opt, "step") and type(opt).__name__ == "FusedAdamW"
+
     def update():
-        torch.nn.utils.clip_grad_norm_(params, 10, norm_type=2)
-        opt.step()
+        if fused_update:  # clip_grad_norm_(params, 10, 2) + AdamW as two launches (csrc/optim.hip)
+            opt.step(max_grad_norm=10)
+        else:
+            torch.nn.utils.clip_grad_norm_(params, 10, norm_type=2)
+            opt.step()
 
     step_no = [0]
 
@@ -659,6 +664,8 @@ def main():
                 capture_feat(key, "feat" if v else None)
         else:
             capture_feat("feat")
+        if fused_update:
+            opt.prepare()  # the .grad tensors are the feature graph's now: rebuild the optimizer's tensor table before capture
         with torch.cuda.graph(graphs["update"], stream=cap, capture_error_mode=cap_mode):
             update()
         for j in range(period):

@@ -460,6 +460,27 @@ int amc3d_bn_backward_synced(int B, int C, long L, int K, int relu, const float 
                              const unsigned char *arg, const float *mean, const float *invstd, const float *gamma,
                              const float *beta, const double *dsums, const double *count, float *dx, void *stream);
 
+/* ---- gradient-norm clipping + AdamW over all parameter tensors in two launches ---------------------
+ * Replaces  torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm, norm_type=2); optimizer.step()  with
+ * torch.optim.AdamW (examples/segmentation/main_AA.py:586-592; optimizer built by openpoints/optim/optim_factory.py:160-230).
+ * table: ntensors records in DEVICE memory; block_map: nblocks pairs (tensor index, chunk index) in device memory, one per
+ * amc3d_adamw_chunk() elements of every tensor; every record's step (a device float of its own: torch counts steps per
+ * parameter) is incremented by the call; partial: nblocks doubles of scratch; total_norm: device float or NULL (the 2-norm of all gradients before clipping, what clip_grad_norm_ returns);
+ * max_grad_norm <= 0: no clipping.  The clipped gradient is used for the update, the .grad tensors are left as they are. */
+typedef struct {
+    float *param;
+    const float *grad;
+    float *exp_avg;
+    float *exp_avg_sq;
+    float *step;
+    long long numel;
+    float weight_decay;
+    float lr;
+} amc3d_adamw_tensor;
+int amc3d_adamw_chunk(void);
+int amc3d_adamw_step(const void *table, const int *block_map, int nblocks, double beta1, double beta2, float eps,
+                     float max_grad_norm, double *partial, float *total_norm, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -449,3 +449,10 @@ def test_confusion_matrix_counts_and_rejects_out_of_range_labels():
         bad = ConfusionMatrix(3)  # no ignore_index: 255 is out of range
         bad.update(pred, true)
         bad.check()
+
+
+def test_fused_adamw_has_no_cpu_path():
+    import torch
+    from amcontrast3d_amd.fused_optim import FusedAdamW
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        FusedAdamW([torch.zeros(3, requires_grad=True)], lr=1e-3)
