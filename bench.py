@@ -493,11 +493,15 @@ def main():
         data["_geometry"] = cur
         torch.cuda.synchronize()
 
-    handover = {"direct": False}  # set once the ping-pong variants are captured
+    # "direct": set once the ping-pong variants are captured; "inputs": [(batch buffers, FPS picks)] x 2 once the feature
+    # variants read stream B's input buffers themselves (then nothing at all moves on the main stream between steps)
+    handover = {"direct": False, "inputs": None}
 
     def rotate(s=0):  # main stream, between steps: what the feature half of the new step reads
         if not overlap:
             copy_batch(data, pool[s % npool])
+            return
+        if handover["inputs"] is not None:
             return
         geometry.copy_into(cur_fps, a_stable)
         if not handover["direct"]:
@@ -511,8 +515,10 @@ def main():
 
     def rotate_side(s=0):  # geometry queue, after rotate(): advance the side streams' buffers by one batch
         plan = schedule.side_step(s, lanes, joint, npool)
-        geometry.copy_into(a_stable, a1_stable + a2_out)
-        copy_batch(in_b, in_a1s)
+        # stream B's inputs for the batch after this one (ping-pong: the set the NEXT step's feature variant reads as well)
+        tb, ta = handover["inputs"][schedule.variants(s, True)[1]] if handover["inputs"] is not None else (in_b, a_stable)
+        geometry.copy_into(ta, a1_stable + a2_out)
+        copy_batch(tb, in_a1s)
         geometry.copy_into(a1_stable, first_level(plan["consume"], a1_out))
         copy_batch(in_a1s, first_level(plan["consume"], in_a))
         for buf, pi in plan["load"]:
@@ -647,21 +653,30 @@ def main():
 
         if pingpong:
             graphs["b1"], graphs["feat1"] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            # Two sets of stream B's inputs (batch buffers + FPS picks) as well: variant v of B reads set v and fills result
+            # set R[v]; one step later variant v of the feature half reads the SAME set v and R[v] -- so the batch and its picks
+            # are never copied into buffers of the feature half's own, and the main stream does nothing between two steps.
+            in_b2 = [in_b, {k: v.clone() for k, v in in_b.items()}]
+            a_st2 = [a_stable, geometry.clone(a_stable)]
             rest = []
-            for key in ("b", "b1"):
+            for v, key in enumerate(("b", "b1")):
                 with torch.cuda.graph(graphs[key], stream=s_b, capture_error_mode=cap_mode):
-                    rest.append(geometry.split(geo_rest(in_b, a_stable))[1])  # the graph's own outputs: R[0], R[1]
-            # nothing in a result set may be a view of stream B's INPUTS (those already belong to the next batch when the
-            # feature half reads the set)
-            inputs = set()
-            geometry._walk([a_stable, in_b], lambda t: inputs.add(t.untyped_storage().data_ptr()))
-            for r in rest:
-                geometry._walk(r, lambda t: None if t.untyped_storage().data_ptr() not in inputs else
-                               sys.exit("bench.py: the geometry plan aliases its inputs; run with AMC3D_NO_PINGPONG=1"))
+                    rest.append(geometry.split(geo_rest(in_b2[v], a_st2[v]))[1])  # the graph's own outputs: R[0], R[1]
+            # a result set may only alias the inputs of its own variant (those belong to the same batch)
+            for v, r in enumerate(rest):
+                other = set()
+                geometry._walk([a_st2[1 - v], in_b2[1 - v], in_a1s, a1_stable, a2_out],
+                               lambda t: other.add(t.untyped_storage().data_ptr()))
+                geometry._walk(r, lambda t: None if t.untyped_storage().data_ptr() not in other else
+                               sys.exit("bench.py: the geometry plan aliases another batch's buffers; run with AMC3D_NO_PINGPONG=1"))
             handover["direct"] = True
+            own = dict(data)  # the feature half's own buffers (the eager per-operator timing below uses them again)
             for v, key in enumerate(("feat", "feat1")):
-                data["_geometry"] = geometry.join(cur_fps, rest[v])
+                data.update(in_b2[v])
+                data["_geometry"] = geometry.join(a_st2[v], rest[v])
                 capture_feat(key, "feat" if v else None)
+            data.update(own)
+            handover["inputs"] = list(zip(in_b2, a_st2))
         else:
             capture_feat("feat")
         if fused_update:
@@ -669,8 +684,9 @@ def main():
         with torch.cuda.graph(graphs["update"], stream=cap, capture_error_mode=cap_mode):
             update()
         for j in range(period):
-            with torch.cuda.graph(graphs[f"rotate{j}"], stream=cap, capture_error_mode=cap_mode):
-                rotate(j)
+            if handover["inputs"] is None:  # (otherwise nothing moves on the main stream: no graph to replay)
+                with torch.cuda.graph(graphs[f"rotate{j}"], stream=cap, capture_error_mode=cap_mode):
+                    rotate(j)
             if overlap:
                 with torch.cuda.graph(graphs[f"side{j}"], stream=s_b, capture_error_mode=cap_mode):
                     rotate_side(j)
@@ -685,14 +701,21 @@ def main():
                     body_b()
         torch.cuda.synchronize()
         if pingpong:
-            # in_b / a_stable still hold the batch the next rotate makes current: its geometry goes into the result set the
-            # next step's feature variant reads
+            # in_b / a_stable (= set 0) still hold the batch the next step works on: it goes into the set the next step's
+            # feature variant reads, and its geometry into that set's results
+            v0 = schedule.variants(step_no[0] % period, True)[0]
             with torch.cuda.stream(s_b):
-                graphs["b1" if (step_no[0] % period) % 2 else "b"].replay()
+                if v0 == 1:
+                    copy_batch(in_b2[1], in_b2[0])
+                    geometry.copy_into(a_st2[1], a_st2[0])
+                graphs["b1" if v0 else "b"].replay()
             torch.cuda.synchronize()
 
+        def rot_replay(j):
+            return graphs[f"rotate{j}"].replay if handover["inputs"] is None else (lambda: None)
+
         def step():
-            run_step([graphs[f"rotate{j}"].replay for j in range(period)], [graphs[f"side{j}"].replay for j in range(period)],
+            run_step([rot_replay(j) for j in range(period)], [graphs[f"side{j}"].replay for j in range(period)],
                      [graphs[f"fps{l}"].replay for l in range(lanes)],
                      graphs["a2"].replay, [graphs["b"].replay, graphs["b1"].replay] if pingpong else graphs["b"].replay,
                      [graphs["feat"].replay, graphs["feat1"].replay] if pingpong else graphs["feat"].replay,
@@ -748,7 +771,7 @@ def main():
             ref = torch.cuda.Event(enable_timing=True)
             ref.record(main_s)
             h0 = time.perf_counter()
-            run_step([timed(graphs[f"rotate{j}"].replay, main_s, "rotate", log) for j in range(period)],
+            run_step([timed(rot_replay(j), main_s, "rotate", log) for j in range(period)],
                      [timed(graphs[f"side{j}"].replay, s_b, "side", log) for j in range(period)],
                      [timed(graphs[f"fps{l}"].replay, s_a[l], f"fps{l}", log) for l in range(lanes)],
                      timed(graphs["a2"].replay, s_a2, "a2", log),
@@ -785,7 +808,7 @@ def main():
         parts = {"features_ms": alone(graphs["feat"].replay, main_s), "update_ms": alone(graphs["update"].replay, main_s),
                  "fps_level1_ms": alone(graphs["fps0"].replay, s_a[0]), "fps_levels2to4_ms": alone(graphs["a2"].replay, s_a2),
                  "neighbourhood_geometry_ms": alone(graphs["b"].replay, s_b),
-                 "rotate_ms": alone(graphs["rotate0"].replay, main_s),
+                 "rotate_ms": alone(rot_replay(0), main_s),
                  "rotate_side_ms": alone(graphs["side0"].replay, s_b)}
 
         # the same step with nothing overlapped: every part replayed on the stream it was captured on, one after the other
@@ -797,7 +820,7 @@ def main():
                     torch.cuda.synchronize()
                     per = {}
                     t = time.perf_counter()
-                for tag, fn, st in (("rotate", graphs[f"rotate{r % period}"].replay, main_s),
+                for tag, fn, st in (("rotate", rot_replay(r % period), main_s),
                                     ("rotate_side", graphs[f"side{r % period}"].replay, s_b),
                                     ("fps1", graphs[f"fps{(r // 2 if joint else r) % lanes}"].replay if not (joint and r % 2)
                                      else (lambda: None), s_a[r % lanes]),

@@ -362,7 +362,7 @@ def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, joint
     fps2 = lambda f: ("fps2", f[1])         # noqa: E731  levels 2-4, from the first level
     geo = lambda b, f: ("geo", b, f)        # noqa: E731  neighbourhoods of batch b computed with the sampling f
     # bench.py's initial buffers
-    data, in_b, in_a1s = 0, 1 % npool, 2 % npool
+    in_b, in_a1s = 1 % npool, 2 % npool
     if joint:
         in_a = [[(3 + 2 * j) % npool, (4 + 2 * j) % npool] for j in range(2)]
         a1_out = [[fps1(b) for b in row] for row in in_a]
@@ -374,7 +374,6 @@ def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, joint
     a1_stable = fps1(in_a1s)
     a2_out = fps2(a1_stable)
     a_stable = (fps1(in_b), fps2(fps1(in_b)))
-    cur_fps = (fps1(data), fps2(fps1(data)))
 
     def at(what, buf):
         for i in buf:
@@ -387,16 +386,20 @@ def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, joint
         what[buf[-1]] = v
 
     n0 = 0
-    R = [None, None]
-    R[schedule.variants(n0 % period, pingpong)[0]] = geo(in_b, a_stable)   # the priming replay of stream B
+    # ping-pong: two sets of stream B's inputs (batch, FPS picks) and results; the feature variant of step n reads set
+    # variants(n)[0], which stream B's variant filled -- inputs by rotate_side, results by B -- during step n - 1
+    v0 = schedule.variants(n0 % period, pingpong)[0]
+    sets = [None, None]
+    sets[v0] = {"batch": in_b, "fps": a_stable, "geo": geo(in_b, a_stable)}   # the priming copy + replay of stream B
     seen = []
     for n in range(n0, n0 + 6 * period):
         s = n % period
-        # rotate (main stream)
-        cur_fps, data = a_stable, in_b
+        reads, fills = schedule.variants(s, pingpong)
+        assert reads != fills
+        # (nothing moves on the main stream)
         # rotate_side (geometry queue)
         plan = schedule.side_step(s, lanes, joint, npool)
-        a_stable, in_b = (a1_stable, a2_out), in_a1s
+        sets[fills] = {"batch": in_a1s, "fps": (a1_stable, a2_out)}
         assert n - at(launched, plan["consume"]) >= (2 if joint else lanes), "first-level FPS consumed before it can have finished"
         a1_stable, in_a1s = at(a1_out, plan["consume"]), at(in_a, plan["consume"])
         assert a1_stable == fps1(in_a1s), "an input buffer was overwritten between its FPS launch and its consumption"
@@ -412,13 +415,12 @@ def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, joint
                 a1_out[plan["launch"]] = fps1(in_a[plan["launch"]])
                 launched[plan["launch"]] = n
         a2_out = fps2(a1_stable)                                   # stream A2
-        reads, fills = schedule.variants(s, pingpong)
-        R[fills] = geo(in_b, a_stable)                             # stream B
-        # the feature half
-        assert cur_fps == (fps1(data), fps2(fps1(data))), (n, data, cur_fps)
-        assert R[reads] == geo(data, cur_fps), (n, data, R[reads])
-        assert reads != fills
-        seen.append(data)
+        sets[fills]["geo"] = geo(sets[fills]["batch"], sets[fills]["fps"])   # stream B, variant `fills`
+        # the feature half, variant `reads`
+        cur = sets[reads]
+        assert cur["fps"] == (fps1(cur["batch"]), fps2(fps1(cur["batch"]))), (n, cur)
+        assert cur["geo"] == geo(cur["batch"], cur["fps"]), (n, cur)
+        seen.append(cur["batch"])
     seen = seen[8:]                          # the initial contents of the buffers drain first
     assert all(seen[i + 1] == (seen[i] + 1) % npool for i in range(len(seen) - 1)), seen
 
