@@ -552,50 +552,63 @@ def main():
     def run_step(f_rotate, f_side, f_a, f_a2, f_b, f_feat, f_update):
         sidx = step_no[0] % period
         step_no[0] += 1
+
+        def critical_path():  # main stream: features (+ gradient all-reduce) + update
+            (f_feat[schedule.variants(sidx, True)[0]] if isinstance(f_feat, list) else f_feat)()
+            if flatg is not None:
+                flatg.allreduce()
+            f_update()
+
         if not overlap:
             f_rotate[sidx]()
-        if overlap:
-            lane = sidx % lanes  # the FPS lane launched `lanes` steps ago delivers now and is relaunched
-            # The main stream only moves what the feature half reads (the batch and its FPS picks); everything else of the
-            # hand-down -- five groups of small copies between the side streams' buffers -- runs on the geometry queue, off
-            # the critical path.  ev_b also orders this step's rotate() after the previous step's rotate_side() (same queue).
-            main_s.wait_event(ev_b)
-            f_rotate[sidx]()
-            ev_main.record(main_s)
-            skip = os.environ.get("AMC3D_SKIP", "")  # diagnostic: leave pipeline parts out (results go stale, timing only)
-            # the first-level launch whose result is consumed now / the one (re)launched (joint: even steps only)
-            plan = schedule.side_step(sidx, lanes, joint, npool)
-            took, go = plan["wait"], plan["launch"]
-            with torch.cuda.stream(s_b):
-                s_b.wait_event(ev_main)        # rotate() has read in_b / a_stable
-                s_b.wait_event(ev_lane[took])  # events, not stream waits: several parts may share a queue
-                s_b.wait_event(ev_a2)
-                f_side[sidx]()
-                ev_rot.record(s_b)
-            def launch_fps():
-                if go is not None:
-                    with torch.cuda.stream(s_a[go]):
-                        s_a[go].wait_event(ev_rot)
-                        if "fps" not in skip:
-                            f_a[go]()
-                        ev_lane[go].record(s_a[go])
-            if not a2_first:
-                launch_fps()
-            with torch.cuda.stream(s_a2):
-                s_a2.wait_event(ev_rot)
-                if "a2" not in skip:
-                    f_a2()
-                ev_a2.record(s_a2)
-            if a2_first:
-                launch_fps()
-            with torch.cuda.stream(s_b):
-                if "geo" not in skip:
-                    (f_b[schedule.variants(sidx, True)[1]] if isinstance(f_b, list) else f_b)()
-                ev_b.record(s_b)
-        (f_feat[schedule.variants(sidx, True)[0]] if isinstance(f_feat, list) else f_feat)()
-        if flatg is not None:
-            flatg.allreduce()
-        f_update()
+            critical_path()
+            return
+        lane = sidx % lanes  # the FPS lane launched `lanes` steps ago delivers now and is relaunched
+        # The main stream only moves what the feature half reads (the batch and its FPS picks; nothing at all once the
+        # feature variants read stream B's input sets); everything else of the hand-down -- five groups of small copies between
+        # the side streams' buffers -- runs on the geometry queue, off the critical path.  ev_b also orders this step's
+        # rotate() after the previous step's rotate_side() (same queue).
+        main_s.wait_event(ev_b)
+        f_rotate[sidx]()
+        ev_main.record(main_s)
+        # the critical path is launched FIRST: the side launches below take the host 0.3-0.5 ms, during which the main stream
+        # used to sit idle at the start of every step (HIP-event timeline: the feature graph started 0.3-0.5 ms into the step)
+        launch_first = not os.environ.get("AMC3D_SIDE_FIRST")
+        if launch_first:
+            critical_path()
+        skip = os.environ.get("AMC3D_SKIP", "")  # diagnostic: leave pipeline parts out (results go stale, timing only)
+        # the first-level launch whose result is consumed now / the one (re)launched (joint: even steps only)
+        plan = schedule.side_step(sidx, lanes, joint, npool)
+        took, go = plan["wait"], plan["launch"]
+        with torch.cuda.stream(s_b):
+            s_b.wait_event(ev_main)        # rotate() has read in_b / a_stable
+            s_b.wait_event(ev_lane[took])  # events, not stream waits: several parts may share a queue
+            s_b.wait_event(ev_a2)
+            f_side[sidx]()
+            ev_rot.record(s_b)
+
+        def launch_fps():
+            if go is not None:
+                with torch.cuda.stream(s_a[go]):
+                    s_a[go].wait_event(ev_rot)
+                    if "fps" not in skip:
+                        f_a[go]()
+                    ev_lane[go].record(s_a[go])
+        if not a2_first:
+            launch_fps()
+        with torch.cuda.stream(s_a2):
+            s_a2.wait_event(ev_rot)
+            if "a2" not in skip:
+                f_a2()
+            ev_a2.record(s_a2)
+        if a2_first:
+            launch_fps()
+        with torch.cuda.stream(s_b):
+            if "geo" not in skip:
+                (f_b[schedule.variants(sidx, True)[1]] if isinstance(f_b, list) else f_b)()
+            ev_b.record(s_b)
+        if not launch_first:
+            critical_path()
 
     def eager_step():
         if flatg is None:
