@@ -963,8 +963,12 @@ def main():
                        "global_batch": args.batch * world, "points": args.points,
                        "parallelism": f"dp{world}" + ("+syncbn+ddp" if use_ddp else "+syncbn" if sync_bn else ""),
                        "launch": "hipGraph replay (fwd+loss+bwd | clip+AdamW)" if use_graph else "eager",
-                       "pipeline": f"{3 + lanes} streams: FPS level 1 of {lanes} future batches in flight | FPS levels 2-4 "
-                                               f"(t+2) | neighbourhood + loss geometry (t+1) | features (t)"
+                       "pipeline": (("3 queues: sampling (FPS levels 2-4 of batch t+2 every step, then level 1 of batches t+3 and "
+                                     "t+4 as one launch every second step) | neighbourhood + loss geometry of batch t+1 (CU-masked) | "
+                                     "features of batch t; geometry handed over without copies (two captured variants each)")
+                                    if (joint and pingpong) else
+                                    f"{3 + lanes} streams: FPS level 1 of {lanes} future batches in flight | FPS levels 2-4 "
+                                    f"(t+2) | neighbourhood + loss geometry (t+1) | features (t)")
                                    if overlap_was else "none"},
             "loss": round(final_loss, 6),
             "replicas_in_sync": replicas_in_sync,
