@@ -183,6 +183,108 @@ __global__ __launch_bounds__(256) void gm_gemm_kernel(int M, int N, long K, int 
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the deep layers, streaming form:  dW[m][n] = sum over positions p of dY[m][p] X[n][p].
+// Both operands are read along their contiguous axis and nothing else is read: the pass is HBM-bound (SA2 of PointNeXt-S:
+// 295 MB for 6.4 GF), and gm_gemm_kernel<true, true> served it at 1.4 TB/s -- 64-byte row pieces per 16-position chunk, a
+// 128 x 128 tile of which a 64-wide layer uses half, a thousand 32 KB partials.  Here
+//   * a chunk is 32 positions: every row contributes one whole 128-byte line per chunk;
+//   * the tile is 128 x TN with TN = 64 or 128 (template): a wave owns 32 rows of dY and all TN rows of X, TN/32
+//     accumulators -- no MFMA issued for channels that do not exist;
+//   * [row][k] LDS images with a 36-float stride (8 consecutive rows x 16 bytes cover the banks once: ds_read_b128 fragments),
+//     double-buffered, the next chunk's six global loads per thread in flight during the MFMAs, one barrier per chunk;
+//   * position ranges long enough for ~2 workgroups per CU (fewer, larger partials; same fixed-order reduction).
+// k-pairing of v_mfma_f32_32x32x2_f32 as in gm_gemm_kernel: step t multiplies positions t (lanes 0-31) and 16 + t (32-63).
+// Requires P % 4 == 0 and 16-byte aligned operands (float4 loads); anything else keeps the generic kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int GW_KC = 32, GW_S = 36, GW_TM = 128;
+
+template <int TN>
+__global__ __launch_bounds__(256) void gw_wgrad_kernel(int M, int N, long P, int splits, long kper, const float *__restrict__ dy,
+                                                       const float *__restrict__ x, float *__restrict__ partial)
+{
+    constexpr int ROWS = GW_TM + TN;               // dY rows then X rows of the tile
+    constexpr int LPT = ROWS * (GW_KC / 4) / 256;  // float4 loads per thread and chunk: 6 (TN = 64) or 8 (TN = 128)
+    constexpr int NJ = TN / 32;
+    extern __shared__ __attribute__((aligned(16))) float gw_smem[];  // 2 stages x ROWS x GW_S
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pl = lane & 31, kh = lane >> 5;
+    const int m0 = blockIdx.y * GW_TM, n0 = blockIdx.x * TN;
+    const int z = blockIdx.z, bz = z / splits, sp = z - bz * splits;
+    const long kbeg = (long)sp * kper, kend = min(P, kbeg + kper);
+    const float *A = dy + (size_t)bz * M * P, *B = x + (size_t)bz * N * P;
+
+    gm_f32x16 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = gm_f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    float4 r[LPT];
+    auto load = [&](long k0) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int row = threadIdx.x / 8 + 32 * i, c4 = threadIdx.x % 8;
+            const long k = k0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < kend) {  // kend - kbeg is a multiple of 4 except at the end of P, and P % 4 == 0: whole float4s
+                if (row < GW_TM) { if (m0 + row < M) v = *reinterpret_cast<const float4 *>(A + (size_t)(m0 + row) * P + k); }
+                else if (n0 + row - GW_TM < N) v = *reinterpret_cast<const float4 *>(B + (size_t)(n0 + row - GW_TM) * P + k);
+            }
+            r[i] = v;
+        }
+    };
+    auto store = [&](float *stage) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int row = threadIdx.x / 8 + 32 * i, c4 = threadIdx.x % 8;
+            *reinterpret_cast<float4 *>(stage + row * GW_S + c4 * 4) = r[i];
+        }
+    };
+    const long nchunks = (kend - kbeg + GW_KC - 1) / GW_KC;
+    if (nchunks > 0) { load(kbeg); store(gw_smem); }
+    __syncthreads();
+    for (long c = 0; c < nchunks; ++c) {
+        const float *as = gw_smem + (c & 1) * ROWS * GW_S, *bs = as + GW_TM * GW_S;
+        const bool more = c + 1 < nchunks;
+        if (more) load(kbeg + (c + 1) * GW_KC);  // in flight while this chunk is multiplied
+        // this lane's 16 positions (kh * 16 + t) of its dY row and of its X rows, in two halves of 8 to bound registers
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float av[8], bv[NJ][8];
+            {
+                const float *pa = as + (wave * 32 + pl) * GW_S + kh * 16 + h * 8;
+                const float4 lo = *reinterpret_cast<const float4 *>(pa), hi = *reinterpret_cast<const float4 *>(pa + 4);
+                av[0] = lo.x; av[1] = lo.y; av[2] = lo.z; av[3] = lo.w; av[4] = hi.x; av[5] = hi.y; av[6] = hi.z; av[7] = hi.w;
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float *pb = bs + (j * 32 + pl) * GW_S + kh * 16 + h * 8;
+                const float4 lo = *reinterpret_cast<const float4 *>(pb), hi = *reinterpret_cast<const float4 *>(pb + 4);
+                bv[j][0] = lo.x; bv[j][1] = lo.y; bv[j][2] = lo.z; bv[j][3] = lo.w;
+                bv[j][4] = hi.x; bv[j][5] = hi.y; bv[j][6] = hi.z; bv[j][7] = hi.w;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[j][t], acc[j], 0, 0, 0);
+        }
+        if (more) store(gw_smem + ((c + 1) & 1) * ROWS * GW_S);
+        __syncthreads();
+    }
+    // accumulator layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float *C = partial + (size_t)z * M * N;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + j * 32 + pl;
+        if (n < N) {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int m = m0 + wave * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * kh;
+                if (m < M) C[(size_t)m * N + n] = acc[j][rr];
+            }
+        }
+    }
+}
+
 static int aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 template <bool AK, bool BK>
@@ -214,8 +316,26 @@ int gemm_conv_backward_data(int b, int cin, int cout, long P, const float *dy, c
     return launch_status("gemm_conv_backward_data");
 }
 
+static bool gw_streaming(int b, int cin, int cout, long P)
+{
+    static const bool off = getenv("AMC3D_NO_STREAMING_WGRAD") != nullptr;
+    return !off && P % 4 == 0 && P >= 4 * GW_KC;
+}
+
 static int gemm_wgrad_splits(int b, int cin, int cout, long P, long *kper)
 {
+    if (gw_streaming(b, cin, cout, P)) {
+        // ~512 workgroups (two per CU), at least 8 chunks each; a range is a whole number of chunks
+        const int tn = cin <= 64 ? 64 : 128;
+        const long tiles = (long)div_up(cout, GW_TM) * div_up(cin, tn);
+        long s = 512 / (tiles * b);
+        const long cap = P / (8 * GW_KC) > 1 ? P / (8 * GW_KC) : 1;
+        if (s > cap) s = cap;
+        if (s < 1) s = 1;
+        const long per = ((P + s - 1) / s + GW_KC - 1) / GW_KC * GW_KC;
+        *kper = per;
+        return (int)((P + per - 1) / per);
+    }
     // enough workgroups to fill the chip, at least 256 positions each
     const long tiles = (long)div_up(cout, GM_T) * div_up(cin, GM_T);
     long s = 1024 / (tiles * b);
@@ -241,6 +361,20 @@ int gemm_conv_backward_weight(int b, int cin, int cout, long P, const float *x, 
 {
     long kper;
     const int s = gemm_wgrad_splits(b, cin, cout, P, &kper);
+    if (gw_streaming(b, cin, cout, P) && aligned16(dy) && aligned16(x)) {
+        if (cin <= 64) {
+            const size_t lds = 2 * (GW_TM + 64) * GW_S * sizeof(float);
+            hipLaunchKernelGGL(gw_wgrad_kernel<64>, dim3(div_up(cin, 64), div_up(cout, GW_TM), b * s), dim3(256), lds, stream, cout,
+                               cin, P, s, kper, dy, x, partial);
+        } else {
+            const size_t lds = 2 * (GW_TM + 128) * GW_S * sizeof(float);
+            (void)hipFuncSetAttribute((const void *)gw_wgrad_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(gw_wgrad_kernel<128>, dim3(div_up(cin, 128), div_up(cout, GW_TM), b * s), dim3(256), lds, stream,
+                               cout, cin, P, s, kper, dy, x, partial);
+        }
+        if (int st = launch_status("gemm_conv_backward_weight")) return st;
+        return reduce_partials(cout * cin, b * s, partial, dw, stream);
+    }
     GemmView A{dy, P, 1}, B{x, P, 1};  // A(m=co,k=p), B(n=ci,k=p): both k-contiguous
     const int va = P % 4 == 0 && aligned16(dy), vb = P % 4 == 0 && aligned16(x);
     gm_launch<true, true>(cout, cin, P, b, s, kper, A, (long)cout * P, B, (long)cin * P, partial, (long)cout * cin, cin, va, vb,

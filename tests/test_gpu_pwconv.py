@@ -18,6 +18,12 @@ SHAPES = [  # B, Cin, Cout, spatial, bias
     (3, 768, 256, (94,), False),     # deepest FP, ragged P
     (1, 1, 1, (5,), True),
     (2, 64, 64, (129,), False),
+    # deep layers with P % 4 == 0: the streaming weight-gradient kernel (csrc/gemm.hip gw_wgrad_kernel), 64- and 128-wide tiles
+    (2, 64, 128, (300, 32), False),   # SA2 of PointNeXt-S
+    (1, 128, 256, (100, 32), False),  # SA3
+    (3, 256, 512, (23, 32), False),   # SA4: short position ranges
+    (2, 96, 200, (1000,), False),     # ragged channel counts
+    (2, 64, 64, (4000,), False),
 ]
 
 
