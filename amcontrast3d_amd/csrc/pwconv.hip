@@ -114,6 +114,31 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(int M, int K, long P, int
         for (int d = 0; d < NIT; ++d) acc[c][d] = pw_f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     const int t_end = min(ntiles, (int)(blockIdx.x + 1) * tiles_per_wg);
+    // vec path: the next tile's rows are loaded into registers before the current tile is multiplied (in flight during the
+    // MFMAs) and stored to LDS after the barrier that retires it
+    constexpr int LPT = (NCT + NIT) * 32 * (PWW_TP / 4) / 256;  // float4 per thread and tile
+    float4 pre[LPT];
+    auto prefetch = [&](int t) {
+        const int b = t / tiles_per_cloud;
+        const long p0 = (long)(t - b * tiles_per_cloud) * PWW_TP;
+        const float *DY = dy + (size_t)b * M * P, *X = x + (size_t)b * K * P;
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) {
+            const int i = threadIdx.x + u * 256;
+            const int row = i / (PWW_TP / 4), c4 = i - row * (PWW_TP / 4);
+            const long p = p0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < NCT * 32) {
+                const int m = m0 + row;
+                if (m < M && p < P) v = *(const float4 *)(DY + (size_t)m * P + p);
+            } else {
+                const int k = k0 + row - NCT * 32;
+                if (k < K && p < P) v = *(const float4 *)(X + (size_t)k * P + p);
+            }
+            pre[u] = v;
+        }
+    };
+    if (vec && (int)(blockIdx.x * tiles_per_wg) < t_end) prefetch(blockIdx.x * tiles_per_wg);
     for (int t = blockIdx.x * tiles_per_wg; t < t_end; ++t) {
         const int b = t / tiles_per_cloud;
         const long p0 = (long)(t - b * tiles_per_cloud) * PWW_TP;
@@ -121,19 +146,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(int M, int K, long P, int
         __syncthreads();  // previous tile consumed
         if (vec) {
             // rows 0..NCT*32-1 are dY channels, the rest X channels; 16 float4 per row
-            for (int i = threadIdx.x; i < (NCT + NIT) * 32 * (PWW_TP / 4); i += 256) {
+#pragma unroll
+            for (int u = 0; u < LPT; ++u) {
+                const int i = threadIdx.x + u * 256;
                 const int row = i / (PWW_TP / 4), c4 = i - row * (PWW_TP / 4);
-                const long p = p0 + c4 * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < NCT * 32) {
-                    const int m = m0 + row;
-                    if (m < M && p < P) v = *(const float4 *)(DY + (size_t)m * P + p);
-                } else {
-                    const int k = k0 + row - NCT * 32;
-                    if (k < K && p < P) v = *(const float4 *)(X + (size_t)k * P + p);
-                }
                 float *d = smem + row * PWW_LD + c4 * 4;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                d[0] = pre[u].x; d[1] = pre[u].y; d[2] = pre[u].z; d[3] = pre[u].w;
             }
         } else {
             for (int i = threadIdx.x; i < (NCT + NIT) * 32 * PWW_TP; i += 256) {
@@ -151,6 +169,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(int M, int K, long P, int
             }
         }
         __syncthreads();
+        if (vec && t + 1 < t_end) prefetch(t + 1);
         // A[i = co][k = position] = dY[co][position],  B[k = position][j = ci] = X[ci][position]
 #pragma unroll
         for (int s = 0; s < PWW_TP / 4; s += 2) {
