@@ -60,6 +60,8 @@ SIGNATURES = {
     "amc3d_cross_entropy_forward": (_i, [_i, _i, _l, _vp, _vp, _ll, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_cross_entropy_backward": (_i, [_i, _i, _l, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_pointwise_conv_forward": (_i, [_i, _i, _i, _l, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_pointwise_conv_forward_workspace_bytes": (_sz, [_i, _i, _i, _l, _i]),
+    "amc3d_pointwise_conv_forward_ws": (_i, [_i, _i, _i, _l, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_pointwise_conv_workspace_bytes": (_sz, [_i, _i, _i, _l]),
     "amc3d_pointwise_conv_backward": (_i, [_i, _i, _i, _l, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_voxelize_workspace_bytes": (_sz, [_i]),

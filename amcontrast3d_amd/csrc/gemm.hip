@@ -299,19 +299,76 @@ static void gm_launch(int M, int N, long K, int batch, int splits, long kper, Ge
 bool gemm_conv_pays(int cin, int cout) { return cin >= 64 && cout >= 64; }
 
 // y (b,cout,P) = W (cout,cin) . x (b,cin,P)
-int gemm_conv_forward(int b, int cin, int cout, long P, const float *x, const float *w, float *y, hipStream_t stream)
+// ---- short layers (SetAbstraction 4, the coarse FeaturePropagation stages: a few hundred positions per cloud, 256-768
+// channels): a handful of 128 x 128 tiles per cloud, each walking the whole K axis -- 48 workgroups for 50-70 us.  The K axis
+// is split over several workgroups (the kernel's `splits`), the partial products land in the caller's workspace and are
+// summed in a fixed order: deterministic, and the chip is filled.
+static int gemm_short_splits(int b, int M, long N, long K)
+{
+    static const bool off = getenv("AMC3D_NO_SPLIT_K") != nullptr;
+    const long tiles = (long)div_up(M, GM_T) * div_up(N, GM_T) * b;
+    if (off || tiles >= 192 || K < 128) return 1;
+    long s = 512 / tiles;
+    if (s > 8) s = 8;
+    if (s > K / 64) s = K / 64;  // at least four chunks per split
+    return s < 2 ? 1 : (int)s;
+}
+
+__global__ __launch_bounds__(256) void gm_split_reduce_kernel(long total, int splits, const float *__restrict__ partial,
+                                                              float *__restrict__ out)
+{
+    // out[b][i] = sum_s partial[b * splits + s][i]; grid (chunks of total, b); total % 4 == 0 is not assumed
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x);
+    if (i >= total) return;
+    const float *p = partial + (size_t)blockIdx.y * splits * total + i;
+    float acc = p[0];
+    for (int sidx = 1; sidx < splits; ++sidx) acc += p[(size_t)sidx * total];
+    out[(size_t)blockIdx.y * total + i] = acc;
+}
+
+size_t gemm_conv_forward_workspace_bytes(int b, int cin, int cout, long P)
+{
+    const int sp = gemm_short_splits(b, cout, P, cin);
+    return sp > 1 ? (size_t)b * sp * cout * P * sizeof(float) : 0;
+}
+
+size_t gemm_conv_backward_data_workspace_bytes(int b, int cin, int cout, long P)
+{
+    const int sp = gemm_short_splits(b, cin, P, cout);
+    return sp > 1 ? (size_t)b * sp * cin * P * sizeof(float) : 0;
+}
+
+int gemm_conv_forward(int b, int cin, int cout, long P, const float *x, const float *w, float *y, float *partial,
+                      hipStream_t stream)
 {
     GemmView A{w, cin, 1}, B{x, 1, P};  // A(m=co,k=ci) k-contiguous; B(n=p,k=ci) at x[k*P + n]: n-contiguous
     const int va = cin % 4 == 0 && aligned16(w), vb = P % 4 == 0 && aligned16(x);
+    const int sp = partial ? gemm_short_splits(b, cout, P, cin) : 1;
+    if (sp > 1) {
+        const long kper = (((long)cin + sp - 1) / sp + GM_KC - 1) / GM_KC * GM_KC;
+        gm_launch<true, false>(cout, (int)P, cin, b, sp, kper, A, 0, B, (long)cin * P, partial, (long)cout * P, P, va, vb, stream);
+        const long total = (long)cout * P;
+        hipLaunchKernelGGL(gm_split_reduce_kernel, dim3(div_up(total, 256), b), dim3(256), 0, stream, total, sp, (const float *)partial, y);
+        return launch_status("gemm_conv_forward");
+    }
     gm_launch<true, false>(cout, (int)P, cin, b, 1, cin, A, 0, B, (long)cin * P, y, (long)cout * P, P, va, vb, stream);
     return launch_status("gemm_conv_forward");
 }
 
 // dx (b,cin,P) = W^T . dy (b,cout,P)
-int gemm_conv_backward_data(int b, int cin, int cout, long P, const float *dy, const float *w, float *dx, hipStream_t stream)
+int gemm_conv_backward_data(int b, int cin, int cout, long P, const float *dy, const float *w, float *dx, float *partial,
+                            hipStream_t stream)
 {
     GemmView A{w, 1, cin}, B{dy, 1, P};  // A(m=ci,k=co) = w[k*cin + m]: m-contiguous
     const int va = cin % 4 == 0 && aligned16(w), vb = P % 4 == 0 && aligned16(dy);
+    const int sp = partial ? gemm_short_splits(b, cin, P, cout) : 1;
+    if (sp > 1) {
+        const long kper = (((long)cout + sp - 1) / sp + GM_KC - 1) / GM_KC * GM_KC;
+        gm_launch<false, false>(cin, (int)P, cout, b, sp, kper, A, 0, B, (long)cout * P, partial, (long)cin * P, P, va, vb, stream);
+        const long total = (long)cin * P;
+        hipLaunchKernelGGL(gm_split_reduce_kernel, dim3(div_up(total, 256), b), dim3(256), 0, stream, total, sp, (const float *)partial, dx);
+        return launch_status("gemm_conv_backward_data");
+    }
     gm_launch<false, false>(cin, (int)P, cout, b, 1, cout, A, 0, B, (long)cout * P, dx, (long)cin * P, P, va, vb, stream);
     return launch_status("gemm_conv_backward_data");
 }
@@ -339,7 +396,7 @@ static int gemm_wgrad_splits(int b, int cin, int cout, long P, long *kper)
     // enough workgroups to fill the chip, at least 256 positions each
     const long tiles = (long)div_up(cout, GM_T) * div_up(cin, GM_T);
     long s = 1024 / (tiles * b);
-    static const long mink = getenv("AMC3D_WGRAD_MINK") ? atol(getenv("AMC3D_WGRAD_MINK")) : 256;
+    static const long mink = getenv("AMC3D_WGRAD_MINK") ? atol(getenv("AMC3D_WGRAD_MINK")) : 64;  // (short layers: 375 positions)
     const long cap = P / mink > 1 ? P / mink : 1;
     if (s > cap) s = cap;
     if (s < 1) s = 1;

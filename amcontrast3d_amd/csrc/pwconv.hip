@@ -263,8 +263,10 @@ static void launch_pw_wgrad(const PwSplit &s, int M, int K, long P, const float 
 
 // gemm.hip: the MFMA-bound variant for layers with >= 64 channels on both sides
 bool gemm_conv_pays(int cin, int cout);
-int gemm_conv_forward(int b, int cin, int cout, long P, const float *x, const float *w, float *y, hipStream_t stream);
-int gemm_conv_backward_data(int b, int cin, int cout, long P, const float *dy, const float *w, float *dx, hipStream_t stream);
+int gemm_conv_forward(int b, int cin, int cout, long P, const float *x, const float *w, float *y, float *partial, hipStream_t stream);
+size_t gemm_conv_forward_workspace_bytes(int b, int cin, int cout, long P);
+size_t gemm_conv_backward_data_workspace_bytes(int b, int cin, int cout, long P);
+int gemm_conv_backward_data(int b, int cin, int cout, long P, const float *dy, const float *w, float *dx, float *partial, hipStream_t stream);
 size_t gemm_conv_wgrad_workspace_bytes(int b, int cin, int cout, long P);
 int gemm_conv_backward_weight(int b, int cin, int cout, long P, const float *x, const float *dy, float *dw, float *partial,
                               hipStream_t stream);
@@ -280,15 +282,40 @@ AMC_API int amc3d_pointwise_conv_forward(int b, int cin, int cout, long P, const
     if (b <= 0 || P <= 0 || cout <= 0) return 0;
     if (cin <= 0 || !x || !weight || !y) return bad_arg("amc3d_pointwise_conv_forward: bad argument");
     if (!bias && gemm_conv_pays(cin, cout) && P < (1L << 31))
-        return gemm_conv_forward(b, cin, cout, P, x, weight, y, (hipStream_t)stream);
+        return gemm_conv_forward(b, cin, cout, P, x, weight, y, nullptr, (hipStream_t)stream);
     pw_gemm(b, cout, cin, P, weight, cin, 1, bias, x, y, (hipStream_t)stream);
     return launch_status("amc3d_pointwise_conv_forward");
+}
+
+// the same with scratch for the short deep layers (a few hundred positions per cloud), whose K axis is then split over
+// workgroups: amc3d_pointwise_conv_forward_workspace_bytes() bytes, 0 for every other shape
+AMC_API size_t amc3d_pointwise_conv_forward_workspace_bytes(int b, int cin, int cout, long P, int has_bias)
+{
+    if (b <= 0 || P <= 0 || cin <= 0 || cout <= 0 || has_bias || !gemm_conv_pays(cin, cout) || P >= (1L << 31)) return 0;
+    return gemm_conv_forward_workspace_bytes(b, cin, cout, P);
+}
+
+AMC_API int amc3d_pointwise_conv_forward_ws(int b, int cin, int cout, long P, const float *x, const float *weight,
+                                            const float *bias, float *y, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (b <= 0 || P <= 0 || cout <= 0) return 0;
+    if (cin <= 0 || !x || !weight || !y) return bad_arg("amc3d_pointwise_conv_forward_ws: bad argument");
+    const size_t need = amc3d_pointwise_conv_forward_workspace_bytes(b, cin, cout, P, bias != nullptr);
+    if (need && (!workspace || workspace_bytes < need)) return bad_arg("amc3d_pointwise_conv_forward_ws: workspace too small");
+    if (!bias && gemm_conv_pays(cin, cout) && P < (1L << 31))
+        return gemm_conv_forward(b, cin, cout, P, x, weight, y, need ? (float *)workspace : nullptr, (hipStream_t)stream);
+    pw_gemm(b, cout, cin, P, weight, cin, 1, bias, x, y, (hipStream_t)stream);
+    return launch_status("amc3d_pointwise_conv_forward_ws");
 }
 
 AMC_API size_t amc3d_pointwise_conv_workspace_bytes(int b, int cin, int cout, long P)
 {
     if (b <= 0 || P <= 0 || cin <= 0 || cout <= 0) return 0;
-    if (gemm_conv_pays(cin, cout) && P < (1L << 31)) return gemm_conv_wgrad_workspace_bytes(b, cin, cout, P);
+    if (gemm_conv_pays(cin, cout) && P < (1L << 31)) {  // weight-gradient partials, then (same stream) the split-K partials of dx
+        const size_t wg = gemm_conv_wgrad_workspace_bytes(b, cin, cout, P);
+        const size_t bd = cout > 128 ? gemm_conv_backward_data_workspace_bytes(b, cin, cout, P) : 0;
+        return wg > bd ? wg : bd;
+    }
     const PwSplit s = pw_split(b, cin, cout, P);
     return (size_t)s.groups * cout * cin * sizeof(float);
 }
@@ -303,7 +330,11 @@ AMC_API int amc3d_pointwise_conv_backward(int b, int cin, int cout, long P, cons
     hipStream_t stream = (hipStream_t)stream_;
     const bool deep = gemm_conv_pays(cin, cout) && P < (1L << 31);
     if (dx) {
-        if (deep && cout > 128) { if (int st = gemm_conv_backward_data(b, cin, cout, P, dy, weight, dx, stream)) return st; }
+        if (deep && cout > 128) {
+            const size_t need = gemm_conv_backward_data_workspace_bytes(b, cin, cout, P);
+            float *part = (need && workspace && workspace_bytes >= need) ? (float *)workspace : nullptr;
+            if (int st = gemm_conv_backward_data(b, cin, cout, P, dy, weight, dx, part, stream)) return st;
+        }
         else pw_gemm(b, cin, cout, P, weight, 1, cin, nullptr, dy, dx, stream);
     }
     if (dweight) {

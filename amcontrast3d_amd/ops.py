@@ -72,6 +72,20 @@ def mixed_precision():
     return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
 
 
+def _pw_forward(lib, bf16, B, Cin, Cout, P, x, w2, bias, y, what="pointwise_conv_forward"):
+    """y = w2 . x (+ bias) through the fp32 or bf16-compute kernels; the fp32 short deep layers get scratch for their
+    split-K partial products (amc3d_pointwise_conv_forward_ws)"""
+    bptr = _ptr(bias) if bias is not None else None
+    if not bf16:
+        wsf = int(lib.amc3d_pointwise_conv_forward_workspace_bytes(B, Cin, Cout, P, int(bias is not None)))
+        if wsf:
+            work = torch.empty(wsf, dtype=torch.uint8, device=x.device)
+            _lib.check(lib.amc3d_pointwise_conv_forward_ws(B, Cin, Cout, P, _ptr(x), _ptr(w2), bptr, _ptr(y), _ptr(work), wsf,
+                                                           _stream(x)), what)
+            return
+    _lib.check(_pw(lib, bf16)[0](B, Cin, Cout, P, _ptr(x), _ptr(w2), bptr, _ptr(y), _stream(x)), what)
+
+
 def _pw(lib, bf16):
     """(forward, workspace_bytes, backward) entry points of the pointwise conv in the requested arithmetic"""
     if bf16:
@@ -1009,8 +1023,7 @@ class LocalAggregationFused(Function):
 
         with torch.cuda.device(dev):
             with timing.span("pointwise_conv_forward", 4 * B * N * (Cin + C), 2.0 * B * N * Cin * C):
-                _lib.check(_pw(lib, ctx.bf16)[0](B, Cin, C, N, _ptr(f), _ptr(w_f), None, _ptr(g_cm), _stream(f)),
-                           "pointwise_conv_forward")
+                _pw_forward(lib, ctx.bf16, B, Cin, C, N, f, w_f, None, g_cm)
             # algorithmic bytes: G read (statistics) + the gathered rows, idx, dp + the pooled outputs
             with timing.span("local_aggregation_forward", 8 * B * N * C + B * M * K * (4 * C + 16) + 9 * B * M * C):
                 if group is None:
@@ -1115,8 +1128,7 @@ class GroupedConvBN(Function):
 
         with torch.cuda.device(dev):
             with timing.span("pointwise_conv_forward", 4 * B * N * (Cin + C), 2.0 * B * N * Cin * C):
-                _lib.check(_pw(lib, ctx.bf16)[0](B, Cin, C, N, _ptr(f), _ptr(w_f), None, _ptr(g_cm), _stream(f)),
-                           "pointwise_conv_forward")
+                _pw_forward(lib, ctx.bf16, B, Cin, C, N, f, w_f, None, g_cm)
             with timing.span("grouped_conv_bn_forward", 8 * B * N * C + B * M * K * (8 * C + 16)):
                 if group is None:
                     call(0)
@@ -1204,8 +1216,7 @@ def grouped_conv_bn_eval(f, dp, idx, weight, bn, relu):
     x1 = torch.empty(B, C, M, K, dtype=torch.float32, device=dev)
     invstd = torch.rsqrt(bn.running_var + bn.eps)
     with torch.cuda.device(dev):
-        _lib.check(lib.amc3d_pointwise_conv_forward(B, Cin, C, N, _ptr(f), _ptr(w_f), None, _ptr(g_cm), _stream(f)),
-                   "pointwise_conv_forward")
+        _pw_forward(lib, False, B, Cin, C, N, f, w_f, None, g_cm)
         _lib.check(lib.amc3d_grouped_conv_bn_forward(
             B, C, N, M, K, 0, int(bool(relu)), float(bn.eps), 0.0, _ptr(g_cm), _ptr(idx), _ptr(dp), _ptr(w_dp), None,
             _ptr(bn.weight), _ptr(bn.bias), _ptr(g_pm), _ptr(x1), _ptr(bn.running_mean), _ptr(invstd), None, None, None,
@@ -1235,8 +1246,7 @@ def local_aggregation_eval(f, dp, idx, weight, bn, relu):
     arg = torch.empty(B, C, M, dtype=torch.uint8, device=dev)
     invstd = torch.rsqrt(bn.running_var + bn.eps)
     with torch.cuda.device(dev):
-        _lib.check(lib.amc3d_pointwise_conv_forward(B, Cin, C, N, _ptr(f), _ptr(w_f), None, _ptr(g_cm), _stream(f)),
-                   "pointwise_conv_forward")
+        _pw_forward(lib, False, B, Cin, C, N, f, w_f, None, g_cm)
         _lib.check(lib.amc3d_local_aggregation_forward(
             B, C, N, M, K, 0, int(bool(relu)), float(bn.eps), 0.0, _ptr(g_cm), _ptr(idx), _ptr(dp), _ptr(w_dp), None,
             _ptr(bn.weight), _ptr(bn.bias), _ptr(g_pm), _ptr(pooled), _ptr(arg), _ptr(ystar), _ptr(bn.running_mean),
@@ -1259,11 +1269,10 @@ class PointwiseConv(Function):
         assert weight.numel() == Cout * Cin, "pointwise_conv needs a 1x1 kernel"
         w2 = weight.reshape(Cout, Cin).contiguous()
         y = torch.empty((B, Cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
-        fwd = _pw(_lib.load(), bf16)[0]
+        lib = _lib.load()
         with torch.cuda.device(x.device), timing.span("pointwise_conv_forward", 4 * B * P * (Cin + Cout),
                                                       2.0 * B * P * Cin * Cout):
-            _lib.check(fwd(B, Cin, Cout, P, _ptr(x), _ptr(w2), _ptr(bias.contiguous()) if bias is not None else None,
-                           _ptr(y), _stream(x)), "pointwise_conv_forward")
+            _pw_forward(lib, bf16, B, Cin, Cout, P, x, w2, bias.contiguous() if bias is not None else None, y)
         ctx.save_for_backward(x, w2)
         ctx.wshape = tuple(weight.shape)
         ctx.has_bias = bias is not None
@@ -1282,7 +1291,7 @@ class PointwiseConv(Function):
         dx = torch.empty_like(x) if need_x else None
         dw = torch.empty(Cout, Cin, dtype=torch.float32, device=dev) if need_w else None
         _, wbytes, bwd = _pw(_lib.load(), ctx.bf16)
-        wb = int(wbytes(B, Cin, Cout, P)) if need_w else 0
+        wb = int(wbytes(B, Cin, Cout, P))  # weight-gradient partials and / or the split-K partials of dx
         work = torch.empty(max(wb, 4), dtype=torch.uint8, device=dev)
         flops = 2.0 * B * P * Cin * Cout * (int(need_x) + int(need_w))
         with torch.cuda.device(dev), timing.span("pointwise_conv_backward",

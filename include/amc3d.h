@@ -249,6 +249,12 @@ int amc3d_cross_entropy_backward(int B, int C, long N, const float *logits, cons
  * y (b,cout,P), weight (cout,cin), bias (cout) or NULL; P = points (Conv1d) or points*neighbours (Conv2d). */
 int amc3d_pointwise_conv_forward(int b, int cin, int cout, long P, const float *x, const float *weight,
                                  const float *bias, float *y, void *stream);
+/* forward with scratch: the short deep layers (>= 64 channels on both sides, a few hundred positions per cloud) split their K
+ * axis over workgroups and sum the partial products in a fixed order; amc3d_pointwise_conv_forward_workspace_bytes() is 0
+ * for every other shape (the call is then amc3d_pointwise_conv_forward) */
+size_t amc3d_pointwise_conv_forward_workspace_bytes(int b, int cin, int cout, long P, int has_bias);
+int amc3d_pointwise_conv_forward_ws(int b, int cin, int cout, long P, const float *x, const float *weight,
+                                    const float *bias, float *y, void *workspace, size_t workspace_bytes, void *stream);
 size_t amc3d_pointwise_conv_workspace_bytes(int b, int cin, int cout, long P);
 /* dx (b,cin,P) = weight^T . dy (NULL to skip); dweight (cout,cin) = sum_{b,p} dy x^T (NULL to skip; needs
  * x and the workspace; summed in a fixed order -> deterministic) */

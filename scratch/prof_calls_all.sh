@@ -1,0 +1,6 @@
+#!/bin/bash
+set -e
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf /tmp/prof_calls
+timeout -k 10 500 rocprofv3 --kernel-trace -d /tmp/prof_calls -o r -- python3 bench.py --lean --steps 3 --warmup 2 --no-graph --no-overlap --fps-lanes 2 "${@:2}" > /dev/null 2> gpurun_out/prof_calls.err
+python3 scratch/kernel_calls_all.py /tmp/prof_calls/r_results.db $1
