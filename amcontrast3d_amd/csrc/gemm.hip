@@ -314,17 +314,25 @@ static int gemm_short_splits(int b, int M, long N, long K)
     return s < 2 ? 1 : (int)s;
 }
 
-__global__ __launch_bounds__(256) void gm_split_reduce_kernel(long total, int splits, const float *__restrict__ partial,
-                                                              float *__restrict__ out)
+__global__ __launch_bounds__(256) void gm_split_reduce_kernel(long total, long P, int splits, const float *__restrict__ partial,
+                                                              const float *__restrict__ bias, float *__restrict__ out)
 {
-    // out[b][i] = sum_s partial[b * splits + s][i]; grid (chunks of total, b); total % 4 == 0 is not assumed
+    // out[b][i] = sum_s partial[b * splits + s][i] (+ bias[i / P]); grid (chunks of total, b); total % 4 == 0 is not assumed
     const long i = ((long)blockIdx.x * 256 + threadIdx.x);
     if (i >= total) return;
     const float *p = partial + (size_t)blockIdx.y * splits * total + i;
     float acc = p[0];
     for (int sidx = 1; sidx < splits; ++sidx) acc += p[(size_t)sidx * total];
-    out[(size_t)blockIdx.y * total + i] = acc;
+    out[(size_t)blockIdx.y * total + i] = bias ? acc + bias[i / P] : acc;
 }
+
+__global__ __launch_bounds__(256) void gm_bias_kernel(long total, long P, const float *__restrict__ bias, float *__restrict__ y)
+{
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x);
+    if (i < total) y[(size_t)blockIdx.y * total + i] += bias[i / P];
+}
+
+bool gemm_conv_short(int b, int rows, long P) { return (long)div_up(rows, GM_T) * div_up(P, GM_T) * b < 192; }
 
 size_t gemm_conv_forward_workspace_bytes(int b, int cin, int cout, long P)
 {
@@ -338,8 +346,8 @@ size_t gemm_conv_backward_data_workspace_bytes(int b, int cin, int cout, long P)
     return sp > 1 ? (size_t)b * sp * cin * P * sizeof(float) : 0;
 }
 
-int gemm_conv_forward(int b, int cin, int cout, long P, const float *x, const float *w, float *y, float *partial,
-                      hipStream_t stream)
+int gemm_conv_forward(int b, int cin, int cout, long P, const float *x, const float *w, const float *bias, float *y,
+                      float *partial, hipStream_t stream)
 {
     GemmView A{w, cin, 1}, B{x, 1, P};  // A(m=co,k=ci) k-contiguous; B(n=p,k=ci) at x[k*P + n]: n-contiguous
     const int va = cin % 4 == 0 && aligned16(w), vb = P % 4 == 0 && aligned16(x);
@@ -348,10 +356,15 @@ int gemm_conv_forward(int b, int cin, int cout, long P, const float *x, const fl
         const long kper = (((long)cin + sp - 1) / sp + GM_KC - 1) / GM_KC * GM_KC;
         gm_launch<true, false>(cout, (int)P, cin, b, sp, kper, A, 0, B, (long)cin * P, partial, (long)cout * P, P, va, vb, stream);
         const long total = (long)cout * P;
-        hipLaunchKernelGGL(gm_split_reduce_kernel, dim3(div_up(total, 256), b), dim3(256), 0, stream, total, sp, (const float *)partial, y);
+        hipLaunchKernelGGL(gm_split_reduce_kernel, dim3(div_up(total, 256), b), dim3(256), 0, stream, total, P, sp,
+                           (const float *)partial, bias, y);
         return launch_status("gemm_conv_forward");
     }
     gm_launch<true, false>(cout, (int)P, cin, b, 1, cin, A, 0, B, (long)cin * P, y, (long)cout * P, P, va, vb, stream);
+    if (bias) {
+        const long total = (long)cout * P;
+        hipLaunchKernelGGL(gm_bias_kernel, dim3(div_up(total, 256), b), dim3(256), 0, stream, total, P, bias, y);
+    }
     return launch_status("gemm_conv_forward");
 }
 
@@ -366,7 +379,8 @@ int gemm_conv_backward_data(int b, int cin, int cout, long P, const float *dy, c
         const long kper = (((long)cout + sp - 1) / sp + GM_KC - 1) / GM_KC * GM_KC;
         gm_launch<false, false>(cin, (int)P, cout, b, sp, kper, A, 0, B, (long)cout * P, partial, (long)cin * P, P, va, vb, stream);
         const long total = (long)cin * P;
-        hipLaunchKernelGGL(gm_split_reduce_kernel, dim3(div_up(total, 256), b), dim3(256), 0, stream, total, sp, (const float *)partial, dx);
+        hipLaunchKernelGGL(gm_split_reduce_kernel, dim3(div_up(total, 256), b), dim3(256), 0, stream, total, P, sp,
+                           (const float *)partial, (const float *)nullptr, dx);
         return launch_status("gemm_conv_backward_data");
     }
     gm_launch<false, false>(cin, (int)P, cout, b, 1, cout, A, 0, B, (long)cout * P, dx, (long)cin * P, P, va, vb, stream);

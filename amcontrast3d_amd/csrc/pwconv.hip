@@ -263,7 +263,16 @@ static void launch_pw_wgrad(const PwSplit &s, int M, int K, long P, const float 
 
 // gemm.hip: the MFMA-bound variant for layers with >= 64 channels on both sides
 bool gemm_conv_pays(int cin, int cout);
-int gemm_conv_forward(int b, int cin, int cout, long P, const float *x, const float *w, float *y, float *partial, hipStream_t stream);
+int gemm_conv_forward(int b, int cin, int cout, long P, const float *x, const float *w, const float *bias, float *y, float *partial,
+                      hipStream_t stream);
+bool gemm_conv_short(int b, int rows, long P);
+// the 128 x 128-tile GEMM (gemm.hip) instead of the streaming kernel above: deep layers without a bias, and -- with or without
+// one -- deep layers so short that the streaming kernel's one-workgroup-per-tile walk of the whole K axis leaves the chip empty
+static bool pw_forward_deep(int b, int cin, int cout, long P, bool has_bias)
+{
+    if (!gemm_conv_pays(cin, cout) || P >= (1L << 31)) return false;
+    return !has_bias || gemm_conv_short(b, cout, P);
+}
 size_t gemm_conv_forward_workspace_bytes(int b, int cin, int cout, long P);
 size_t gemm_conv_backward_data_workspace_bytes(int b, int cin, int cout, long P);
 int gemm_conv_backward_data(int b, int cin, int cout, long P, const float *dy, const float *w, float *dx, float *partial, hipStream_t stream);
@@ -281,8 +290,8 @@ AMC_API int amc3d_pointwise_conv_forward(int b, int cin, int cout, long P, const
 {
     if (b <= 0 || P <= 0 || cout <= 0) return 0;
     if (cin <= 0 || !x || !weight || !y) return bad_arg("amc3d_pointwise_conv_forward: bad argument");
-    if (!bias && gemm_conv_pays(cin, cout) && P < (1L << 31))
-        return gemm_conv_forward(b, cin, cout, P, x, weight, y, nullptr, (hipStream_t)stream);
+    if (pw_forward_deep(b, cin, cout, P, bias != nullptr))
+        return gemm_conv_forward(b, cin, cout, P, x, weight, bias, y, nullptr, (hipStream_t)stream);
     pw_gemm(b, cout, cin, P, weight, cin, 1, bias, x, y, (hipStream_t)stream);
     return launch_status("amc3d_pointwise_conv_forward");
 }
@@ -291,7 +300,7 @@ AMC_API int amc3d_pointwise_conv_forward(int b, int cin, int cout, long P, const
 // workgroups: amc3d_pointwise_conv_forward_workspace_bytes() bytes, 0 for every other shape
 AMC_API size_t amc3d_pointwise_conv_forward_workspace_bytes(int b, int cin, int cout, long P, int has_bias)
 {
-    if (b <= 0 || P <= 0 || cin <= 0 || cout <= 0 || has_bias || !gemm_conv_pays(cin, cout) || P >= (1L << 31)) return 0;
+    if (b <= 0 || P <= 0 || cin <= 0 || cout <= 0 || !pw_forward_deep(b, cin, cout, P, has_bias != 0)) return 0;
     return gemm_conv_forward_workspace_bytes(b, cin, cout, P);
 }
 
@@ -302,8 +311,8 @@ AMC_API int amc3d_pointwise_conv_forward_ws(int b, int cin, int cout, long P, co
     if (cin <= 0 || !x || !weight || !y) return bad_arg("amc3d_pointwise_conv_forward_ws: bad argument");
     const size_t need = amc3d_pointwise_conv_forward_workspace_bytes(b, cin, cout, P, bias != nullptr);
     if (need && (!workspace || workspace_bytes < need)) return bad_arg("amc3d_pointwise_conv_forward_ws: workspace too small");
-    if (!bias && gemm_conv_pays(cin, cout) && P < (1L << 31))
-        return gemm_conv_forward(b, cin, cout, P, x, weight, y, need ? (float *)workspace : nullptr, (hipStream_t)stream);
+    if (pw_forward_deep(b, cin, cout, P, bias != nullptr))
+        return gemm_conv_forward(b, cin, cout, P, x, weight, bias, y, need ? (float *)workspace : nullptr, (hipStream_t)stream);
     pw_gemm(b, cout, cin, P, weight, cin, 1, bias, x, y, (hipStream_t)stream);
     return launch_status("amc3d_pointwise_conv_forward_ws");
 }
@@ -313,7 +322,7 @@ AMC_API size_t amc3d_pointwise_conv_workspace_bytes(int b, int cin, int cout, lo
     if (b <= 0 || P <= 0 || cin <= 0 || cout <= 0) return 0;
     if (gemm_conv_pays(cin, cout) && P < (1L << 31)) {  // weight-gradient partials, then (same stream) the split-K partials of dx
         const size_t wg = gemm_conv_wgrad_workspace_bytes(b, cin, cout, P);
-        const size_t bd = cout > 128 ? gemm_conv_backward_data_workspace_bytes(b, cin, cout, P) : 0;
+        const size_t bd = (cout > 128 || gemm_conv_short(b, cin, P)) ? gemm_conv_backward_data_workspace_bytes(b, cin, cout, P) : 0;
         return wg > bd ? wg : bd;
     }
     const PwSplit s = pw_split(b, cin, cout, P);
@@ -330,7 +339,7 @@ AMC_API int amc3d_pointwise_conv_backward(int b, int cin, int cout, long P, cons
     hipStream_t stream = (hipStream_t)stream_;
     const bool deep = gemm_conv_pays(cin, cout) && P < (1L << 31);
     if (dx) {
-        if (deep && cout > 128) {
+        if (deep && (cout > 128 || gemm_conv_short(b, cin, P))) {
             const size_t need = gemm_conv_backward_data_workspace_bytes(b, cin, cout, P);
             float *part = (need && workspace && workspace_bytes >= need) ? (float *)workspace : nullptr;
             if (int st = gemm_conv_backward_data(b, cin, cout, P, dy, weight, dx, part, stream)) return st;

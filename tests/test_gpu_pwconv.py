@@ -24,6 +24,11 @@ SHAPES = [  # B, Cin, Cout, spatial, bias
     (3, 256, 512, (23, 32), False),   # SA4: short position ranges
     (2, 96, 200, (1000,), False),     # ragged channel counts
     (2, 64, 64, (4000,), False),
+    # short deep layers: K split over workgroups, bias added by the reduction
+    (8, 256, 512, (94,), True),       # SA4 skip conv
+    (8, 128, 256, (375,), True),
+    (2, 768, 256, (96,), False),
+    (2, 256, 96, (200,), False),      # cout <= 128 but short: backward-data on the tiled GEMM as well
 ]
 
 
