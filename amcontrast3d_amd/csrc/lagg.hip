@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void lagg_bwd_scatter_kernel(int C, int n, int
                                                                const float *__restrict__ dp, const float *__restrict__ mean,
                                                                const float *__restrict__ invstd, const float *__restrict__ gamma,
                                                                const float *__restrict__ beta, float *__restrict__ Q,
-                                                               double *__restrict__ partial, int nparts_per_b)
+                                                               double *__restrict__ partial, int nparts_per_b, int tiles_per_wg)
 {
     extern __shared__ float lagg_smem[];
     const int ct = min(LAGG_CT, C - (int)blockIdx.y * LAGG_CT);
@@ -333,8 +333,8 @@ __global__ __launch_bounds__(256) void lagg_bwd_scatter_kernel(int C, int n, int
         const int cl = lane + 64 * h, c = cl < ct ? c0 + cl : c0;
         mu[h] = mean[c]; is[h] = invstd[c]; ga[h] = gamma[c]; be[h] = beta[c];
     }
-    for (int tt = 0; tt < LAGG_TILES; ++tt) {
-        const int m0 = (blockIdx.x * LAGG_TILES + tt) * LAGG_MT;
+    for (int tt = 0; tt < tiles_per_wg; ++tt) {
+        const int m0 = (blockIdx.x * tiles_per_wg + tt) * LAGG_MT;
         if (m0 >= M) break;
         __syncthreads();
         for (int t = threadIdx.x; t < ct * LAGG_MT; t += 256) {
@@ -668,9 +668,19 @@ static int lagg_stats_tiles(int b, int C, int n)
     return wgs1 <= 8192 ? 1 : LAGG_TILES;
 }
 
+// ... and of the backward scatter kernel (its workgroups walk their centroids serially: a few dozen of them took 50-100 us
+// on the coarse stages of PointNeXt-L)
+static int lagg_scatter_tiles(int b, int C, int M)
+{
+    static const bool off = getenv("AMC3D_LAGG_SCATTER_TILES4") != nullptr;
+    const long wgs1 = (long)b * div_up(M, LAGG_MT) * div_up(C, LAGG_CT);
+    return (wgs1 <= 8192 && !off) ? 1 : LAGG_TILES;
+}
+
 static size_t lagg_partial_bytes(int b, int C, int n, int M)
 {
-    const size_t pf = (size_t)b * div_up(div_up(n, LAGG_NT), lagg_stats_tiles(b, C, n)), pb = (size_t)b * div_up(div_up(M, LAGG_MT), LAGG_TILES);
+    const size_t pf = (size_t)b * div_up(div_up(n, LAGG_NT), lagg_stats_tiles(b, C, n)),
+                 pb = (size_t)b * div_up(div_up(M, LAGG_MT), lagg_scatter_tiles(b, C, M));
     const size_t pc = (size_t)b * div_up((long)M * 32, LAGG_PT);  // collapse kernel (K = 32), at most one partial per tile
     size_t m = pf > pb ? pf : pb;
     if (pc > m) m = pc;
@@ -790,14 +800,15 @@ AMC_API int amc3d_local_aggregation_backward(int b, int cout, int n, int npoints
     float *Q = (float *)((char *)workspace + lagg_partial_bytes(b, cout, n, npoints));
     float *coef = Q + (size_t)b * n * cout;
     const int ct = cout < LAGG_CT ? cout : LAGG_CT;
-    const int nparts_b = div_up(div_up(npoints, LAGG_MT), LAGG_TILES);
+    const int stiles = lagg_scatter_tiles(b, cout, npoints);
+    const int nparts_b = div_up(div_up(npoints, LAGG_MT), stiles);
     if (phase != 2) {
         if (int st = fill_i32((int *)Q, 0, (size_t)b * n * cout, stream)) return st;
         size_t lds = (size_t)3 * ct * (LAGG_MT + 1) * sizeof(float);
         const size_t red = (size_t)4 * ct * 5 * sizeof(double);
         if (lds < red) lds = red;
         hipLaunchKernelGGL(lagg_bwd_scatter_kernel, dim3(nparts_b, cout / ct, b), dim3(256), lds, stream, cout, n, npoints, nsample,
-                           relu, dpooled, ystar, arg, idx, dp, mean, invstd, gamma, beta, Q, partial, nparts_b);
+                           relu, dpooled, ystar, arg, idx, dp, mean, invstd, gamma, beta, Q, partial, nparts_b, stiles);
     }
     hipLaunchKernelGGL(lagg_bwd_finalize_kernel, dim3(cout), dim3(256), 0, stream, cout, nparts_b * b,
                        (double)b * (double)npoints * (double)nsample, partial, gm.mom, gd, w_dp, mean, invstd,
