@@ -286,8 +286,19 @@ __global__ __launch_bounds__(1024) void gcc_reduce_partials_kernel(int total, in
     const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + e;
     float s = 0.f;
-    if (i < total)
-        for (int k = sl; k < nparts; k += 16) s += partial[(size_t)k * total + i];
+    if (i < total) {
+        // four loads in flight per thread (a fixed order all the same: four interleaved sub-sums, added in order)
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = sl;
+        for (; k + 48 < nparts; k += 64) {
+            s0 += partial[(size_t)k * total + i];
+            s1 += partial[(size_t)(k + 16) * total + i];
+            s2 += partial[(size_t)(k + 32) * total + i];
+            s3 += partial[(size_t)(k + 48) * total + i];
+        }
+        for (; k < nparts; k += 16) s0 += partial[(size_t)k * total + i];
+        s = (s0 + s1) + (s2 + s3);
+    }
     red[sl][e] = s;
     __syncthreads();
     if (sl == 0 && i < total) {

@@ -327,20 +327,23 @@ __global__ __launch_bounds__(256) void sat_finalize_kernel(int C2, int nparts, d
     for (int s = 32; s >= 1; s >>= 1) { s1 += __shfl_xor(s1, s, 64); s2 += __shfl_xor(s2, s, 64); }
     if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = s1; s_b[threadIdx.x >> 6] = s2; }
     __syncthreads();
+    // gridDim.y slices of the pooled output share a channel: every slice reduces the partials (same order, same values),
+    // slice 0 publishes the statistics
+    const bool first = blockIdx.y == 0;
     if (threadIdx.x == 0) {
         s1 = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
         s2 = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
         if (backward) {  // o0 = dbeta = sum dq, o1 = dgamma = sum dq xhat, o2 / o3 = their means
-            o0[c] = (float)s1; o1[c] = (float)s2; o2[c] = (float)(s1 / count); o3[c] = (float)(s2 / count);
+            if (first) { o0[c] = (float)s1; o1[c] = (float)s2; o2[c] = (float)(s1 / count); o3[c] = (float)(s2 / count); }
         } else {
             const double mu = s1 / count;
             double var = s2 / count - mu * mu;
             if (var < 0.0) var = 0.0;
             const float mf = (float)mu, vu = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
             const float isf = (float)(1.0 / sqrt(var + (double)eps));
-            o0[c] = mf; o1[c] = isf; o2[c] = vu;
+            if (first) { o0[c] = mf; o1[c] = isf; o2[c] = vu; }
             s_stat[0] = mf; s_stat[1] = isf;
-            if (running_mean && momentum >= 0.f) {
+            if (first && running_mean && momentum >= 0.f) {
                 running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * mf;
                 running_var[c] = running_var[c] * (1.f - momentum) + momentum * vu;
                 if (c == 0 && tracked) *tracked += 1;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256) void sat_finalize_kernel(int C2, int nparts, d
     // the max-pool of the normalised values, from the raw extrema (monotonicity: see the file header)
     const float mf = s_stat[0], isf = s_stat[1], g = gamma2[c], bt = beta2[c];
     const float *src = g >= 0.f ? rmax : rmin;
-    for (int i = threadIdx.x; i < B * M; i += 256) {
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < B * M; i += 256 * gridDim.y) {
         const int bb = i / M, m = i - bb * M;
         const size_t q = ((size_t)bb * C2 + c) * M + m;
         float y = sat_bn(src[q], mf, isf, g, bt);
@@ -434,7 +437,7 @@ AMC_API int amc3d_sa_tail_forward(int B, int C1, int C2, int M, int K, const flo
     a.rmax = (float *)((char *)workspace + (size_t)groups * B * C2 * 2 * sizeof(double));
     a.rmin = a.rmax + (size_t)B * C2 * M;
     sat_launch<0>(a, groups, stream);
-    hipLaunchKernelGGL(sat_finalize_kernel, dim3(C2), dim3(256), 0, stream, C2, groups * B,
+    hipLaunchKernelGGL(sat_finalize_kernel, dim3(C2, (unsigned)((long)B * M >= 16384 ? 8 : 1)), dim3(256), 0, stream, C2, groups * B,
                        (double)B * (double)M * 32.0, eps2, momentum2, 0, (const double *)workspace, mean2, invstd2,
                        var_unbiased2, (float *)nullptr, running_mean2, running_var2, tracked2, B, M, relu2, gamma2, beta2,
                        (const float *)a.rmax, (const float *)a.rmin, pooled);
