@@ -396,11 +396,12 @@ static bool gw_streaming(int b, int cin, int cout, long P)
 static int gemm_wgrad_splits(int b, int cin, int cout, long P, long *kper)
 {
     if (gw_streaming(b, cin, cout, P)) {
-        // ~512 workgroups (two per CU), at least 8 chunks each; a range is a whole number of chunks
+        // ~512 workgroups (two per CU), at least `minc` chunks each; a range is a whole number of chunks
+        static const long minc = getenv("AMC3D_GW_MINCHUNKS") ? atol(getenv("AMC3D_GW_MINCHUNKS")) : 4;
         const int tn = cin <= 64 ? 64 : 128;
         const long tiles = (long)div_up(cout, GW_TM) * div_up(cin, tn);
         long s = 512 / (tiles * b);
-        const long cap = P / (8 * GW_KC) > 1 ? P / (8 * GW_KC) : 1;
+        const long cap = P / (minc * GW_KC) > 1 ? P / (minc * GW_KC) : 1;
         if (s > cap) s = cap;
         if (s < 1) s = 1;
         const long per = ((P + s - 1) / s + GW_KC - 1) / GW_KC * GW_KC;
