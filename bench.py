@@ -391,7 +391,10 @@ def main():
     # latency chain, more clouds cost nothing) instead of one launch per step: the sampling queue then delivers a batch
     # every t_fps / 2.  With one launch per step on one queue the step cannot be shorter than t_fps (8.1-8.3 ms alone),
     # which the feature half has reached; a queue per lane costs a fourth hardware queue (slower, measured below).
-    joint = overlap and lanes == 2 and not os.environ.get("AMC3D_NO_FPS_JOINT")
+    # More than two lanes (64k / 120k-point clouds, whose first level takes several feature halves): the same with J = lanes
+    # batches per launch, one launch every J steps -- XL-MM at 2 x 64000 points: 55 ms/step with a queue per lane, 40 ms so.
+    joint = overlap and lanes >= 2 and not os.environ.get("AMC3D_NO_FPS_JOINT")
+    nfps = 2 if joint else lanes  # distinct first-level launches (joint: the two J-batch buffers)
     a2_rides = joint and os.environ.get("AMC3D_A2_ON_FPS", "1") != "0"  # FPS levels 2-4 on the sampling queue (see below)
     # Hardware queues.  Ordinary HIP streams of a process share GPU_MAX_HW_QUEUES (default 4) queues round-robin, and
     # whatever shares a queue with a running FPS kernel (8 ms on 8 workgroups) waits for it; which stream that is
@@ -401,7 +404,7 @@ def main():
     #   Q_geo : FPS levels 2-4, then the neighbourhood / loss geometry of the same batch
     from amcontrast3d_amd import ops as _ops
     # others, for scratch/queue_sweep.sh: "pooled", "fps,a2,b", ...; more than two lanes: a queue per lane (they must overlap)
-    qplan = os.environ.get("AMC3D_QUEUES", "fps,geo" if lanes <= 2 else ",".join([f"fps{l}" for l in range(lanes)] + ["geo"]))
+    qplan = os.environ.get("AMC3D_QUEUES", "fps,geo" if (lanes <= 2 or joint) else ",".join([f"fps{l}" for l in range(lanes)] + ["geo"]))
     if (not use_graph and "AMC3D_QUEUES" not in os.environ) or qplan == "probed":
         # launched kernel by kernel, dedicated queues lose the overlap (pipeline.py): two pooled streams probed to sit
         # on hardware queues of their own, as the eager GeometryPrefetcher uses them
@@ -473,14 +476,14 @@ def main():
         in_a = [{k: v.clone() for k, v in pool[(3 + l) % npool].items()} for l in range(lanes)]
         a1_out = [geo_fps_first(in_a[l]) for l in range(lanes)]  # written by streams A1[lane]: first FPS level
         if joint:
-            # two double-batch buffers J[0], J[1], launched alternately at even steps; lane l of a launch is consumed 2 + l
-            # steps later, through per-lane views of the joint input / output tensors
+            # two J-batch buffers (J = lanes), launched alternately every J steps; lane l of a launch is consumed J + l steps
+            # later, through per-lane views of the joint input / output tensors
             nbat = args.batch
-            in_aJ = [{k: torch.cat([pool[(3 + 2 * j) % npool][k], pool[(4 + 2 * j) % npool][k]]) for k in pool[0]}
+            in_aJ = [{k: torch.cat([pool[(3 + lanes * j + t) % npool][k] for t in range(lanes)]) for k in pool[0]}
                      for j in range(2)]
             a1_outJ = [geo_fps_first(in_aJ[j]) for j in range(2)]
-            in_a = [[{k: v[l * nbat:(l + 1) * nbat] for k, v in in_aJ[j].items()} for l in range(2)] for j in range(2)]
-            a1_out = [[geometry._walk(a1_outJ[j], lambda t, l=l: t[l * nbat:(l + 1) * nbat]) for l in range(2)]
+            in_a = [[{k: v[l * nbat:(l + 1) * nbat] for k, v in in_aJ[j].items()} for l in range(lanes)] for j in range(2)]
+            a1_out = [[geometry._walk(a1_outJ[j], lambda t, l=l: t[l * nbat:(l + 1) * nbat]) for l in range(lanes)]
                       for j in range(2)]
         a1_stable = geometry.clone(geo_fps_first(in_a1s))  # batch t+2: read by stream A2
         a2_out = geo_fps_tail(a1_stable)       # written by stream A2 (batch t+2): FPS levels 2..4
@@ -614,7 +617,7 @@ def main():
         if flatg is None:
             opt.zero_grad(set_to_none=True)
         run_step([lambda j=j: rotate(j) for j in range(period)], [lambda j=j: rotate_side(j) for j in range(period)],
-                 [lambda l=l: body_a(l) for l in range(lanes)], body_a2,
+                 [lambda l=l: body_a(l) for l in range(nfps)], body_a2,
                  body_b, fwd_bwd, update)
 
     step = eager_step
@@ -627,7 +630,7 @@ def main():
         if flatg is None:
             opt.zero_grad(set_to_none=True)
         names = (["a2", "b", "feat", "update"] + [f"rotate{j}" for j in range(period)] + [f"side{j}" for j in range(period)]
-                 + [f"fps{l}" for l in range(lanes)])
+                 + [f"fps{l}" for l in range(nfps)])
         graphs = {k: torch.cuda.CUDAGraph() for k in names}
         cap = main_s if not os.environ.get("AMC3D_CAPTURE_SIDE") else torch.cuda.Stream()
         # with a process group alive, RCCL's watchdog thread polls events while we capture: only this thread's calls
@@ -704,7 +707,7 @@ def main():
                 with torch.cuda.graph(graphs[f"side{j}"], stream=s_b, capture_error_mode=cap_mode):
                     rotate_side(j)
         if overlap:
-            for l in range(lanes):
+            for l in range(nfps):
                 with torch.cuda.graph(graphs[f"fps{l}"], stream=s_a[l], capture_error_mode=cap_mode):
                     body_a(l)
             with torch.cuda.graph(graphs["a2"], stream=s_a2, capture_error_mode=cap_mode):
@@ -729,7 +732,7 @@ def main():
 
         def step():
             run_step([rot_replay(j) for j in range(period)], [graphs[f"side{j}"].replay for j in range(period)],
-                     [graphs[f"fps{l}"].replay for l in range(lanes)],
+                     [graphs[f"fps{l}"].replay for l in range(nfps)],
                      graphs["a2"].replay, [graphs["b"].replay, graphs["b1"].replay] if pingpong else graphs["b"].replay,
                      [graphs["feat"].replay, graphs["feat1"].replay] if pingpong else graphs["feat"].replay,
                      graphs["update"].replay)
@@ -786,7 +789,7 @@ def main():
             h0 = time.perf_counter()
             run_step([timed(rot_replay(j), main_s, "rotate", log) for j in range(period)],
                      [timed(graphs[f"side{j}"].replay, s_b, "side", log) for j in range(period)],
-                     [timed(graphs[f"fps{l}"].replay, s_a[l], f"fps{l}", log) for l in range(lanes)],
+                     [timed(graphs[f"fps{l}"].replay, s_a[l], f"fps{l}", log) for l in range(nfps)],
                      timed(graphs["a2"].replay, s_a2, "a2", log),
                      # ping-pong: the variants in the order run_step picks them (a feature variant must never run beside
                      # the B variant that writes the result set it reads)
@@ -835,8 +838,8 @@ def main():
                     t = time.perf_counter()
                 for tag, fn, st in (("rotate", rot_replay(r % period), main_s),
                                     ("rotate_side", graphs[f"side{r % period}"].replay, s_b),
-                                    ("fps1", graphs[f"fps{(r // 2 if joint else r) % lanes}"].replay if not (joint and r % 2)
-                                     else (lambda: None), s_a[r % lanes]),
+                                    ("fps1", graphs[f"fps{(r // lanes) % 2 if joint else r % lanes}"].replay
+                                     if not (joint and r % lanes) else (lambda: None), s_a[r % lanes]),
                                     ("fps2to4", graphs["a2"].replay, s_a2), ("geometry", graphs["b"].replay, s_b),
                                     ("features", graphs["feat"].replay, main_s)):
                     h = time.perf_counter()

@@ -348,7 +348,8 @@ def test_reference_overlay_and_native_module_registration():
     sys.modules.pop("pointnet2_batch_cuda"); sys.modules.pop("pointops_cuda")
 
 
-@pytest.mark.parametrize("lanes,joint,npool", [(2, True, 4), (2, False, 4), (2, True, 3), (3, False, 4), (2, True, 5), (1, False, 4)])
+@pytest.mark.parametrize("lanes,joint,npool", [(2, True, 4), (2, False, 4), (2, True, 3), (3, False, 4), (2, True, 5), (1, False, 4),
+                                               (3, True, 4), (4, True, 4), (4, True, 6)])
 def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, joint, npool):
     """bench.py's pipelined loop replayed with batch ids instead of tensors (amcontrast3d_amd/schedule.py holds its index
     arithmetic): at every step the feature half must see ONE batch -- its points, its four FPS levels and its neighbourhood /
@@ -357,16 +358,16 @@ def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, joint
     from amcontrast3d_amd import schedule
     pingpong = True
     period = schedule.period(lanes, npool, pingpong, joint)
-    assert period % lanes == 0 and period % npool == 0 and period % 2 == 0 and (not joint or period % 4 == 0)
+    assert period % lanes == 0 and period % npool == 0 and period % 2 == 0 and (not joint or period % (2 * lanes) == 0)
     fps1 = lambda b: ("fps1", b)            # noqa: E731  first FPS level of batch b
     fps2 = lambda f: ("fps2", f[1])         # noqa: E731  levels 2-4, from the first level
     geo = lambda b, f: ("geo", b, f)        # noqa: E731  neighbourhoods of batch b computed with the sampling f
     # bench.py's initial buffers
     in_b, in_a1s = 1 % npool, 2 % npool
     if joint:
-        in_a = [[(3 + 2 * j) % npool, (4 + 2 * j) % npool] for j in range(2)]
+        in_a = [[(3 + lanes * j + t) % npool for t in range(lanes)] for j in range(2)]
         a1_out = [[fps1(b) for b in row] for row in in_a]
-        launched = [[-10, -10], [-10, -10]]
+        launched = [[-10] * lanes, [-10] * lanes]
     else:
         in_a = [(3 + l) % npool for l in range(lanes)]
         a1_out = [fps1(b) for b in in_a]
@@ -400,7 +401,7 @@ def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, joint
         # rotate_side (geometry queue)
         plan = schedule.side_step(s, lanes, joint, npool)
         sets[fills] = {"batch": in_a1s, "fps": (a1_stable, a2_out)}
-        assert n - at(launched, plan["consume"]) >= (2 if joint else lanes), "first-level FPS consumed before it can have finished"
+        assert n - at(launched, plan["consume"]) >= lanes, "first-level FPS consumed before it can have finished"
         a1_stable, in_a1s = at(a1_out, plan["consume"]), at(in_a, plan["consume"])
         assert a1_stable == fps1(in_a1s), "an input buffer was overwritten between its FPS launch and its consumption"
         for buf, pi in plan["load"]:
@@ -410,7 +411,7 @@ def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, joint
             if joint:
                 j = plan["launch"]
                 a1_out[j] = [fps1(b) for b in in_a[j]]
-                launched[j] = [n, n]
+                launched[j] = [n] * lanes
             else:
                 a1_out[plan["launch"]] = fps1(in_a[plan["launch"]])
                 launched[plan["launch"]] = n
@@ -421,7 +422,7 @@ def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, joint
         assert cur["fps"] == (fps1(cur["batch"]), fps2(fps1(cur["batch"]))), (n, cur)
         assert cur["geo"] == geo(cur["batch"], cur["fps"]), (n, cur)
         seen.append(cur["batch"])
-    seen = seen[8:]                          # the initial contents of the buffers drain first
+    seen = seen[4 * lanes + 4:]              # the initial contents of the buffers drain first
     assert all(seen[i + 1] == (seen[i] + 1) % npool for i in range(len(seen) - 1)), seen
 
 
