@@ -385,7 +385,15 @@ def main():
         # two lanes on ONE queue deliver a sampling every t_fps: enough while t_fps stays below the step time (~1.25 x the
         # eager feature half).  The margin is wide on purpose: a third lane means a fourth dedicated queue, and with more
         # hardware queues than the 4 the runtime schedules natively the S step takes 17 ms instead of 8.7 (measured).
-        lanes = 2 if t_fps <= 1.5 * t_feat else int(min(6, max(2, -(-t_fps // max(0.6 * t_feat, 1e-3)))))
+        if t_fps <= 1.5 * t_feat:
+            lanes = 2
+        else:
+            # long sampling chains (64k / 120k-point clouds): the joint launch runs every level of J batches once per J steps
+            # and has to fit into J steps next to a busy chip (the L2-resident kernel slows down there): all levels timed,
+            # half an eager feature half allowed per batch, at most 8 batches per launch
+            nlev = len(list((model.module if hasattr(model, "module") else model).encoder.encoder))
+            t_all = _ms(lambda: geometry.precompute_fps_levels(model, data["pos"], 0, nlev), 1)
+            lanes = int(min(8, max(3, -(-t_all // max(0.5 * t_feat, 1e-3)))))
     lanes = max(1, lanes)
     # First-level FPS of TWO future batches as one launch every second step (16 workgroups instead of 8: the kernel is a
     # latency chain, more clouds cost nothing) instead of one launch per step: the sampling queue then delivers a batch
@@ -395,7 +403,11 @@ def main():
     # batches per launch, one launch every J steps -- XL-MM at 2 x 64000 points: 55 ms/step with a queue per lane, 40 ms so.
     joint = overlap and lanes >= 2 and not os.environ.get("AMC3D_NO_FPS_JOINT")
     nfps = 2 if joint else lanes  # distinct first-level launches (joint: the two J-batch buffers)
-    a2_rides = joint and os.environ.get("AMC3D_A2_ON_FPS", "1") != "0"  # FPS levels 2-4 on the sampling queue (see below)
+    # More than two lanes = clouds whose FPS levels 2-4 are long chains as well (120000 points: level 2 alone is 22 ms, longer
+    # than the feature half): the joint launch then runs ALL sampling levels of its J batches, and the separate levels-2-4
+    # stage of the pipeline disappears (its results went through one more set of buffers and one more step of latency).
+    fps_all = joint and lanes > 2 and not os.environ.get("AMC3D_NO_FPS_ALL")
+    a2_rides = joint and lanes == 2 and os.environ.get("AMC3D_A2_ON_FPS", "1") != "0"  # FPS levels 2-4 on the sampling queue (see below)
     # Hardware queues.  Ordinary HIP streams of a process share GPU_MAX_HW_QUEUES (default 4) queues round-robin, and
     # whatever shares a queue with a running FPS kernel (8 ms on 8 workgroups) waits for it; which stream that is
     # changes with every stream anybody creates (graph-internal branches, RCCL).  So the two long-latency chains get
@@ -445,6 +457,9 @@ def main():
     def geo_fps_first(batch):  # encoder stage 0 is the stride-1 stem (no sampling); stage 1 holds the first FPS
         return geometry.precompute_fps_levels(model, batch["pos"], 0, 2)
 
+    def geo_fps_all(batch):
+        return geometry.precompute_fps_levels(model, batch["pos"], 0, nlevels)
+
     def geo_fps_tail(first_level):
         return geometry.precompute_fps_levels(model, first_level[-1]["new_p"], 2, nlevels)
 
@@ -481,7 +496,7 @@ def main():
             nbat = args.batch
             in_aJ = [{k: torch.cat([pool[(3 + lanes * j + t) % npool][k] for t in range(lanes)]) for k in pool[0]}
                      for j in range(2)]
-            a1_outJ = [geo_fps_first(in_aJ[j]) for j in range(2)]
+            a1_outJ = [(geo_fps_all if fps_all else geo_fps_first)(in_aJ[j]) for j in range(2)]
             in_a = [[{k: v[l * nbat:(l + 1) * nbat] for k, v in in_aJ[j].items()} for l in range(lanes)] for j in range(2)]
             a1_out = [[geometry._walk(a1_outJ[j], lambda t, l=l: t[l * nbat:(l + 1) * nbat]) for l in range(lanes)]
                       for j in range(2)]
@@ -520,16 +535,20 @@ def main():
         plan = schedule.side_step(s, lanes, joint, npool)
         # stream B's inputs for the batch after this one (ping-pong: the set the NEXT step's feature variant reads as well)
         tb, ta = handover["inputs"][schedule.variants(s, True)[1]] if handover["inputs"] is not None else (in_b, a_stable)
-        geometry.copy_into(ta, a1_stable + a2_out)
-        copy_batch(tb, in_a1s)
-        geometry.copy_into(a1_stable, first_level(plan["consume"], a1_out))
-        copy_batch(in_a1s, first_level(plan["consume"], in_a))
+        if fps_all:  # the consumed lane holds every sampling level: straight into stream B's inputs
+            geometry.copy_into(ta, first_level(plan["consume"], a1_out))
+            copy_batch(tb, first_level(plan["consume"], in_a))
+        else:
+            geometry.copy_into(ta, a1_stable + a2_out)
+            copy_batch(tb, in_a1s)
+            geometry.copy_into(a1_stable, first_level(plan["consume"], a1_out))
+            copy_batch(in_a1s, first_level(plan["consume"], in_a))
         for buf, pi in plan["load"]:
             copy_batch(first_level(buf, in_a), pool[pi])
 
     def body_a(lane=0):  # joint mode: `lane` is the index of the double-batch buffer
         if joint:
-            geometry.copy_into(a1_outJ[lane], geo_fps_first(in_aJ[lane]))
+            geometry.copy_into(a1_outJ[lane], (geo_fps_all if fps_all else geo_fps_first)(in_aJ[lane]))
         else:
             geometry.copy_into(a1_out[lane], geo_fps_first(in_a[lane]))
 
@@ -586,7 +605,8 @@ def main():
         with torch.cuda.stream(s_b):
             s_b.wait_event(ev_main)        # rotate() has read in_b / a_stable
             s_b.wait_event(ev_lane[took])  # events, not stream waits: several parts may share a queue
-            s_b.wait_event(ev_a2)
+            if not fps_all:
+                s_b.wait_event(ev_a2)
             f_side[sidx]()
             ev_rot.record(s_b)
 
@@ -599,11 +619,12 @@ def main():
                     ev_lane[go].record(s_a[go])
         if not a2_first:
             launch_fps()
-        with torch.cuda.stream(s_a2):
-            s_a2.wait_event(ev_rot)
-            if "a2" not in skip:
-                f_a2()
-            ev_a2.record(s_a2)
+        if not fps_all:
+            with torch.cuda.stream(s_a2):
+                s_a2.wait_event(ev_rot)
+                if "a2" not in skip:
+                    f_a2()
+                ev_a2.record(s_a2)
         if a2_first:
             launch_fps()
         with torch.cuda.stream(s_b):
@@ -710,8 +731,9 @@ def main():
             for l in range(nfps):
                 with torch.cuda.graph(graphs[f"fps{l}"], stream=s_a[l], capture_error_mode=cap_mode):
                     body_a(l)
-            with torch.cuda.graph(graphs["a2"], stream=s_a2, capture_error_mode=cap_mode):
-                body_a2()
+            if not fps_all:
+                with torch.cuda.graph(graphs["a2"], stream=s_a2, capture_error_mode=cap_mode):
+                    body_a2()
             if not pingpong:
                 with torch.cuda.graph(graphs["b"], stream=s_b, capture_error_mode=cap_mode):
                     body_b()
@@ -790,7 +812,7 @@ def main():
             run_step([timed(rot_replay(j), main_s, "rotate", log) for j in range(period)],
                      [timed(graphs[f"side{j}"].replay, s_b, "side", log) for j in range(period)],
                      [timed(graphs[f"fps{l}"].replay, s_a[l], f"fps{l}", log) for l in range(nfps)],
-                     timed(graphs["a2"].replay, s_a2, "a2", log),
+                     timed(graphs["a2"].replay if not fps_all else (lambda: None), s_a2, "a2", log),
                      # ping-pong: the variants in the order run_step picks them (a feature variant must never run beside
                      # the B variant that writes the result set it reads)
                      [timed(graphs[k].replay, s_b, "b", log) for k in (("b", "b1") if pingpong else ("b", "b"))],
@@ -822,7 +844,7 @@ def main():
             torch.cuda.synchronize()
             return round((time.perf_counter() - t) / reps * 1e3, 3)
         parts = {"features_ms": alone(graphs["feat"].replay, main_s), "update_ms": alone(graphs["update"].replay, main_s),
-                 "fps_level1_ms": alone(graphs["fps0"].replay, s_a[0]), "fps_levels2to4_ms": alone(graphs["a2"].replay, s_a2),
+                 "fps_level1_ms": alone(graphs["fps0"].replay, s_a[0]), "fps_levels2to4_ms": alone(graphs["a2"].replay, s_a2) if not fps_all else None,
                  "neighbourhood_geometry_ms": alone(graphs["b"].replay, s_b),
                  "rotate_ms": alone(rot_replay(0), main_s),
                  "rotate_side_ms": alone(graphs["side0"].replay, s_b)}
@@ -840,7 +862,8 @@ def main():
                                     ("rotate_side", graphs[f"side{r % period}"].replay, s_b),
                                     ("fps1", graphs[f"fps{(r // lanes) % 2 if joint else r % lanes}"].replay
                                      if not (joint and r % lanes) else (lambda: None), s_a[r % lanes]),
-                                    ("fps2to4", graphs["a2"].replay, s_a2), ("geometry", graphs["b"].replay, s_b),
+                                    ("fps2to4", graphs["a2"].replay if not fps_all else (lambda: None), s_a2),
+                                    ("geometry", graphs["b"].replay, s_b),
                                     ("features", graphs["feat"].replay, main_s)):
                     h = time.perf_counter()
                     with torch.cuda.stream(st):

@@ -348,9 +348,11 @@ def test_reference_overlay_and_native_module_registration():
     sys.modules.pop("pointnet2_batch_cuda"); sys.modules.pop("pointops_cuda")
 
 
-@pytest.mark.parametrize("lanes,joint,npool", [(2, True, 4), (2, False, 4), (2, True, 3), (3, False, 4), (2, True, 5), (1, False, 4),
-                                               (3, True, 4), (4, True, 4), (4, True, 6)])
-def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, joint, npool):
+@pytest.mark.parametrize("lanes,joint,npool,all_levels", [
+    (2, True, 4, False), (2, False, 4, False), (2, True, 3, False), (3, False, 4, False), (2, True, 5, False), (1, False, 4, False),
+    (3, True, 4, False), (4, True, 4, False), (4, True, 6, False),
+    (3, True, 4, True), (4, True, 4, True), (6, True, 4, True)])   # all_levels: the joint launch runs every sampling level
+def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, joint, npool, all_levels):
     """bench.py's pipelined loop replayed with batch ids instead of tensors (amcontrast3d_amd/schedule.py holds its index
     arithmetic): at every step the feature half must see ONE batch -- its points, its four FPS levels and its neighbourhood /
     loss geometry -- a first-level FPS result must be `lanes` (joint: 2-3) steps old when it is consumed (it takes about a step),
@@ -366,7 +368,8 @@ def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, joint
     in_b, in_a1s = 1 % npool, 2 % npool
     if joint:
         in_a = [[(3 + lanes * j + t) % npool for t in range(lanes)] for j in range(2)]
-        a1_out = [[fps1(b) for b in row] for row in in_a]
+        full = (lambda b: (fps1(b), fps2(fps1(b)))) if all_levels else fps1
+        a1_out = [[full(b) for b in row] for row in in_a]
         launched = [[-10] * lanes, [-10] * lanes]
     else:
         in_a = [(3 + l) % npool for l in range(lanes)]
@@ -400,22 +403,27 @@ def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, joint
         # (nothing moves on the main stream)
         # rotate_side (geometry queue)
         plan = schedule.side_step(s, lanes, joint, npool)
-        sets[fills] = {"batch": in_a1s, "fps": (a1_stable, a2_out)}
         assert n - at(launched, plan["consume"]) >= lanes, "first-level FPS consumed before it can have finished"
-        a1_stable, in_a1s = at(a1_out, plan["consume"]), at(in_a, plan["consume"])
-        assert a1_stable == fps1(in_a1s), "an input buffer was overwritten between its FPS launch and its consumption"
+        if all_levels:  # the consumed lane goes straight into stream B's input set
+            sets[fills] = {"batch": at(in_a, plan["consume"]), "fps": at(a1_out, plan["consume"])}
+            assert sets[fills]["fps"][0] == fps1(sets[fills]["batch"]), "an input buffer was overwritten before its consumption"
+        else:
+            sets[fills] = {"batch": in_a1s, "fps": (a1_stable, a2_out)}
+            a1_stable, in_a1s = at(a1_out, plan["consume"]), at(in_a, plan["consume"])
+            assert a1_stable == fps1(in_a1s), "an input buffer was overwritten between its FPS launch and its consumption"
         for buf, pi in plan["load"]:
             put(in_a, buf, pi)
         # first-level FPS launch (finishes about a step later; modelled as reading its inputs now)
         if plan["launch"] is not None:
             if joint:
                 j = plan["launch"]
-                a1_out[j] = [fps1(b) for b in in_a[j]]
+                a1_out[j] = [full(b) for b in in_a[j]]
                 launched[j] = [n] * lanes
             else:
                 a1_out[plan["launch"]] = fps1(in_a[plan["launch"]])
                 launched[plan["launch"]] = n
-        a2_out = fps2(a1_stable)                                   # stream A2
+        if not all_levels:
+            a2_out = fps2(a1_stable)                               # stream A2
         sets[fills]["geo"] = geo(sets[fills]["batch"], sets[fills]["fps"])   # stream B, variant `fills`
         # the feature half, variant `reads`
         cur = sets[reads]
