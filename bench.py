@@ -406,7 +406,7 @@ def main():
     # More than two lanes = clouds whose FPS levels 2-4 are long chains as well (120000 points: level 2 alone is 22 ms, longer
     # than the feature half): the joint launch then runs ALL sampling levels of its J batches, and the separate levels-2-4
     # stage of the pipeline disappears (its results went through one more set of buffers and one more step of latency).
-    fps_all = joint and lanes > 2 and not os.environ.get("AMC3D_NO_FPS_ALL")
+    fps_all = joint and (lanes > 2 or bool(os.environ.get("AMC3D_FPS_ALL"))) and not os.environ.get("AMC3D_NO_FPS_ALL")
     a2_rides = joint and lanes == 2 and os.environ.get("AMC3D_A2_ON_FPS", "1") != "0"  # FPS levels 2-4 on the sampling queue (see below)
     # Hardware queues.  Ordinary HIP streams of a process share GPU_MAX_HW_QUEUES (default 4) queues round-robin, and
     # whatever shares a queue with a running FPS kernel (8 ms on 8 workgroups) waits for it; which stream that is
@@ -435,7 +435,7 @@ def main():
         # AMC3D_CU_MASK="" turns the masks off.
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
         # (measured for the two-lane configuration only: with more lanes -- 64k / 120k-point clouds -- no mask by default)
-        geo_cus = (9 * ncu // 16 if a2_rides else 3 * ncu // 4) if lanes == 2 else 0
+        geo_cus = (9 * ncu // 16 if (a2_rides or fps_all) else 3 * ncu // 4) if lanes == 2 else 0
         cum = {k: (int(a), int(b)) for k, a, b in
                (v.split(":") for v in os.environ.get("AMC3D_CU_MASK", f"geo:0:{geo_cus}").split(",") if v)}
         q = {k: _ops.dedicated_stream(dev, *cum.get(k, (0, 0))) for k in qplan.split(",")}
