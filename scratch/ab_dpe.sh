@@ -1,3 +1,4 @@
+# NOTE: the switch this script toggles (an experiment of round 2) was measured and removed again; kept for the record of how it was measured
 set -e
 cd $GRAFT_REPO_ROOT
 timeout -k 10 600 python -m pytest tests/test_gpu_lagg.py tests/test_gpu_model.py -x -q 2>&1 | tail -3

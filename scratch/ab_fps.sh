@@ -1,3 +1,4 @@
+# NOTE: the switch this script toggles (an experiment of round 2) was measured and removed again; kept for the record of how it was measured
 cd $GRAFT_REPO_ROOT
 for w in 0 16 17; do
   export AMC3D_FPS_WAVES=$w
