@@ -43,14 +43,16 @@ def max_over_ranks(value, device):
     """MAX-reduce a python float over ranks (step time = slowest rank)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
+    from .graphs import on_side_stream
     t = torch.tensor([value], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    on_side_stream(lambda: dist.all_reduce(t, op=dist.ReduceOp.MAX))
     return float(t.item())
 
 
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        from .graphs import on_side_stream
+        on_side_stream(dist.barrier)
 
 
 def wrap_data_parallel(model, device, world):
@@ -83,7 +85,8 @@ def allreduce_gradients(params, bucket_bytes=32 << 20):
         buckets.append(cur)
     for b in buckets:
         flat = torch.cat([g.reshape(-1) for g in b])
-        dist.all_reduce(flat)
+        from .graphs import on_side_stream
+        on_side_stream(lambda: dist.all_reduce(flat))
         flat.div_(world)
         off = 0
         for g in b:
@@ -155,8 +158,9 @@ class FlatGradients:
         exercises the same RCCL call)"""
         if not (dist.is_available() and dist.is_initialized()):
             return
+        from .graphs import on_side_stream  # never on a stream that captures graphs (graphs.on_side_stream)
         if dist.get_backend() == "nccl":
-            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
+            on_side_stream(lambda: dist.all_reduce(self.flat, op=dist.ReduceOp.AVG))
         else:  # gloo has no AVG
-            dist.all_reduce(self.flat)
+            on_side_stream(lambda: dist.all_reduce(self.flat))
             self.flat.div_(dist.get_world_size())

@@ -111,7 +111,8 @@ def summarize(cm, cm_b=None, cm_i=None, distributed=False):
         tp, union, count = m.tp, m.union, m.count
         if distributed:
             import torch.distributed as dist
-            dist.all_reduce(tp), dist.all_reduce(union), dist.all_reduce(count)
+            from .graphs import on_side_stream
+            on_side_stream(lambda: (dist.all_reduce(tp), dist.all_reduce(union), dist.all_reduce(count)))
         out += tuple(get_mious(tp, union, count))
     return out
 

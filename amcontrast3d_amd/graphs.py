@@ -7,7 +7,9 @@ collectives inside a graph.  `SegmentedGraph` does neither: the step function ru
 time it reaches a collective (`collective(fn)`, called by ops.SyncBatchNormFused) the capture is ended, `fn` is kept as
 an eager call, and a new capture begins in the same memory pool.  Replay = graph, collective, graph, collective, ...
 in the recorded order on the current stream: the kernels are replayed as graphs, the collectives are ordinary
-`torch.distributed` calls between them, as they would be in an eager loop.
+`torch.distributed` calls between them, as they would be in an eager loop.  (Collectives issued while graphs are still
+being captured -- warm-up steps, the capturing pass itself, barriers -- go through `on_side_stream`; before capturing on a
+stream that has run collectives, call `quiesce()`.)
 
 Backward.  autograd normally runs CUDA nodes on a worker thread, and a stream capture must be ended by the thread that
 began it; `capture()` therefore runs the function under `torch.autograd.set_multithreading_enabled(False)`, which keeps
@@ -22,11 +24,45 @@ import torch
 _active = None  # the SegmentedGraph that is capturing on this thread, if any
 
 
+_side_streams = {}  # device index -> the stream every collective of this process is issued on
+
+
+def on_side_stream(fn):
+    """Run `fn` (a torch.distributed call) on this device's collective stream, ordered after the current stream's work and
+    before its later work.  Why not on the current stream: c10d runs a blocking collective on the caller's stream and
+    records the work's completion event there; its watchdog thread polls that event until it sees it complete -- up to
+    ~100 ms later -- and HIP refuses to query an event whose stream is capturing AT THAT MOMENT (hipErrorCapturedEvent, which
+    also invalidates the capture).  A training loop that captures graphs on its main stream after any eager collective on
+    that stream (warm-up steps, a barrier) therefore aborts every few runs.  The collective stream never captures."""
+    if not (torch.cuda.is_available() and torch.cuda.is_initialized()):
+        return fn()  # CPU process groups (gloo tests)
+    cur = torch.cuda.current_stream()
+    if torch.cuda.is_current_stream_capturing():
+        return fn()  # a plain capture that wants the collective INSIDE the graph (RCCL records it; not what bench.py does)
+    side = _side_streams.get(cur.device.index)
+    if side is None:
+        side = _side_streams[cur.device.index] = torch.cuda.Stream(device=cur.device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        out = fn()
+    cur.wait_stream(side)
+    return out
+
+
+def quiesce(seconds=0.3):
+    """Call before capturing graphs on a stream that has run collectives: drains the GPU and gives c10d's watchdog thread
+    (poll interval ~100 ms) time to retire the finished works, whose events it must not query once the stream captures."""
+    import time
+    torch.cuda.synchronize()
+    time.sleep(seconds)
+
+
 def collective(fn):
-    """Run `fn` (a torch.distributed call) now; inside SegmentedGraph.capture() also cut the graph here."""
+    """Run `fn` (a torch.distributed call) now, on the collective stream; inside SegmentedGraph.capture() also cut the
+    graph here."""
     if _active is not None:
         return _active._cut(fn)
-    return fn()
+    return on_side_stream(fn)
 
 
 class SegmentedGraph:
@@ -35,7 +71,6 @@ class SegmentedGraph:
         self.items = []      # torch.cuda.CUDAGraph | callable, in replay order
         self.pool = None
         self._cur = None
-        self._side = None
 
     # -- capture ---------------------------------------------------------------------------------
     def _begin(self):
@@ -50,15 +85,8 @@ class SegmentedGraph:
     def _cut(self, fn):
         self._end()
         self.items.append(fn)
-        # Keeps the ranks' collective sequences aligned during the capturing pass -- on a SIDE stream: c10d runs a blocking
-        # collective on the caller's stream and records the work's completion event there, its watchdog thread polls that
-        # event, and polling an event of a stream that has meanwhile begun capturing again fails with
-        # hipErrorCapturedEvent and invalidates the capture (seen as an intermittent abort, once in a few runs).
-        cur = torch.cuda.current_stream()
-        self._side.wait_stream(cur)
-        with torch.cuda.stream(self._side):
-            out = fn()
-        cur.wait_stream(self._side)
+        # keeps the ranks' collective sequences aligned during the capturing pass (on the collective stream: on_side_stream)
+        out = on_side_stream(fn)
         self._begin()
         return out
 
@@ -69,7 +97,6 @@ class SegmentedGraph:
         assert _active is None and not self.items, "one capture per SegmentedGraph"
         stream = stream if stream is not None else torch.cuda.current_stream()
         self.pool = torch.cuda.graph_pool_handle()
-        self._side = torch.cuda.Stream()
         torch.cuda.synchronize()
         with torch.cuda.stream(stream), torch.autograd.set_multithreading_enabled(False):
             _active = self
@@ -94,7 +121,7 @@ class SegmentedGraph:
             if isinstance(it, torch.cuda.CUDAGraph):
                 it.replay()
             else:
-                it()
+                it()  # on the current stream: see quiesce() before capturing on this stream again
 
     @property
     def segments(self):

@@ -210,8 +210,8 @@ def rehearse_cpu(args):
         import torch.distributed as tdist
         chk = torch.stack([p.detach().double().sum() for p in params])
         lo, hi = chk.clone(), chk.clone()
-        tdist.all_reduce(lo, op=tdist.ReduceOp.MIN)
-        tdist.all_reduce(hi, op=tdist.ReduceOp.MAX)
+        from amcontrast3d_amd.graphs import on_side_stream
+        on_side_stream(lambda: (tdist.all_reduce(lo, op=tdist.ReduceOp.MIN), tdist.all_reduce(hi, op=tdist.ReduceOp.MAX)))
         sync = bool(torch.equal(lo, hi))
     if rank == 0:
         print(json.dumps({"metric": "rehearsal", "value": 0.0, "unit": "none", "n_gpus": world, "steps": args.steps,
@@ -648,6 +648,12 @@ def main():
         for _ in range(3):
             eager_step()
         torch.cuda.synchronize()
+        if world > 1 or sync_bn:
+            # before the captures: the warm-up steps' collectives ran on a stream that never captures (graphs.on_side_stream),
+            # and c10d's watchdog gets time to retire them anyway (graphs.quiesce) -- it must not poll an event of a stream
+            # that is capturing
+            from amcontrast3d_amd.graphs import quiesce
+            quiesce()
         if flatg is None:
             opt.zero_grad(set_to_none=True)
         names = (["a2", "b", "feat", "update"] + [f"rotate{j}" for j in range(period)] + [f"side{j}" for j in range(period)]
@@ -792,8 +798,8 @@ def main():
         import torch.distributed as tdist
         chk = torch.stack([p.detach().double().sum() for p in params] + [p.detach().double().abs().sum() for p in params])
         lo, hi = chk.clone(), chk.clone()
-        tdist.all_reduce(lo, op=tdist.ReduceOp.MIN)
-        tdist.all_reduce(hi, op=tdist.ReduceOp.MAX)
+        from amcontrast3d_amd.graphs import on_side_stream
+        on_side_stream(lambda: (tdist.all_reduce(lo, op=tdist.ReduceOp.MIN), tdist.all_reduce(hi, op=tdist.ReduceOp.MAX)))
         replicas_in_sync = bool(torch.equal(lo, hi))
 
     if use_graph and overlap and rank == 0 and os.environ.get("AMC3D_TIMELINE"):
