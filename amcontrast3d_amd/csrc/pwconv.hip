@@ -226,7 +226,9 @@ static PwSplit pw_split(int b, int cin, int cout, long P)
     s.tiles_per_cloud = div_up(P, PWW_TP);
     s.ntiles = s.tiles_per_cloud * b;
     const int max_groups = max(1, 2048 / (s.mchunks * s.kchunks));
-    int groups = min(max(1, s.ntiles / 8), max_groups);
+    // eight tiles per workgroup on long layers; short ones (a few dozen tiles: the coarse stages) two, or they run on a handful
+    // of workgroups (6 workgroups took 37-94 us for the masking module's coarse convs)
+    int groups = min(max(1, s.ntiles >= 512 ? s.ntiles / 8 : (s.ntiles + 1) / 2), max_groups);
     s.tiles_per_wg = div_up(s.ntiles, groups);
     s.groups = div_up(s.ntiles, s.tiles_per_wg);
     return s;
