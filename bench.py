@@ -361,6 +361,10 @@ def main():
     overlap = not args.no_overlap and not use_ddp
     prio = [int(v) for v in os.environ.get("AMC3D_STREAM_PRIO", "0,0,0,0").split(",")]  # main, fps lanes, a2, b
     main_s = torch.cuda.Stream(priority=prio[0])  # all work of this process runs on non-default streams (capture recipe)
+    if os.environ.get("AMC3D_MAIN_CUS"):  # experiment: the main stream on a CU-masked queue of its own, "first:count"
+        from amcontrast3d_amd import ops as _ops0
+        _f, _n = (int(v) for v in os.environ["AMC3D_MAIN_CUS"].split(":"))
+        main_s = _ops0.dedicated_stream(dev, _f, _n)
     main_s.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(main_s)
     lanes = args.fps_lanes
