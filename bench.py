@@ -341,22 +341,23 @@ def main():
         if flatg is not None:
             flatg.gather()  # copy mode: one multi-tensor copy into the all-reduce buffer, .grad -> its views
 
-    # Software pipeline over consecutive batches.  The coordinate-only half of a step
-    # (amcontrast3d_amd/geometry.py) does not depend on features or weights, so it runs ahead, on two side
-    # streams, while the current batch runs its feature half on the main stream:
-    #     streams A1[0..L) first sampling level of batches t+3 .. t+2+L: FPS 24000 -> 6000 (one workgroup per cloud:
-    #               8 of the 256 CUs for ~10 ms, a chain of 6000 dependent iterations).  The chain is latency-bound
-    #               and leaves 97 % of the chip idle, so L = --fps-lanes of them (default 2) are in flight at once,
-    #               each for a different future batch and launched L steps before its result is consumed: one
-    #               launch and one completed sampling per step
-    #     stream A2 sampling levels 2-4 of batch t+2   : FPS 6000 -> 1500 -> 375 -> 93 (~2.5 ms, same shape)
-    #     stream B  neighbourhoods of batch t+1      : ball queries, relative positions, 3-NN, and the loss
-    #               geometry (k-NN, class votes, positive masks, ambiguities)
-    #     main      features of batch t            : forward, loss, backward (+ all-reduce, clip, AdamW)
-    # Every step still does one full pass of each inside the timed region (the synthetic "next batches" are
-    # the same resident batch).  Each part is its own hipGraph on its own stream: on ROCm 7.2 separate
-    # graphs on separate streams overlap, whereas branches inside ONE captured graph are serialised with
-    # heavy per-node overhead (scratch/graph_conc.py: 1.6 ms vs 4.8 ms for three 0.95 ms chains).
+    # Software pipeline over consecutive batches.  The coordinate-only half of a step (amcontrast3d_amd/geometry.py) does
+    # not depend on features or weights, so it runs ahead, on two side queues, while the current batch runs its feature half
+    # on the main stream (index arithmetic in amcontrast3d_amd/schedule.py):
+    #     sampling queue  FPS 24000 -> 6000 of J = --fps-lanes future batches (default 2) as ONE launch every J steps: one
+    #                     workgroup per cloud, a chain of 6000 dependent iterations (8 ms), latency-bound -- more clouds per
+    #                     launch cost nothing.  Lane l of a launch is consumed J + l steps later.  With J = 2 the sampling
+    #                     levels 2-4 of batch t+2 (6000 -> 1500 -> 375 -> 93, 2.3 ms) run on the same queue every step, ahead
+    #                     of the launch; with J > 2 (64k / 120k-point clouds) the launch runs every level itself
+    #     geometry queue  neighbourhoods of batch t+1: ball queries, relative positions, reverse lists, 3-NN, and the loss
+    #                     geometry (k-NN, class votes, positive masks, ambiguities, anchor lists); CU-masked; two captured
+    #                     variants that fill two result sets in turn
+    #     main            features of batch t: forward, loss, backward (+ all-reduce), clip + AdamW; two captured variants
+    #                     that read the result set (and the input set) stream B's variant worked on one step earlier
+    # Every step still does one full pass of each inside the timed region, on `--pool` rotating resident batches.  Each part is
+    # its own hipGraph on its own stream: on ROCm 7.2 separate graphs on separate streams overlap, whereas branches inside ONE
+    # captured graph are serialised with heavy per-node overhead (scratch/graph_conc.py: 1.6 ms vs 4.8 ms for three 0.95 ms
+    # chains).
     from amcontrast3d_amd import geometry
     overlap = not args.no_overlap and not use_ddp
     prio = [int(v) for v in os.environ.get("AMC3D_STREAM_PRIO", "0,0,0,0").split(",")]  # main, fps lanes, a2, b
