@@ -61,10 +61,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--fps-lanes", type=int, default=0,
-                    help="first-level FPS chains in flight (each for a different future batch; one launch per step).  0 = "
-                         "choose: 2 where the chain is shorter than the feature half (24k-point clouds), else enough lanes, "
-                         "each on a hardware queue of its own, that chains / lanes stays below it (64k / 120k-point clouds "
-                         "in small batches: a chain of 16000-30000 dependent iterations on ONE workgroup per cloud)")
+                    help="future batches whose FPS runs as one joint launch (one launch every J steps on the sampling queue).  "
+                         "0 = choose: 2 where the first-level chain is about a feature half long (24k-point clouds), else 3-8 "
+                         "so that the chain of all levels fits into J steps (64k / 120k-point clouds in small batches: "
+                         "16000-30000 dependent iterations on ONE workgroup per cloud)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="compute each batch's geometry inline instead of one step ahead on a side stream")
     ap.add_argument("--sync-bn", action="store_true", help="(default at N > 1; kept for older command lines)")
