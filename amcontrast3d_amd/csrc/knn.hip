@@ -917,8 +917,8 @@ static int kg_build(const KnnWorkspace &w, char *base, int n, int m, int nbatch,
     int *cursor = (int *)(base + w.cursor);
     float4 *sorted = (float4 *)(base + w.sorted);
     const size_t cells = (size_t)knn_cell_cap(n) + 1;
-    if (int st = fill_i32(cell_start, 0, cells, stream)) return st;
-    if (int st = fill_i32(cursor, 0, cells, stream)) return st;
+    // cell_start and cursor are neighbours in the workspace (knn_layout): one launch zeroes both and the padding between
+    if (int st = fill_i32(cell_start, 0, (size_t)(cursor - cell_start) + cells, stream)) return st;
     hipLaunchKernelGGL(kg_init_kernel, dim3(1), dim3(64), 0, stream, bbox, fb_count);
     hipLaunchKernelGGL(kg_bbox_kernel, dim3(min(div_up(n, 256), 64)), dim3(256), 0, stream, n, xyz, bbox);
     if (!(fixed_h > 0.f))
