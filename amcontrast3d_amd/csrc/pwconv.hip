@@ -46,6 +46,21 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, long P, cons
 #pragma unroll
     for (int c = 0; c < NCT; ++c) acc[c] = pw_f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
+    // vec path: the X chunk of the NEXT k-step is loaded into registers before the current one is multiplied (layers with more
+    // than 32 input channels walk 2-4 chunks per tile: load -> barrier -> multiply left every load exposed)
+    constexpr int LPT = PW_KC * PW_TP / 4 / 256;  // 4 float4 per thread and chunk
+    float4 pre[LPT];
+    auto prefetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) {
+            const int i = threadIdx.x + u * 256;
+            const int kk = i / (PW_TP / 4), c4 = i - kk * (PW_TP / 4);
+            const int k = k0 + kk;
+            const long p = p0 + c4 * 4;
+            pre[u] = (k < K && p < P) ? *(const float4 *)(X + (size_t)k * P + p) : make_float4(0.f, 0.f, 0.f, 0.f);  // P % 4 == 0
+        }
+    };
+    if (vec) prefetch(0);
     for (int k0 = 0; k0 < K; k0 += PW_KC) {
         __syncthreads();  // previous chunk consumed
         // A chunk (NCT*32 rows x 32 k); consecutive threads walk the contiguous axis of a
@@ -57,13 +72,11 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, long P, cons
         }
         // X chunk (32 k x 128 positions)
         if (vec) {
-            for (int i = threadIdx.x; i < PW_KC * PW_TP / 4; i += 256) {
+#pragma unroll
+            for (int u = 0; u < LPT; ++u) {
+                const int i = threadIdx.x + u * 256;
                 const int kk = i / (PW_TP / 4), c4 = i - kk * (PW_TP / 4);
-                const int k = k0 + kk;
-                const long p = p0 + c4 * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < K && p < P) v = *(const float4 *)(X + (size_t)k * P + p);  // P % 4 == 0: p + 3 < P
-                *(float4 *)(xs + kk * PW_TP + c4 * 4) = v;
+                *(float4 *)(xs + kk * PW_TP + c4 * 4) = pre[u];
             }
         } else {
             for (int i = threadIdx.x; i < PW_KC * PW_TP; i += 256) {
@@ -74,6 +87,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(int M, int K, long P, cons
             }
         }
         __syncthreads();
+        if (vec && k0 + PW_KC < K) prefetch(k0 + PW_KC);  // in flight during the MFMAs
         // MFMA operands: A[i = channel][k] -> lane (pl, kh) holds A(pl, kh); B[k][j = position] -> X(kh, pl)
 #pragma unroll 4
         for (int s = 0; s < PW_KC; s += 2) {
