@@ -183,7 +183,8 @@ class SetAbstraction(nn.Module):
             geom = self.plan(p)
         idx, new_p = geom['fps_idx'], geom['new_p']
         fi = None
-        if self.use_res or 'df' in self.feature_type:
+        res_fused = self._fused_residual(f, geom)
+        if not res_fused and (self.use_res or 'df' in self.feature_type):
             import os
             if (f.is_cuda and f.dtype == torch.float32 and geom.get('fps_idx32') is not None
                     and os.environ.get("AMC3D_OWN_GATHER")):
@@ -207,9 +208,27 @@ class SetAbstraction(nn.Module):
             dp, fj = self.grouper(new_p, p, f, geom=geom if 'idx' in geom else None)
             fj = get_aggregation_feautres(new_p, dp, fi, fj, feature_type=self.feature_type)
             f = run_convblocks(self.convs, fj, pool_max=True)  # conv/BN/ReLU stack + max over the neighbours
-        if self.use_res:
+        if res_fused:  # gather at the FPS picks + skip conv + bias + add + ReLU as one kernel (csrc/sa_res.hip)
+            from amcontrast3d_amd import ops
+            conv = self.skipconv[0]
+            f = ops.sa_residual(f, pf[1], geom['fps_idx32'], conv.weight, conv.bias)
+        elif self.use_res:
             f = self.act(f + identity)
         return new_p, f
+
+    def _fused_residual(self, f, geom):
+        """True when the residual branch (pointnext_AA.py:157-168) has the form the fused kernels cover: a bare 1x1 Conv1d
+        as skip conv, ReLU, fp32 features on the GPU and int32 FPS picks in the plan"""
+        import os
+        if (not self.use_res or 'df' in self.feature_type or os.environ.get("AMC3D_NO_SA_RESIDUAL")
+                or geom.get('fps_idx32') is None or not f.is_cuda or f.dtype != torch.float32 or f.dim() != 3):
+            return False
+        sk = self.skipconv
+        if not isinstance(sk, nn.Sequential) or len(sk) != 1 or not isinstance(sk[0], nn.Conv1d) or type(self.act) is not nn.ReLU:
+            return False
+        conv = sk[0]
+        return (conv.kernel_size == (1,) and conv.stride == (1,) and conv.groups == 1 and conv.padding == (0,)
+                and conv.in_channels == f.shape[1] and conv.weight.dtype == torch.float32)
 
 
 class FeaturePropogation(nn.Module):

@@ -1306,6 +1306,67 @@ def pointwise_conv(x, weight, bias=None, bf16=False):
     return PointwiseConv.apply(x, weight, bias, bf16)
 
 
+class SAResidual(Function):
+    """out = relu(y + skipconv(f[:, :, fps_idx])): the residual branch of a strided SetAbstraction block with use_res
+    (pointnext_AA.py:157-168: torch.gather -> Conv1d with bias -> add -> ReLU) on csrc/sa_res.hip -- one launch forward;
+    backward: ReLU mask + bias gradient + zero-fill, W^T . g scattered to the sampled columns, and the weight gradient.
+    y (B,Cout,M) pooled main branch, f (B,Cin,N), fps_idx (B,M) int32, weight (Cout,Cin,1), bias (Cout) or None."""
+
+    @staticmethod
+    def forward(ctx, y, f, fps_idx, weight, bias):
+        _need_gpu(y, f, fps_idx, weight)
+        _need_dtype(torch.float32, y=y, f=f, weight=weight, bias=bias)
+        _need_dtype(torch.int32, fps_idx=fps_idx)
+        y, f, fps_idx = y.contiguous(), f.contiguous(), fps_idx.contiguous()
+        B, Cin, N = f.shape
+        Cout, M = weight.shape[0], fps_idx.shape[1]
+        assert y.shape == (B, Cout, M) and fps_idx.shape[0] == B and weight.numel() == Cout * Cin
+        w2 = weight.reshape(Cout, Cin).contiguous()
+        bias = bias.contiguous() if bias is not None else None
+        out = torch.empty_like(y)
+        keep = any(ctx.needs_input_grad)
+        fi = torch.empty(B, Cin, M, dtype=torch.float32, device=f.device) if keep else None
+        with torch.cuda.device(f.device), timing.span("sa_residual_forward", 4 * B * M * (Cin * (2 if keep else 1) + 2 * Cout) + 4 * B * M,
+                                                      2.0 * B * M * Cin * Cout):
+            _lib.check(_lib.load().amc3d_sa_residual_forward(B, Cin, Cout, N, M, _ptr(f), _ptr(fps_idx), _ptr(w2),
+                                                             _ptr(bias) if bias is not None else None, _ptr(y), _ptr(out),
+                                                             _ptr(fi) if keep else None, _stream(f)), "sa_residual_forward")
+        if keep:
+            ctx.save_for_backward(out, fi, fps_idx, w2)
+        ctx.n, ctx.wshape, ctx.has_bias = N, tuple(weight.shape), bias is not None
+        ctx.mark_non_differentiable(fps_idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, fi, fps_idx, w2 = ctx.saved_tensors
+        B, Cout, M = out.shape
+        Cin, N = w2.shape[1], ctx.n
+        dout = dout.contiguous()
+        dev = dout.device
+        need_f, need_w = ctx.needs_input_grad[1], ctx.needs_input_grad[3]
+        need_b = ctx.has_bias and ctx.needs_input_grad[4]
+        g = torch.empty_like(out)
+        df = torch.empty(B, Cin, N, dtype=torch.float32, device=dev) if need_f else None
+        dw = torch.empty(Cout, Cin, dtype=torch.float32, device=dev) if need_w else None
+        db = torch.empty(Cout, dtype=torch.float32, device=dev) if need_b else None
+        lib = _lib.load()
+        wb = int(lib.amc3d_sa_residual_workspace_bytes(B, Cin, Cout, M))
+        work = torch.empty(max(wb, 4), dtype=torch.uint8, device=dev)
+        nbytes = 4 * B * M * 3 * Cout + (4 * B * Cin * N + 4 * B * M * Cout) * int(need_f) + 4 * B * M * (Cin + Cout) * int(need_w)
+        with torch.cuda.device(dev), timing.span("sa_residual_backward", nbytes,
+                                                 2.0 * B * M * Cin * Cout * (int(need_f) + int(need_w))):
+            _lib.check(lib.amc3d_sa_residual_backward(B, Cin, Cout, N, M, _ptr(dout), _ptr(out), _ptr(fi), _ptr(fps_idx),
+                                                      _ptr(w2), _ptr(g), _ptr(df) if need_f else None,
+                                                      _ptr(dw) if need_w else None, _ptr(db) if need_b else None,
+                                                      _ptr(work), wb, _stream(dout)), "sa_residual_backward")
+        return g, df, None, (dw.view(ctx.wshape) if need_w else None), db
+
+
+def sa_residual(y, f, fps_idx, weight, bias):
+    return SAResidual.apply(y, f, fps_idx, weight, bias)
+
+
 def _library_wgrad(dy3, x3):
     """dW (Cout,Cin) = sum_b dy[b] . x[b]^T as plain library GEMMs: batched GEMM + sum over the batch, or one GEMM
     over (batch x positions) where the batched form hits a slow library heuristic (256x256x375: 97 vs 25 us,

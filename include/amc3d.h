@@ -262,6 +262,21 @@ int amc3d_pointwise_conv_backward(int b, int cin, int cout, long P, const float 
                                   const float *dy, float *dx, float *dweight, void *workspace,
                                   size_t workspace_bytes, void *stream);
 
+/* ---- residual branch of a strided SetAbstraction block (openpoints/models/backbone/pointnext_AA.py:157-168, use_res):
+ *     fi = torch.gather(f, -1, idx...); identity = self.skipconv(fi); ...; f = self.act(f + identity)
+ * forward:  out (b,cout,m) = relu(y + weight . f[:, :, fps_idx] + bias), f (b,cin,n), fps_idx (b,m) int32 (the FPS picks:
+ *           distinct within a cloud), weight (cout,cin), bias (cout) or NULL, y (b,cout,m) = the pooled main branch;
+ *           fi (b,cin,m) or NULL = the gathered columns, kept for the weight gradient.
+ * backward: g (b,cout,m) = dout * (out > 0) -- the gradient w.r.t. y AND w.r.t. the skip conv's output;
+ *           df (b,cin,n) or NULL = weight^T . g at the sampled columns, zero elsewhere (written whole: no pre-zeroing);
+ *           dweight (cout,cin) or NULL (needs fi; fixed-order partial sums); dbias (cout) or NULL (fixed order). */
+int amc3d_sa_residual_forward(int b, int cin, int cout, int n, int m, const float *f, const int *fps_idx,
+                              const float *weight, const float *bias, const float *y, float *out, float *fi, void *stream);
+size_t amc3d_sa_residual_workspace_bytes(int b, int cin, int cout, int m);
+int amc3d_sa_residual_backward(int b, int cin, int cout, int n, int m, const float *dout, const float *out,
+                               const float *fi, const int *fps_idx, const float *weight, float *g, float *df,
+                               float *dweight, float *dbias, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- input pipeline on the device (openpoints/dataset/data_util.py:92-174; dataset/s3dis/s3dis.py:122-144) -----------
  * voxelize: floor(coord / voxel_size) in float64 -> FNV-1a 64-bit hash of the three cell coordinates (fnv_hash_vec) ->
  * stable sort by key -> voxel ids / starts / counts.  coord (n,3) fp32 must be shifted to its min corner (crop_pc does
