@@ -64,6 +64,7 @@ SIGNATURES = {
     "amc3d_pointwise_conv_forward_ws": (_i, [_i, _i, _i, _l, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_pointwise_conv_workspace_bytes": (_sz, [_i, _i, _i, _l]),
     "amc3d_pointwise_conv_backward": (_i, [_i, _i, _i, _l, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "amc3d_bias_grad": (_i, [_i, _i, _l, _vp, _vp, _vp]),
     "amc3d_sa_residual_forward": (_i, [_i, _i, _i, _i, _i] + [_vp] * 8),
     "amc3d_sa_residual_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "amc3d_sa_residual_backward": (_i, [_i, _i, _i, _i, _i] + [_vp] * 10 + [_sz, _vp]),

@@ -202,9 +202,8 @@ def feature_propagation_first_block(blk, f1, f2, geom):
     if (conv.bias is not None or conv.kernel_size != (1,) or conv.stride != (1,) or conv.groups != 1
             or conv.in_channels != c1 + f2.shape[1]):
         return None
-    w = conv.weight[:, :, 0]
-    y = ops.three_interpolate_add(conv1x1_weight(f2, w[:, c1:].contiguous()), geom['idx'], geom['weight'],
-                                  conv1x1_weight(f1, w[:, :c1].contiguous()))
+    w1, w2 = ops.split_weight(conv.weight, c1)
+    y = ops.three_interpolate_add(conv1x1_weight(f2, w2), geom['idx'], geom['weight'], conv1x1_weight(f1, w1))
     group = _synced_bn_group(bn, y)
     if _eval_bn(bn, y):
         return ops.bn_eval(y, bn, True, False)

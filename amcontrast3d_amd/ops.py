@@ -1298,12 +1298,37 @@ class PointwiseConv(Function):
                                                  4 * B * P * ((Cin + Cout) * int(need_x) + (Cin + Cout) * int(need_w)), flops):
             _lib.check(bwd(B, Cin, Cout, P, _ptr(x), _ptr(w2), _ptr(dy), _ptr(dx) if need_x else None,
                            _ptr(dw) if need_w else None, _ptr(work), wb, _stream(dy)), "pointwise_conv_backward")
-        db = dy.reshape(B, Cout, -1).float().sum(dim=(0, 2)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(Cout, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(_lib.load().amc3d_bias_grad(B, Cout, P, _ptr(dy), _ptr(db), _stream(dy)), "bias_grad")
         return dx, (dw.view(ctx.wshape) if need_w else None), db, None
 
 
 def pointwise_conv(x, weight, bias=None, bf16=False):
     return PointwiseConv.apply(x, weight, bias, bf16)
+
+
+class SplitWeight(Function):
+    """(w[:, :c1], w[:, c1:]) of a 1x1-conv weight (Cout, C1+C2, 1) as two contiguous (Cout, C) matrices -- the two halves of a
+    FeaturePropogation conv applied to the skip features and to the coarse features separately.  As torch slices the
+    backward is zeros + copy per slice, an add, and zeros + copy for the select (7 launches per decoder level); here it is
+    one concatenation."""
+
+    @staticmethod
+    def forward(ctx, weight, c1):
+        w = weight.reshape(weight.shape[0], -1)
+        ctx.wshape = tuple(weight.shape)
+        return w[:, :c1].contiguous(), w[:, c1:].contiguous()
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        return torch.cat((g1, g2), dim=1).view(ctx.wshape), None
+
+
+def split_weight(weight, c1):
+    return SplitWeight.apply(weight, c1)
 
 
 class SAResidual(Function):

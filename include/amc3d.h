@@ -262,6 +262,10 @@ int amc3d_pointwise_conv_backward(int b, int cin, int cout, long P, const float 
                                   const float *dy, float *dx, float *dweight, void *workspace,
                                   size_t workspace_bytes, void *stream);
 
+/* dbias (c) = sum_{b,p} dy (b,c,P): bias gradient of a 1x1 convolution with bias (the stem conv and the head's last conv,
+ * base_seg.py:236-252, pointnext_AA.py:104-127 with is_head), summed in a fixed order */
+int amc3d_bias_grad(int b, int c, long P, const float *dy, float *dbias, void *stream);
+
 /* ---- residual branch of a strided SetAbstraction block (openpoints/models/backbone/pointnext_AA.py:157-168, use_res):
  *     fi = torch.gather(f, -1, idx...); identity = self.skipconv(fi); ...; f = self.act(f + identity)
  * forward:  out (b,cout,m) = relu(y + weight . f[:, :, fps_idx] + bias), f (b,cin,n), fps_idx (b,m) int32 (the FPS picks:
