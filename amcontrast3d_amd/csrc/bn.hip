@@ -380,6 +380,145 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
     }
 }
 
+// ---- short layers: one 1024-thread workgroup per channel does the statistics AND the normalisation (forward) resp. the
+// two sums AND dx (backward) in ONE launch.  The coarse FeaturePropagation stages (>= 64 channels, <= 16 k elements per
+// channel) are a few hundred KB: the second read of the channel comes from L2, and a launch (plus the dependency gap behind
+// it in the captured step) costs more than the pass.  Statistics in fp64 in a fixed order, as in the two-kernel path.
+constexpr int BNC_THREADS = 1024;
+constexpr long BNC_MAX_ELEMS = 16384;  // measured: at 48 k elements per channel (64 workgroups) the two-launch form is faster
+
+__device__ __forceinline__ void block_sum2_f64(double &a, double &b, double (*s_buf)[2])
+{
+    for (int s = 32; s >= 1; s >>= 1) { a += __shfl_xor(a, s, 64); b += __shfl_xor(b, s, 64); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_buf[wave][0] = a; s_buf[wave][1] = b; }
+    __syncthreads();
+    a = 0.0; b = 0.0;
+    for (int w = 0; w < BNC_THREADS / 64; ++w) { a += s_buf[w][0]; b += s_buf[w][1]; }
+}
+
+__global__ __launch_bounds__(BNC_THREADS) void bn_fwd_channel_kernel(int B, int C, long L, int relu, int vec, float eps,
+                                                                      float momentum, const float *__restrict__ x,
+                                                                      const float *__restrict__ gamma,
+                                                                      const float *__restrict__ beta, float *__restrict__ y,
+                                                                      float *__restrict__ mean_out, float *__restrict__ invstd_out,
+                                                                      float *__restrict__ var_out, float *__restrict__ running_mean,
+                                                                      float *__restrict__ running_var, long long *__restrict__ tracked)
+{
+    __shared__ double s_buf[BNC_THREADS / 64][2];
+    __shared__ float s_stat[2];
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float *row = x + ((size_t)b * C + c) * L;
+        if (vec) {
+            for (long i = threadIdx.x * 4L; i < L; i += BNC_THREADS * 4L) {
+                const float4 v = *reinterpret_cast<const float4 *>(row + i);
+                s1 += (double)v.x + (double)v.y + ((double)v.z + (double)v.w);
+                s2 += (double)v.x * (double)v.x + (double)v.y * (double)v.y + ((double)v.z * (double)v.z + (double)v.w * (double)v.w);
+            }
+        } else {
+            for (long i = threadIdx.x; i < L; i += BNC_THREADS) {
+                const float v = row[i];
+                s1 += (double)v;
+                s2 += (double)v * (double)v;
+            }
+        }
+    }
+    block_sum2_f64(s1, s2, s_buf);
+    if (threadIdx.x == 0) {
+        const double cnt = (double)B * (double)L;
+        const double mu = s1 / cnt;
+        double var = s2 / cnt - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)mu, isf = (float)(1.0 / sqrt(var + (double)eps));
+        const float vu = (float)(cnt > 1.0 ? var * cnt / (cnt - 1.0) : var);
+        s_stat[0] = mf; s_stat[1] = isf;
+        mean_out[c] = mf; invstd_out[c] = isf; var_out[c] = vu;
+        if (running_mean && momentum >= 0.f) {
+            running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * mf;
+            running_var[c] = running_var[c] * (1.f - momentum) + momentum * vu;
+            if (c == 0 && tracked) *tracked += 1;
+        }
+    }
+    __syncthreads();
+    const float m = s_stat[0], is = s_stat[1], g = gamma[c], bt = beta[c];
+    for (int b = 0; b < B; ++b) {
+        const float *xr = x + ((size_t)b * C + c) * L;
+        float *yr = y + ((size_t)b * C + c) * L;
+        if (vec) {
+            for (long i = threadIdx.x * 4L; i < L; i += BNC_THREADS * 4L) {
+                float4 v = *reinterpret_cast<const float4 *>(xr + i);
+                v.x = bn_val(v.x, m, is, g, bt); v.y = bn_val(v.y, m, is, g, bt);
+                v.z = bn_val(v.z, m, is, g, bt); v.w = bn_val(v.w, m, is, g, bt);
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4 *>(yr + i) = v;
+            }
+        } else {
+            for (long i = threadIdx.x; i < L; i += BNC_THREADS) {
+                const float v = bn_val(xr[i], m, is, g, bt);
+                yr[i] = relu ? fmaxf(v, 0.f) : v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(BNC_THREADS) void bn_bwd_channel_kernel(int B, int C, long L, int relu, int vec,
+                                                                      const float *__restrict__ x, const float *__restrict__ dy,
+                                                                      const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                                      const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                      float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                                      float *__restrict__ dx)
+{
+    __shared__ double s_buf[BNC_THREADS / 64][2];
+    const int c = blockIdx.x;
+    const float m = mean[c], is = invstd[c], g = gamma[c], bt = beta[c];
+    double sa = 0.0, sb = 0.0;
+    auto term = [&](float d, float xv) {
+        const float xh = __fmul_rn(__fsub_rn(xv, m), is);
+        if (relu && !(__fadd_rn(__fmul_rn(xh, g), bt) > 0.f)) d = 0.f;
+        sa += (double)d;
+        sb += (double)d * (double)xh;
+    };
+    for (int b = 0; b < B; ++b) {
+        const size_t base = ((size_t)b * C + c) * L;
+        if (vec) {
+            for (long i = threadIdx.x * 4L; i < L; i += BNC_THREADS * 4L) {
+                const float4 d4 = *reinterpret_cast<const float4 *>(dy + base + i);
+                const float4 x4 = *reinterpret_cast<const float4 *>(x + base + i);
+                term(d4.x, x4.x); term(d4.y, x4.y); term(d4.z, x4.z); term(d4.w, x4.w);
+            }
+        } else {
+            for (long i = threadIdx.x; i < L; i += BNC_THREADS) term(dy[base + i], x[base + i]);
+        }
+    }
+    block_sum2_f64(sa, sb, s_buf);
+    const double cnt = (double)B * (double)L;
+    const float ma = (float)(sa / cnt), mb = (float)(sb / cnt), gi = __fmul_rn(g, is);
+    if (threadIdx.x == 0) { dbeta[c] = (float)sa; dgamma[c] = (float)sb; }
+    auto one = [&](float xv, float d) {
+        const float xh = __fmul_rn(__fsub_rn(xv, m), is);
+        if (relu && !(__fadd_rn(__fmul_rn(xh, g), bt) > 0.f)) d = 0.f;
+        return gi * (d - ma - xh * mb);
+    };
+    for (int b = 0; b < B; ++b) {
+        const size_t base = ((size_t)b * C + c) * L;
+        if (vec) {
+            for (long i = threadIdx.x * 4L; i < L; i += BNC_THREADS * 4L) {
+                const float4 d4 = *reinterpret_cast<const float4 *>(dy + base + i);
+                const float4 x4 = *reinterpret_cast<const float4 *>(x + base + i);
+                float4 o;
+                o.x = one(x4.x, d4.x); o.y = one(x4.y, d4.y); o.z = one(x4.z, d4.z); o.w = one(x4.w, d4.w);
+                *reinterpret_cast<float4 *>(dx + base + i) = o;
+            }
+        } else {
+            for (long i = threadIdx.x; i < L; i += BNC_THREADS) dx[base + i] = one(x[base + i], dy[base + i]);
+        }
+    }
+}
+
+static bool bn_channel_form(int B, int C, long L) { return C >= 64 && (long)B * L <= BNC_MAX_ELEMS; }
+
 // nn.BatchNorm bookkeeping in ONE launch (torch/nn/modules/batchnorm.py: num_batches_tracked += 1, then the
 // exponential -- or, momentum < 0 standing for None, cumulative -- moving average of mean and unbiased variance)
 __global__ __launch_bounds__(1024) void bn_running_kernel(int C, float momentum, const float *__restrict__ mean,
@@ -520,6 +659,12 @@ AMC_API int amc3d_bn_forward(int B, int C, long L, int K, int relu, float eps, f
     hipStream_t stream = (hipStream_t)stream_;
     const BnSplit sp = bn_split(B, C, L);
     const int vec = (L % 4 == 0) && aligned16(x);
+    if (K == 0 && bn_channel_form(B, C, L) && !(running_mean && momentum < 0.f)) {
+        hipLaunchKernelGGL(bn_fwd_channel_kernel, dim3(C), dim3(BNC_THREADS), 0, stream, B, C, L, relu, vec && aligned16(y), eps,
+                           momentum, x, gamma, beta, y, mean, invstd, var_unbiased, running_mean, running_var,
+                           num_batches_tracked);
+        return launch_status("amc3d_bn_forward");
+    }
     hipLaunchKernelGGL(bn_stats_kernel, dim3(sp.nchunks, C), dim3(BN_THREADS), 0, stream, B, C, L, sp, vec, x,
                        (double *)workspace);
     BnFused f{};
@@ -565,6 +710,11 @@ AMC_API int amc3d_bn_backward(int B, int C, long L, int K, int relu, const float
     const int nchunks = sp.nchunks;
     const int vec = (L % 4 == 0) && (K % 4 == 0 || !mode) && aligned16(x) && aligned16(dy) && aligned16(dx) && L < (1L << 31);
     double *partial = (double *)workspace;
+    if (mode == 0 && bn_channel_form(B, C, L)) {
+        hipLaunchKernelGGL(bn_bwd_channel_kernel, dim3(C), dim3(BNC_THREADS), 0, stream, B, C, L, relu, vec, x, dy, mean, invstd,
+                           gamma, beta, dgamma, dbeta, dx);
+        return launch_status("amc3d_bn_backward");
+    }
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nchunks, C), dim3(BN_THREADS), 0, stream, mode, B, C, L, K, relu, sp, vec, x,
                        dy, arg, mean, invstd, gamma, beta, partial);
     const long per_block = BN_THREADS * 16;

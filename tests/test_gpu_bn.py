@@ -9,7 +9,10 @@ DEV = "cuda:0"
 
 
 @pytest.mark.parametrize("shape,relu", [((2, 32, 500, 32), True), ((3, 7, 65, 31), False), ((8, 64, 3000), True),
-                                        ((2, 5, 1), False), ((2, 16, 33, 4), True)])
+                                        ((2, 5, 1), False), ((2, 16, 33, 4), True),
+                                        # one workgroup per channel, one launch (>= 64 channels, <= 16 k elements each); larger ones: two launches
+                                        ((8, 256, 375), True), ((8, 128, 1500), False), ((3, 70, 333), True),
+                                        ((8, 64, 6000), True), ((2, 64, 93, 32), True)])
 def test_bn_act_matches_torch(shape, relu):
     from amcontrast3d_amd.ops import BatchNormAct
     g = torch.Generator().manual_seed(1)
