@@ -1027,107 +1027,94 @@ __global__ __launch_bounds__(256) void bq_grid_kernel(int nq, int n, int m, floa
 // three_nn (interpolate_gpu.cu:16-59) on the grid: the 3 nearest known points of every unknown point, ties
 // resolved as the reference's ascending strict-'<' scan does (the lower index ranks first), i.e. the list is
 // ordered by (distance, index) -- exact without a replay.  Shell expansion and stopping rule as in kg_query.
-__global__ __launch_bounds__(256) void nn3_grid_kernel(int nq, int n, int m, const float *__restrict__ unknown,
-                                                       const GridParams *__restrict__ gp,
-                                                       const int *__restrict__ cell_start,
-                                                       const float4 *__restrict__ sorted, float *__restrict__ dist2,
-                                                       int *__restrict__ idx)
+// One THREAD per query: a 3-NN query meets a dozen candidates in its 27 cells, so a wave per query (the first version of
+// this kernel: 275 us for the 192000 queries of the finest FeaturePropagation level, 104 us now) spends its time in
+// cross-lane bookkeeping; a thread keeps the three best in registers and walks the nine x-runs of its neighbourhood itself,
+// four candidates in flight.  Larger or smaller cells are slower (0.7 x / 1.4 x the calibrated edge: 121 us).
+__global__ __launch_bounds__(256) void nn3_grid_thread_kernel(int nq, int n, int m, const float *__restrict__ unknown,
+                                                              const GridParams *__restrict__ gp,
+                                                              const int *__restrict__ cell_start,
+                                                              const float4 *__restrict__ sorted, float *__restrict__ dist2,
+                                                              int *__restrict__ idx)
 {
-    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
     const GridParams g = *gp;
     const float inf = __builtin_inff();
-    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < nq; q += gridDim.x * 4) {
-        const int bs = q / n;
-        const float qx = unknown[(size_t)q * 3], qy = unknown[(size_t)q * 3 + 1], qz = unknown[(size_t)q * 3 + 2];
-        const int cx = cell_coord(qx, g.minx, g.inv_h, g.nx), cy = cell_coord(qy, g.miny, g.inv_h, g.ny),
-                  cz = cell_coord(qz, g.minz, g.inv_h, g.nz);
-        const int *cs = cell_start + (size_t)bs * g.ncell;
-        float v = inf;            // lanes 0..2: ascending (distance, index)
-        int id = bs * m;          // -> local index 0, the reference's initial besti
-        float tau = inf;
-        int tau_id = 0x7fffffff;
-        auto feed = [&](int b0, int len) {
-            int incl = len;
-            for (int s = 1; s < 64; s <<= 1) {
-                const int o = __shfl_up(incl, s, 64);
-                if (lane >= s) incl += o;
-            }
-            const int total = __builtin_amdgcn_readlane(incl, 63);
-            const int excl = incl - len;
-            const unsigned long long runs = __ballot(len > 0);
-            for (int c0 = 0; c0 < total; c0 += 64) {
-                const int c = c0 + lane;
-                int base = 0;
-                unsigned long long rm = runs;
-                while (rm) {
-                    const int src = (int)__builtin_ctzll(rm);
-                    rm &= rm - 1;
-                    const int e0 = __builtin_amdgcn_readlane(excl, src);
-                    if (e0 >= c0 + 64) break;
-                    base = c >= e0 ? __builtin_amdgcn_readlane(b0, src) - e0 : base;
-                }
-                const bool valid = c < total;
-                const float4 p = sorted[valid ? base + c : __builtin_amdgcn_readfirstlane(base + c)];
-                const float d2 = dist2_ref(qx, qy, qz, p.x, p.y, p.z);
-                const int pi = __float_as_int(p.w);
-                unsigned long long pass = __ballot(valid && (d2 < tau || (d2 == tau && pi < tau_id)));
-                while (pass) {
-                    const int src = (int)__builtin_ctzll(pass);
-                    pass &= pass - 1;
-                    const float cd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), src));
-                    const int ci = __builtin_amdgcn_readlane(pi, src);
-                    if (cd < tau || (cd == tau && ci < tau_id)) {
-                        const int pos = (int)__popcll(__ballot(lane < 3 && (v < cd || (v == cd && id < ci))));
-                        const float upv = lane_below_f32(v);
-                        const int upi = lane_below_i32(id);
-                        if (lane > pos) { v = upv; id = upi; }
-                        if (lane == pos) { v = cd; id = ci; }
-                        tau = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 2));
-                        tau_id = __builtin_amdgcn_readlane(id, 2);
-                    }
-                }
-            }
-        };
-        for (int R = 1;; ++R) {
-            const int side = 2 * R + 1, npairs = side * side;
-            for (int p0 = 0; p0 < npairs; p0 += 64) {
-                const int pi = p0 + lane;
-                int bA = 0, eA = 0, bB = 0, eB = 0;
-                if (pi < npairs) {
-                    const int dz = pi / side - R, dy = pi % side - R;
-                    const int z = cz + dz, y = cy + dy;
-                    if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
-                        const int row = (z * g.ny + y) * g.nx;
-                        const bool rim = R == 1 || dz == -R || dz == R || dy == -R || dy == R;
-                        if (rim) {
-                            bA = cs[row + max(cx - R, 0)];
-                            eA = cs[row + min(cx + R, g.nx - 1) + 1];
-                        } else {
-                            if (cx - R >= 0) { bA = cs[row + cx - R]; eA = cs[row + cx - R + 1]; }
-                            if (cx + R < g.nx) { bB = cs[row + cx + R]; eB = cs[row + cx + R + 1]; }
-                        }
-                    }
-                }
-                feed(bA, eA - bA);
-                if (R > 1) feed(bB, eB - bB);
-            }
-            float dmin = 3.4e38f;
-            bool whole = true;
-            if (cx - R > 0) { dmin = fminf(dmin, qx - (g.minx + (float)(cx - R) * g.h)); whole = false; }
-            if (cx + R + 1 < g.nx) { dmin = fminf(dmin, (g.minx + (float)(cx + R + 1) * g.h) - qx); whole = false; }
-            if (cy - R > 0) { dmin = fminf(dmin, qy - (g.miny + (float)(cy - R) * g.h)); whole = false; }
-            if (cy + R + 1 < g.ny) { dmin = fminf(dmin, (g.miny + (float)(cy + R + 1) * g.h) - qy); whole = false; }
-            if (cz - R > 0) { dmin = fminf(dmin, qz - (g.minz + (float)(cz - R) * g.h)); whole = false; }
-            if (cz + R + 1 < g.nz) { dmin = fminf(dmin, (g.minz + (float)(cz + R + 1) * g.h) - qz); whole = false; }
-            if (whole) break;
-            dmin -= g.margin;
-            if (dmin > 0.f && tau < dmin * dmin * 0.99999f) break;  // strictly nearer than anything unseen
+    const int bs = q / n;
+    const float qx = unknown[(size_t)q * 3], qy = unknown[(size_t)q * 3 + 1], qz = unknown[(size_t)q * 3 + 2];
+    const int cx = cell_coord(qx, g.minx, g.inv_h, g.nx), cy = cell_coord(qy, g.miny, g.inv_h, g.ny),
+              cz = cell_coord(qz, g.minz, g.inv_h, g.nz);
+    const int *cs = cell_start + (size_t)bs * g.ncell;
+    float d0 = inf, d1 = inf, d2 = inf;
+    int i0 = bs * m, i1 = bs * m, i2 = bs * m;  // local index 0: the reference's initial besti
+    auto consider = [&](const float4 p) {
+        const float cd = dist2_ref(qx, qy, qz, p.x, p.y, p.z);
+        const int ci = __float_as_int(p.w);
+        if (cd < d2 || (cd == d2 && ci < i2)) {
+            if (cd < d1 || (cd == d1 && ci < i1)) {
+                d2 = d1; i2 = i1;
+                if (cd < d0 || (cd == d0 && ci < i0)) { d1 = d0; i1 = i0; d0 = cd; i0 = ci; }
+                else { d1 = cd; i1 = ci; }
+            } else { d2 = cd; i2 = ci; }
         }
-        if (lane < 3) {
-            dist2[(size_t)q * 3 + lane] = v;
-            idx[(size_t)q * 3 + lane] = id - bs * m;
+    };
+    auto run = [&](int b0, int e0) {  // four candidates in flight: the walk is a chain of cache latencies otherwise
+        for (int c = b0; c < e0; c += 4) {
+            const int last = e0 - 1;
+            const float4 p0 = sorted[c], p1 = sorted[min(c + 1, last)], p2 = sorted[min(c + 2, last)],
+                         p3 = sorted[min(c + 3, last)];
+            consider(p0);
+            if (c + 1 < e0) consider(p1);
+            if (c + 2 < e0) consider(p2);
+            if (c + 3 < e0) consider(p3);
         }
+    };
+    {   // first shell: the bounds of its nine x-runs as one batch of loads (18 in flight), then the runs
+        const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1) + 1;
+        int rb[9], re[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int z = cz + t / 3 - 1, y = cy + t % 3 - 1;
+            const bool in = z >= 0 && z < g.nz && y >= 0 && y < g.ny;
+            const int row = in ? (z * g.ny + y) * g.nx : 0;
+            rb[t] = in ? cs[row + xa] : 0;
+            re[t] = in ? cs[row + xb] : 0;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) run(rb[t], re[t]);
     }
+    for (int R = 1;; ++R) {
+        for (int dz = -R; R > 1 && dz <= R; ++dz) {
+            const int z = cz + dz;
+            if (z < 0 || z >= g.nz) continue;
+            for (int dy = -R; dy <= R; ++dy) {
+                const int y = cy + dy;
+                if (y < 0 || y >= g.ny) continue;
+                const int row = (z * g.ny + y) * g.nx;
+                const bool rim = R == 1 || dz == -R || dz == R || dy == -R || dy == R;
+                if (rim) {
+                    run(cs[row + max(cx - R, 0)], cs[row + min(cx + R, g.nx - 1) + 1]);
+                } else {
+                    if (cx - R >= 0) run(cs[row + cx - R], cs[row + cx - R + 1]);
+                    if (cx + R < g.nx) run(cs[row + cx + R], cs[row + cx + R + 1]);
+                }
+            }
+        }
+        float dmin = 3.4e38f;
+        bool whole = true;
+        if (cx - R > 0) { dmin = fminf(dmin, qx - (g.minx + (float)(cx - R) * g.h)); whole = false; }
+        if (cx + R + 1 < g.nx) { dmin = fminf(dmin, (g.minx + (float)(cx + R + 1) * g.h) - qx); whole = false; }
+        if (cy - R > 0) { dmin = fminf(dmin, qy - (g.miny + (float)(cy - R) * g.h)); whole = false; }
+        if (cy + R + 1 < g.ny) { dmin = fminf(dmin, (g.miny + (float)(cy + R + 1) * g.h) - qy); whole = false; }
+        if (cz - R > 0) { dmin = fminf(dmin, qz - (g.minz + (float)(cz - R) * g.h)); whole = false; }
+        if (cz + R + 1 < g.nz) { dmin = fminf(dmin, (g.minz + (float)(cz + R + 1) * g.h) - qz); whole = false; }
+        if (whole) break;
+        dmin -= g.margin;
+        if (dmin > 0.f && d2 < dmin * dmin * 0.99999f) break;  // strictly nearer than anything unseen
+    }
+    dist2[(size_t)q * 3] = d0; dist2[(size_t)q * 3 + 1] = d1; dist2[(size_t)q * 3 + 2] = d2;
+    idx[(size_t)q * 3] = i0 - bs * m; idx[(size_t)q * 3 + 1] = i1 - bs * m; idx[(size_t)q * 3 + 2] = i2 - bs * m;
 }
 
 bool grid_search_pays(int b, int n, int m) { return b <= 64 && (long)n * m >= (1L << 21) && (long)b * n >= 4 * KG_SAMPLES; }
@@ -1162,7 +1149,7 @@ int three_nn_grid(int b, int n, int m, const float *unknown, const float *known,
     // cell edge = p80 of the 2nd-neighbour distance among every 2nd known point (~ the 4th neighbour): swept in
     // scratch/nn3_bench.py, 1.0 x that is the fastest
     if (int st = kg_build(w, base, b * m, b * n, b, known, unknown, off_s, off_q, 2, 2, 1.0f, 0.f, stream)) return st;
-    hipLaunchKernelGGL(nn3_grid_kernel, dim3(min(div_up((long)b * n, 4), 256 * 32)), dim3(256), 0, stream, b * n, n, m,
+    hipLaunchKernelGGL(nn3_grid_thread_kernel, dim3(div_up((long)b * n, 256)), dim3(256), 0, stream, b * n, n, m,
                        unknown, (const GridParams *)(base + w.params), (const int *)(base + w.cell_start),
                        (const float4 *)(base + w.sorted), dist2, idx);
     return launch_status("amc3d_three_nn");

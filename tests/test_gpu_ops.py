@@ -193,7 +193,9 @@ def test_three_nn_and_interpolation_golden(dev, ops_fix, tag):
                                         (1, 2000, 1031, "lattice"), (2, 6000, 1500, "room"), (1, 50, 1, "dup"),
                                         # n*m >= 2^21: grid search; lattice/dup = equal distances everywhere
                                         (1, 4000, 1000, "lattice"), (2, 5000, 700, "dup"), (1, 3000, 800, "uniform"),
-                                        (3, 1500, 1500, "room")])
+                                        (3, 1500, 1500, "room"),
+                                        # the finest FeaturePropagation level of the benchmarked step (per cloud)
+                                        (2, 24000, 6000, "room")])
 def test_three_nn_vs_oracle(dev, B, N, M, kind):
     from amcontrast3d_amd import _lib, ops
     from oracle import pointops_ref as K
