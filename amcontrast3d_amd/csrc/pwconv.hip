@@ -389,7 +389,7 @@ AMC_API int amc3d_pointwise_conv_backward(int b, int cin, int cout, long P, cons
                                           size_t workspace_bytes, void *stream_)
 {
     if (b <= 0 || P <= 0) return 0;
-    if (cin <= 0 || cout <= 0 || !weight || !dy) return bad_arg("amc3d_pointwise_conv_backward: bad argument");
+    if (cin <= 0 || cout <= 0 || !dy || (dx && !weight)) return bad_arg("amc3d_pointwise_conv_backward: bad argument");
     hipStream_t stream = (hipStream_t)stream_;
     const bool deep = gemm_conv_pays(cin, cout) && P < (1L << 31);
     if (dx) {

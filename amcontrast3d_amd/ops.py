@@ -1393,15 +1393,26 @@ def sa_residual(y, f, fps_idx, weight, bias):
 
 
 def _library_wgrad(dy3, x3):
-    """dW (Cout,Cin) = sum_b dy[b] . x[b]^T as plain library GEMMs: batched GEMM + sum over the batch, or one GEMM
-    over (batch x positions) where the batched form hits a slow library heuristic (256x256x375: 97 vs 25 us,
-    measured once on MI355X).  The form is a pure function of the shape -- the same in eager and captured runs and on
-    every rank, so the summation order (hence the bits of dW) never depends on timing; AMC3D_WGRAD_FORM=bmm|flat
+    """dW (Cout,Cin) = sum_b dy[b] . x[b]^T of a deep short layer.  Longer layers: batched library GEMM + sum over the
+    batch.  The shortest ones (< 1024 positions per cloud, >= 128 channels: the two coarsest FeaturePropagation levels), where
+    the batched form hits a slow library heuristic (256x256x375: 97 us) and one GEMM over (batch x positions) needs
+    transposed copies of both operands: this library's streaming weight-gradient kernel (csrc/gemm.hip, fixed-order
+    partial sums; the step takes the same time, measured, with 8 copies and 4 library launches fewer).  The form is a pure
+    function of the shape -- the same in eager and captured runs and on every rank; AMC3D_WGRAD_FORM=bmm|flat|own
     overrides it."""
     import os
     B, Cout, P = dy3.shape
     Cin = x3.shape[1]
-    form = os.environ.get("AMC3D_WGRAD_FORM") or ("flat" if P < 1024 and min(Cin, Cout) >= 128 else "bmm")
+    form = os.environ.get("AMC3D_WGRAD_FORM") or ("own" if P < 1024 and min(Cin, Cout) >= 128 else "bmm")
+    if form == "own":
+        lib = _lib.load()
+        dw = torch.empty(Cout, Cin, dtype=torch.float32, device=dy3.device)
+        wb = int(lib.amc3d_pointwise_conv_workspace_bytes(B, Cin, Cout, P))
+        work = torch.empty(max(wb, 4), dtype=torch.uint8, device=dy3.device)
+        with torch.cuda.device(dy3.device):
+            _lib.check(lib.amc3d_pointwise_conv_backward(B, Cin, Cout, P, _ptr(x3), None, _ptr(dy3), None, _ptr(dw), _ptr(work),
+                                                         wb, _stream(dy3)), "pointwise_conv_backward")
+        return dw
     if form == "flat":
         return torch.matmul(dy3.transpose(0, 1).reshape(Cout, B * P), x3.transpose(0, 1).reshape(Cin, B * P).t())
     return torch.bmm(dy3, x3.transpose(1, 2)).sum(0)

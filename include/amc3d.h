@@ -256,7 +256,7 @@ size_t amc3d_pointwise_conv_forward_workspace_bytes(int b, int cin, int cout, lo
 int amc3d_pointwise_conv_forward_ws(int b, int cin, int cout, long P, const float *x, const float *weight,
                                     const float *bias, float *y, void *workspace, size_t workspace_bytes, void *stream);
 size_t amc3d_pointwise_conv_workspace_bytes(int b, int cin, int cout, long P);
-/* dx (b,cin,P) = weight^T . dy (NULL to skip); dweight (cout,cin) = sum_{b,p} dy x^T (NULL to skip; needs
+/* dx (b,cin,P) = weight^T . dy (NULL to skip; weight may then be NULL too); dweight (cout,cin) = sum_{b,p} dy x^T (NULL to skip; needs
  * x and the workspace; summed in a fixed order -> deterministic) */
 int amc3d_pointwise_conv_backward(int b, int cin, int cout, long P, const float *x, const float *weight,
                                   const float *dy, float *dx, float *dweight, void *workspace,
