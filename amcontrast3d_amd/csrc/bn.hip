@@ -156,7 +156,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_kernel(int C, long L, int r
                                                             const float *__restrict__ mean,
                                                             const float *__restrict__ invstd,
                                                             const float *__restrict__ gamma,
-                                                            const float *__restrict__ beta, float *__restrict__ y, BnFused f)
+                                                            const float *__restrict__ beta, float *__restrict__ y, BnFused f,
+                                                            const float *__restrict__ res)
 {
     const int bc = blockIdx.y;  // b * C + c
     const int c = bc % C;
@@ -165,17 +166,23 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_kernel(int C, long L, int r
     const float g = gamma[c], bt = beta[c];
     const float *xr = x + (size_t)bc * L;
     float *yr = y + (size_t)bc * L;
+    const float *rr = res ? res + (size_t)bc * L : nullptr;  // y = [relu](bn(x) + res): the residual of an InvResMLP block
     if ((L & 3) == 0) {
         for (long i = ((long)blockIdx.x * BN_THREADS + threadIdx.x) * 4; i < L; i += (long)gridDim.x * BN_THREADS * 4) {
             float4 v = *reinterpret_cast<const float4 *>(xr + i);
             v.x = bn_val(v.x, m, is, g, bt); v.y = bn_val(v.y, m, is, g, bt);
             v.z = bn_val(v.z, m, is, g, bt); v.w = bn_val(v.w, m, is, g, bt);
+            if (rr) {
+                const float4 r4 = *reinterpret_cast<const float4 *>(rr + i);
+                v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+            }
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             *reinterpret_cast<float4 *>(yr + i) = v;
         }
     } else {
         for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < L; i += (long)gridDim.x * BN_THREADS) {
             float v = bn_val(xr[i], m, is, g, bt);
+            if (rr) v += rr[i];
             yr[i] = relu ? fmaxf(v, 0.f) : v;
         }
     }
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_kernel(
     int mode, int B, int C, long L, int K, int relu, BnSplit sp, int vec, const float *__restrict__ x,
     const float *__restrict__ dy, const unsigned char *__restrict__ arg, const float *__restrict__ mean,
     const float *__restrict__ invstd, const float *__restrict__ gamma, const float *__restrict__ beta,
-    double *__restrict__ partial)
+    double *__restrict__ partial, const float *__restrict__ ymask)
 {
     __shared__ double s_buf[BN_THREADS / 64];
     const int c = blockIdx.y, chunk = blockIdx.x;
@@ -287,11 +294,29 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_kernel(
         sa += (double)d;
         sb += (double)d * (double)xh;
     };
+    // ymask (mode 0): the layer's OUTPUT y = relu(bn(x) + residual); the ReLU passed where y > 0
+    auto term_y = [&](float d, float xv, float yv) {
+        const float xh = __fmul_rn(__fsub_rn(xv, m), is);
+        if (!(yv > 0.f)) d = 0.f;
+        sa += (double)d;
+        sb += (double)d * (double)xh;
+    };
     for (int u = chunk; u < sp.units; u += sp.nchunks) {
         const int b = u / sp.cps, sg = u - b * sp.cps;
         const long l0 = sg * sp.seg, l1 = min(Lq, l0 + sp.seg);
         const size_t base = ((size_t)b * C + c) * Lq;
-        if (mode == 0 && vec) {
+        if (mode == 0 && ymask) {
+            if (vec) {
+                for (long i = l0 + threadIdx.x * 4; i < l1; i += BN_THREADS * 4) {
+                    const float4 d4 = *reinterpret_cast<const float4 *>(dy + base + i);
+                    const float4 x4 = *reinterpret_cast<const float4 *>(x + base + i);
+                    const float4 y4 = *reinterpret_cast<const float4 *>(ymask + base + i);
+                    term_y(d4.x, x4.x, y4.x); term_y(d4.y, x4.y, y4.y); term_y(d4.z, x4.z, y4.z); term_y(d4.w, x4.w, y4.w);
+                }
+            } else {
+                for (long i = l0 + threadIdx.x; i < l1; i += BN_THREADS) term_y(dy[base + i], x[base + i], ymask[base + i]);
+            }
+        } else if (mode == 0 && vec) {
             for (long i = l0 + threadIdx.x * 4; i < l1; i += BN_THREADS * 4) {
                 const float4 d4 = *reinterpret_cast<const float4 *>(dy + base + i);
                 const float4 x4 = *reinterpret_cast<const float4 *>(x + base + i);
@@ -318,7 +343,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
     const unsigned char *__restrict__ arg, const float *__restrict__ mean, const float *__restrict__ invstd,
     const float *__restrict__ gamma, const float *__restrict__ beta, const double *__restrict__ partial, int nchunks,
     double count, const double *__restrict__ count_dev, float *__restrict__ dgamma, float *__restrict__ dbeta,
-    float *__restrict__ dx)
+    float *__restrict__ dx, const float *__restrict__ ymask, float *__restrict__ dres)
 {
     const int bc = blockIdx.y;
     const int c = bc % C;
@@ -345,6 +370,33 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
         if (relu && !(__fadd_rn(__fmul_rn(xh, g), bt) > 0.f)) d = 0.f;
         return gi * (d - ma - xh * mb);
     };
+    if (ymask) {  // mode 0 with a residual: mask from the layer's output, the masked gradient is also the residual's
+        const float *yr = ymask + (size_t)bc * L, *dyr = dy + (size_t)bc * L;
+        float *rr = dres + (size_t)bc * L;
+        auto one_y = [&](float xv, float d) { return gi * (d - ma - __fmul_rn(__fsub_rn(xv, m), is) * mb); };
+        if (vec) {
+            for (long i = ((long)blockIdx.x * BN_THREADS + threadIdx.x) * 4; i < L; i += (long)gridDim.x * BN_THREADS * 4) {
+                const float4 x4 = *reinterpret_cast<const float4 *>(xr + i);
+                const float4 y4 = *reinterpret_cast<const float4 *>(yr + i);
+                float4 d4 = *reinterpret_cast<const float4 *>(dyr + i);
+                if (!(y4.x > 0.f)) d4.x = 0.f;
+                if (!(y4.y > 0.f)) d4.y = 0.f;
+                if (!(y4.z > 0.f)) d4.z = 0.f;
+                if (!(y4.w > 0.f)) d4.w = 0.f;
+                *reinterpret_cast<float4 *>(rr + i) = d4;
+                float4 o;
+                o.x = one_y(x4.x, d4.x); o.y = one_y(x4.y, d4.y); o.z = one_y(x4.z, d4.z); o.w = one_y(x4.w, d4.w);
+                *reinterpret_cast<float4 *>(dr + i) = o;
+            }
+        } else {
+            for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < L; i += (long)gridDim.x * BN_THREADS) {
+                const float d = yr[i] > 0.f ? dyr[i] : 0.f;
+                rr[i] = d;
+                dr[i] = one_y(xr[i], d);
+            }
+        }
+        return;
+    }
     if (vec) {  // L % 4 == 0, K % 4 == 0 in mode 1: the four elements share their pooled position
         const unsigned Lu = (unsigned)L, Ku = (unsigned)K;
         for (unsigned i = (blockIdx.x * BN_THREADS + threadIdx.x) * 4u; i < Lu; i += gridDim.x * BN_THREADS * 4u) {
@@ -609,7 +661,7 @@ AMC_API int amc3d_bn_act(int B, int C, long L, int relu, const float *x, const f
     const long per_block = BN_THREADS * 4 * 4;
     const int gx = (int)min((L + per_block - 1) / per_block, (long)4096);
     hipLaunchKernelGGL(bn_act_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, (hipStream_t)stream, C, L, relu, x, mean,
-                       invstd, gamma, beta, y, BnFused{});
+                       invstd, gamma, beta, y, BnFused{}, (const float *)nullptr);
     return launch_status("amc3d_bn_act");
 }
 
@@ -680,7 +732,7 @@ AMC_API int amc3d_bn_forward(int B, int C, long L, int K, int relu, float eps, f
         const long per_block = BN_THREADS * 4 * 4;
         const int gx = (int)min((L + per_block - 1) / per_block, (long)4096);
         hipLaunchKernelGGL(bn_act_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, stream, C, L, relu, x, mean, invstd, gamma,
-                           beta, y, f);
+                           beta, y, f, (const float *)nullptr);
         st = launch_status("amc3d_bn_forward");
     } else {
         st = launch_bn_max(B, C, (int)(L / K), K, relu, x, mean, invstd, gamma, beta, y, arg, f, stream);
@@ -716,13 +768,74 @@ AMC_API int amc3d_bn_backward(int B, int C, long L, int K, int relu, const float
         return launch_status("amc3d_bn_backward");
     }
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nchunks, C), dim3(BN_THREADS), 0, stream, mode, B, C, L, K, relu, sp, vec, x,
-                       dy, arg, mean, invstd, gamma, beta, partial);
+                       dy, arg, mean, invstd, gamma, beta, partial, (const float *)nullptr);
     const long per_block = BN_THREADS * 16;
     const int gx = (int)min((L + per_block - 1) / per_block, (long)4096);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, stream, mode, C, L, K, relu, vec, x, dy, arg,
                        mean, invstd, gamma, beta, (const double *)partial, nchunks, (double)B * (double)L,
-                       (const double *)nullptr, dgamma, dbeta, dx);
+                       (const double *)nullptr, dgamma, dbeta, dx, (const float *)nullptr, (float *)nullptr);
     return launch_status("amc3d_bn_backward");
+}
+
+// y = relu(bn(x) + res) with batch statistics: the tail of an InvResMLP block (pointnext_AA.py:296-307: pwconv's last
+// Conv1d -> BatchNorm1d without activation, `f += identity`, `self.act(f)`) in the two launches of a plain BatchNorm layer.
+AMC_API int amc3d_bn_residual_forward(int B, int C, long L, float eps, float momentum, const float *x, const float *res,
+                                      const float *gamma, const float *beta, float *y, float *mean, float *invstd,
+                                      float *var_unbiased, float *running_mean, float *running_var,
+                                      long long *num_batches_tracked, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    if (B <= 0 || C <= 0 || L <= 0) return 0;
+    if (!x || !res || !gamma || !beta || !y || !mean || !invstd || !var_unbiased || !workspace ||
+        workspace_bytes < amc3d_bn_workspace_bytes(C) || (running_mean && (!running_var || !num_batches_tracked)))
+        return bad_arg("amc3d_bn_residual_forward: bad argument");
+    if ((L % 4 == 0) && !(aligned16(x) && aligned16(res) && aligned16(y)))
+        return bad_arg("amc3d_bn_residual_forward: x, res and y must be 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    const BnSplit sp = bn_split(B, C, L);
+    const int vec = (L % 4 == 0) && aligned16(x);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(sp.nchunks, C), dim3(BN_THREADS), 0, stream, B, C, L, sp, vec, x,
+                       (double *)workspace);
+    BnFused f{};
+    f.partial = (const double *)workspace;
+    f.nchunks = sp.nchunks;
+    f.count = (double)B * (double)L;
+    f.eps = eps;
+    f.momentum = momentum;
+    f.mean_out = mean; f.invstd_out = invstd; f.var_out = var_unbiased;
+    f.running_mean = running_mean; f.running_var = running_var; f.tracked = num_batches_tracked;
+    const long per_block = BN_THREADS * 4 * 4;
+    const int gx = (int)min((L + per_block - 1) / per_block, (long)4096);
+    hipLaunchKernelGGL(bn_act_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, stream, C, L, 1, x, mean, invstd, gamma, beta, y, f,
+                       res);
+    if (running_mean && momentum < 0.f)
+        hipLaunchKernelGGL(bn_running_kernel, dim3(1), dim3(1024), 0, stream, C, momentum, mean, var_unbiased, running_mean,
+                           running_var, num_batches_tracked);
+    return launch_status("amc3d_bn_residual_forward");
+}
+
+// backward of the same: dq = dy * (y > 0); dres = dq; dx, dgamma, dbeta = BatchNorm backward of dq
+AMC_API int amc3d_bn_residual_backward(int B, int C, long L, const float *x, const float *y, const float *dy,
+                                       const float *mean, const float *invstd, const float *gamma, const float *beta,
+                                       float *dx, float *dres, float *dgamma, float *dbeta, void *workspace,
+                                       size_t workspace_bytes, void *stream_)
+{
+    if (B <= 0 || C <= 0 || L <= 0) return 0;
+    if (!x || !y || !dy || !mean || !invstd || !gamma || !beta || !dx || !dres || !dgamma || !dbeta || !workspace ||
+        workspace_bytes < amc3d_bn_workspace_bytes(C))
+        return bad_arg("amc3d_bn_residual_backward: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const BnSplit sp = bn_split(B, C, L);
+    const int vec = (L % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(dy) && aligned16(dx) && aligned16(dres) &&
+                    L < (1L << 31);
+    double *partial = (double *)workspace;
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(sp.nchunks, C), dim3(BN_THREADS), 0, stream, 0, B, C, L, 1, 1, sp, vec, x, dy,
+                       (const unsigned char *)nullptr, mean, invstd, gamma, beta, partial, y);
+    const long per_block = BN_THREADS * 16;
+    const int gx = (int)min((L + per_block - 1) / per_block, (long)4096);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, stream, 0, C, L, 1, 1, vec, x, dy,
+                       (const unsigned char *)nullptr, mean, invstd, gamma, beta, (const double *)partial, sp.nchunks,
+                       (double)B * (double)L, (const double *)nullptr, dgamma, dbeta, dx, y, dres);
+    return launch_status("amc3d_bn_residual_backward");
 }
 
 // running_mean / running_var / num_batches_tracked update of nn.BatchNorm in training mode; momentum < 0 = None
@@ -787,7 +900,7 @@ AMC_API int amc3d_bn_forward_synced(int B, int C, long L, int K, int relu, float
         const long per_block = BN_THREADS * 4 * 4;
         const int gx = (int)min((L + per_block - 1) / per_block, (long)4096);
         hipLaunchKernelGGL(bn_act_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, stream, C, L, relu, x, mean, invstd, gamma,
-                           beta, y, f);
+                           beta, y, f, (const float *)nullptr);
         st = launch_status("amc3d_bn_forward_synced");
     } else {
         st = launch_bn_max(B, C, (int)(L / K), K, relu, x, mean, invstd, gamma, beta, y, arg, f, stream);
@@ -815,7 +928,7 @@ AMC_API int amc3d_bn_backward_sums(int B, int C, long L, int K, int relu, const 
     const BnSplit sp = bn_split(B, C, mode ? L / K : L);
     const int vec = (L % 4 == 0) && (K % 4 == 0 || !mode) && aligned16(x) && aligned16(dy) && L < (1L << 31);
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(sp.nchunks, C), dim3(BN_THREADS), 0, stream, mode, B, C, L, K, relu, sp, vec,
-                       x, dy, arg, mean, invstd, gamma, beta, (double *)workspace);
+                       x, dy, arg, mean, invstd, gamma, beta, (double *)workspace, (const float *)nullptr);
     hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(C), dim3(64), 0, stream, sp.nchunks, (const double *)workspace, dsums,
                        dbeta, dgamma);
     return launch_status("amc3d_bn_backward_sums");
@@ -836,6 +949,6 @@ AMC_API int amc3d_bn_backward_synced(int B, int C, long L, int K, int relu, cons
     const int gx = (int)min((L + per_block - 1) / per_block, (long)4096);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, (hipStream_t)stream_, mode, C, L, K, relu,
                        vec, x, dy, arg, mean, invstd, gamma, beta, dsums, 1, 0.0, count, (float *)nullptr, (float *)nullptr,
-                       dx);
+                       dx, (const float *)nullptr, (float *)nullptr);
     return launch_status("amc3d_bn_backward_synced");
 }

@@ -306,7 +306,12 @@ class InvResMLP(nn.Module):
     def forward(self, pf, geom=None):
         p, f = pf
         identity = f
-        f = run_convblocks(self.pwconv, self.convs([p, f], geom=geom))
+        agg = self.convs([p, f], geom=geom)
+        if (self.use_res and type(self.act) is nn.ReLU and len(self.pwconv) and agg.shape[-1] == identity.shape[-1]
+                and agg.shape[1] == identity.shape[1]):
+            # `f += identity; act(f)` inside the last BatchNorm's kernels where the block has that form
+            return [p, run_convblocks(self.pwconv, agg, residual=identity)]
+        f = run_convblocks(self.pwconv, agg)
         if f.shape[-1] == identity.shape[-1] and self.use_res:
             f += identity
         return [p, self.act(f)]

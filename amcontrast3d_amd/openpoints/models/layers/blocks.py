@@ -232,15 +232,18 @@ def _pw_pays(conv, x):
     return positions >= 131072 and max(cin, cout) <= 128 or (max(cin, cout) <= 64 and positions >= 32768)
 
 
-def run_convblocks(blocks, x, pool_max=False, pre=None, activated=False):
+def run_convblocks(blocks, x, pool_max=False, pre=None, activated=False, residual=None):
     """Evaluate a stack of conv blocks (the nn.Sequential the factories above build), optionally followed by
     the max over the last (neighbour) dimension.  Where a block is conv -> plain BatchNorm [-> ReLU] in
     training mode, BatchNorm statistics, normalisation, ReLU and (for the last block) the max-pool run as
     fused gfx950 kernels (amcontrast3d_amd/csrc/bn.hip); everything else runs the stored modules as they are.
     Parameters, buffers and their bookkeeping stay those of the nn modules.
     `pre`: the already computed output of the first block's convolution (the fused gather+conv kernel).
-    `activated`: x is the activated output of a first block evaluated elsewhere (fused_first_block); `blocks` are the rest."""
-    from amcontrast3d_amd.ops import BatchNormAct, BatchNormMax, SyncBatchNormFused
+    `activated`: x is the activated output of a first block evaluated elsewhere (fused_first_block); `blocks` are the rest.
+    `residual`: the result is relu(stack(x) + residual) -- an InvResMLP block's `f += identity; act(f)` -- inside the last
+    block's BatchNorm kernels where that block is conv -> plain training-mode BatchNorm without activation."""
+    from amcontrast3d_amd.ops import BatchNormAct, BatchNormMax, BatchNormResidualAct, SyncBatchNormFused
+    res_done = False
     mods = list(blocks)
     pooled = False
     fused = _sa_tail_activated(mods, x, pool_max) if activated else _sa_tail(mods, pool_max, pre)
@@ -270,6 +273,10 @@ def run_convblocks(blocks, x, pool_max=False, pre=None, activated=False):
                 if last and pool_max and y.dim() == 4 and y.shape[-1] <= 255:
                     x, _, _ = BatchNormMax.apply(y, bn.weight, bn.bias, bn.eps, relu, bn)
                     pooled = True
+                elif (last and residual is not None and not relu and not pool_max and residual.shape == y.shape
+                      and residual.is_cuda and residual.dtype == torch.float32 and not os.environ.get("AMC3D_NO_BN_RESIDUAL")):
+                    x, _, _ = BatchNormResidualAct.apply(y, residual, bn.weight, bn.bias, bn.eps, bn)
+                    res_done = True
                 else:
                     x, _, _ = BatchNormAct.apply(y, bn.weight, bn.bias, bn.eps, relu, bn)
             else:
@@ -286,6 +293,8 @@ def run_convblocks(blocks, x, pool_max=False, pre=None, activated=False):
                 x = blk(x)
     if pool_max and not pooled:
         x = torch.max(x, dim=-1, keepdim=False)[0]
+    if residual is not None and not res_done:
+        x = torch.relu(x + residual)
     return x
 
 

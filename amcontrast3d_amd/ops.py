@@ -651,6 +651,53 @@ class BatchNormAct(Function):
         return dx, dgamma, dbeta, None, None, None
 
 
+class BatchNormResidualAct(Function):
+    """y = relu(batch_norm(x) + res) with batch statistics: the tail of an InvResMLP block (pointnext_AA.py:296-307: the
+    last Conv1d -> BatchNorm1d of pwconv, `f += identity`, `self.act(f)`) in the two launches of a plain BatchNorm layer;
+    backward: dres = dy * (y > 0) and the BatchNorm backward of that, two launches.  Returns (y, mean, unbiased variance)."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps, bn=None):
+        _need_gpu(x, res, gamma, beta)
+        _need_dtype(torch.float32, x=x, res=res, gamma=gamma, beta=beta)
+        x, res = x.contiguous(), res.contiguous()
+        assert x.shape == res.shape
+        B, C = x.shape[0], x.shape[1]
+        L = x.numel() // (B * C)
+        dev = x.device
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty_like(mean)
+        var_u = torch.empty_like(mean)
+        y = torch.empty_like(x)
+        work, wb = _bn_ws(C, dev)
+        mom, rm, rv, nbt = _bn_running_args(bn)
+        with torch.cuda.device(dev), timing.span("bn_residual_forward", x.numel() * 16):
+            _lib.check(_lib.load().amc3d_bn_residual_forward(B, C, L, float(eps), mom, _ptr(x), _ptr(res), _ptr(gamma), _ptr(beta),
+                                                             _ptr(y), _ptr(mean), _ptr(invstd), _ptr(var_u), rm, rv, nbt,
+                                                             _ptr(work), wb, _stream(x)), "bn_residual_forward")
+        ctx.save_for_backward(x, y, gamma, beta, mean, invstd)
+        ctx.mark_non_differentiable(mean, var_u)
+        ctx.set_materialize_grads(False)
+        return y, mean, var_u
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, y, gamma, beta, mean, invstd = ctx.saved_tensors
+        B, C = x.shape[0], x.shape[1]
+        L = x.numel() // (B * C)
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        work, wb = _bn_ws(C, x.device, extra=C * 8)
+        with torch.cuda.device(x.device), timing.span("bn_residual_backward", x.numel() * 28):
+            _lib.check(_lib.load().amc3d_bn_residual_backward(B, C, L, _ptr(x), _ptr(y), _ptr(dy), _ptr(mean), _ptr(invstd),
+                                                              _ptr(gamma), _ptr(beta), _ptr(dx), _ptr(dres), _ptr(dgamma),
+                                                              _ptr(dbeta), _ptr(work), wb, _stream(x)), "bn_residual_backward")
+        return dx, dres, dgamma, dbeta, None, None
+
+
 @torch.no_grad()
 def bn_update_running(bn, mean, var_unbiased):
     """nn.BatchNorm's training-mode buffer update (num_batches_tracked, running_mean, running_var) in one launch."""

@@ -485,6 +485,18 @@ int amc3d_bn_backward_synced(int B, int C, long L, int K, int relu, const float 
                              const unsigned char *arg, const float *mean, const float *invstd, const float *gamma,
                              const float *beta, const double *dsums, const double *count, float *dx, void *stream);
 
+/* ---- tail of an InvResMLP block (openpoints/models/backbone/pointnext_AA.py:296-307): y = relu(batch_norm(x) + res) with
+ * batch statistics -- the last Conv1d -> BatchNorm1d of pwconv, `f += identity`, `self.act(f)` -- in the two launches of a
+ * plain BatchNorm layer; backward: dres = dy * (y > 0), dx / dgamma / dbeta = BatchNorm backward of that.  x, res, y, dy,
+ * dx, dres (B,C,L) fp32; workspace: amc3d_bn_workspace_bytes(C). */
+int amc3d_bn_residual_forward(int B, int C, long L, float eps, float momentum, const float *x, const float *res,
+                              const float *gamma, const float *beta, float *y, float *mean, float *invstd,
+                              float *var_unbiased, float *running_mean, float *running_var,
+                              long long *num_batches_tracked, void *workspace, size_t workspace_bytes, void *stream);
+int amc3d_bn_residual_backward(int B, int C, long L, const float *x, const float *y, const float *dy, const float *mean,
+                               const float *invstd, const float *gamma, const float *beta, float *dx, float *dres,
+                               float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- gradient-norm clipping + AdamW over all parameter tensors in two launches ---------------------
  * Replaces  torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm, norm_type=2); optimizer.step()  with
  * torch.optim.AdamW (examples/segmentation/main_AA.py:586-592; optimizer built by openpoints/optim/optim_factory.py:160-230).

@@ -48,6 +48,71 @@ def test_bn_act_matches_torch(shape, relu):
         assert torch.allclose(var_u, x.var(dims, unbiased=True), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 24000), (3, 7, 65), (8, 128, 1500), (2, 64, 6001), (2, 16, 33, 4)])
+def test_bn_residual_act_matches_torch(shape):
+    """relu(bn(x) + res): the tail of an InvResMLP block (pointnext_AA.py:296-307) in the BatchNorm kernels"""
+    from amcontrast3d_amd.ops import BatchNormResidualAct
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(shape, generator=g) * 3 + 1.5).to(DEV)
+    res = torch.randn(shape, generator=g).to(DEV)
+    C = shape[1]
+    gamma = (torch.rand(C, generator=g) - 0.3).to(DEV)
+    beta = torch.randn(C, generator=g).to(DEV)
+    go = torch.randn(shape, generator=g).to(DEV)
+
+    def ref(dtype):
+        leaves = [t.to(dtype).requires_grad_(True) for t in (x, res, gamma, beta)]
+        y = torch.relu(torch.nn.functional.batch_norm(leaves[0], None, None, leaves[2], leaves[3], True, 0.1, 1e-5) + leaves[1])
+        y.backward(go.to(dtype))
+        return [y.detach()] + [t.grad for t in leaves]
+
+    leaves = [t.clone().requires_grad_(True) for t in (x, res, gamma, beta)]
+    y, mean, var_u = BatchNormResidualAct.apply(leaves[0], leaves[1], leaves[2], leaves[3], 1e-5)
+    y.backward(go)
+    r64, r32 = ref(torch.float64), ref(torch.float32)
+    for got, a64, a32 in zip([y] + [t.grad for t in leaves], r64, r32):
+        err = float((got.double() - a64).abs().max())
+        err_torch = float((a32.double() - a64).abs().max())
+        scale = max(1.0, float(a64.abs().max()))
+        assert err <= max(2 * err_torch, 1e-5 * scale), (err, err_torch)
+    dims = [0] + list(range(2, x.dim()))
+    assert torch.allclose(mean, x.mean(dims), atol=1e-5)
+
+
+def test_invresmlp_fused_residual_equals_unfused(monkeypatch):
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from amcontrast3d_amd import timing
+    from openpoints.models.backbone.pointnext_AA import InvResMLP
+    from openpoints.utils import EasyConfig
+    torch.manual_seed(0)
+    ga = EasyConfig(); ga.update({'NAME': 'ballquery', 'radius': 0.2, 'nsample': 32})
+    blk = InvResMLP(32, norm_args={'norm': 'bn'}, act_args={'act': 'relu'}, group_args=ga, expansion=4).to(DEV).train()
+    p = torch.rand(2, 1500, 3, device=DEV)
+    f = torch.randn(2, 32, 1500, device=DEV)
+    go = torch.randn(2, 32, 1500, device=DEV)
+    state = {k: v.clone() for k, v in blk.state_dict().items()}
+
+    def run():
+        blk.load_state_dict(state)
+        for q in blk.parameters():
+            q.grad = None
+        fi = f.clone().requires_grad_(True)
+        with timing.count_calls() as calls:
+            out = blk([p, fi])[1]
+            out.backward(go)
+        return out.detach(), fi.grad, [q.grad.clone() for q in blk.parameters()], dict(calls)
+
+    o1, d1, g1, c1 = run()
+    monkeypatch.setenv("AMC3D_NO_BN_RESIDUAL", "1")
+    o0, d0, g0, c0 = run()
+    assert c1.get("bn_residual_forward") == 1 and c1.get("bn_residual_backward") == 1 and "bn_residual_forward" not in c0, (c1, c0)
+    assert float((o1 - o0).abs().max()) <= 1e-5 * float(o0.abs().max())
+    assert float((d1 - d0).norm()) <= 1e-4 * float(d0.norm())
+    for a, b in zip(g1, g0):
+        assert float((a - b).norm()) <= 1e-4 * float(b.norm()) + 1e-7
+
+
 @pytest.mark.parametrize("shape,relu", [((2, 32, 500, 32), False), ((2, 16, 100, 32), True), ((3, 9, 17, 5), False)])
 def test_bn_max_matches_torch(shape, relu):
     from amcontrast3d_amd.ops import BatchNormMax
