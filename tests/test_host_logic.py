@@ -145,7 +145,8 @@ def test_c_abi_exports_every_declared_symbol():
     # no torch / libc10 dependency in the boundary library
     import subprocess
     deps = subprocess.run(["ldd", so], capture_output=True, text=True).stdout
-    assert "torch" not in deps and "c10" not in deps
+    names = [line.split()[0] for line in deps.splitlines() if line.split()]  # library names only: a load address may
+    assert not any("torch" in n or "c10" in n for n in names), names               # well contain the digits "c10"
 
 
 def test_compat_modules_have_the_reference_entry_points():
