@@ -50,6 +50,27 @@ def test_matches_clip_grad_norm_plus_torch_adamw(clip):
         assert float(sb["state"][k]["step"]) == float(sa["state"][k]["step"])  # per parameter: one of them skipped a step
 
 
+def test_large_model_two_level_norm():
+    """more than 2048 chunks of 1024 elements (PointNeXt-XL has 40 k): the chunk norms are folded by an extra launch"""
+    from amcontrast3d_amd.fused_optim import FusedAdamW
+    g = torch.Generator().manual_seed(2)
+    shapes = [(1024, 1024), (777, 513), (2048, 700, 1), (4097,), (1,)]
+    a = [torch.randn(*s, generator=g).to(DEV).requires_grad_(True) for s in shapes]
+    b = [p.detach().clone().requires_grad_(True) for p in a]
+    ref = torch.optim.AdamW(a, lr=1e-2, weight_decay=1e-2)
+    got = FusedAdamW(b, lr=1e-2, weight_decay=1e-2)
+    for it in range(3):
+        for p, q in zip(a, b):
+            gr = torch.randn(p.shape, generator=g).to(DEV)
+            p.grad, q.grad = gr.clone(), gr.clone()
+        want_norm = torch.nn.utils.clip_grad_norm_(a, 10.0, norm_type=2)
+        ref.step()
+        norm = got.step(max_grad_norm=10.0)
+        assert abs(float(norm) - float(want_norm)) <= 1e-5 * float(want_norm)
+        for p, q in zip(a, b):
+            assert float((p - q).detach().abs().max()) <= 2e-6 * max(1.0, float(p.detach().abs().max()))
+
+
 def test_state_dict_round_trip_and_resume_from_torch_adamw():
     from amcontrast3d_amd.fused_optim import FusedAdamW
     a, b, c = _params(3), _params(3), _params(3)
