@@ -309,8 +309,29 @@ __global__ __launch_bounds__(1024) void gcc_reduce_partials_kernel(int total, in
     }
 }
 
+// <= 16 partials (the wide, short layers of PointNeXt-XL: a 4096 x 1024 weight over 124 positions has two): a thread sums
+// four outputs' partials in order -- the value the kernel above produces for nparts <= 16 (one partial per slice, slices added
+// in order), without 1024 threads per 64 outputs (96 -> 15 us for 4 M outputs)
+__global__ __launch_bounds__(256) void gcc_reduce_few_kernel(int total4, int nparts, const float4 *__restrict__ partial,
+                                                             float4 *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    float4 t = partial[i];
+    for (int k = 1; k < nparts; ++k) {
+        const float4 v = partial[(size_t)k * total4 + i];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    out[i] = t;
+}
+
 int reduce_partials(int total, int nparts, const float *partial, float *out, hipStream_t stream)
 {
+    if (nparts >= 1 && nparts <= 16 && total % 4 == 0 && total >= 65536 && (((uintptr_t)partial | (uintptr_t)out) & 15) == 0) {
+        hipLaunchKernelGGL(gcc_reduce_few_kernel, dim3(div_up(total / 4, 256)), dim3(256), 0, stream, total / 4, nparts,
+                           (const float4 *)partial, (float4 *)out);
+        return launch_status("reduce_partials");
+    }
     hipLaunchKernelGGL(gcc_reduce_partials_kernel, dim3(div_up(total, 64)), dim3(1024), 0, stream, total, nparts, partial, out);
     return launch_status("reduce_partials");
 }

@@ -29,6 +29,10 @@ SHAPES = [  # B, Cin, Cout, spatial, bias
     (8, 128, 256, (375,), True),
     (2, 768, 256, (96,), False),
     (2, 256, 96, (200,), False),      # cout <= 128 but short: backward-data on the tiled GEMM as well
+    # the wide, short layers of PointNeXt-XL (InvResMLP 512 -> 2048 over 2 x 248 positions): a handful of partials per
+    # weight gradient, summed by the few-partials reduction
+    (2, 512, 2048, (248,), False),
+    (2, 1024, 256, (64,), False),
 ]
 
 
