@@ -60,6 +60,37 @@ AMC_API int amc3d_stream_create_masked(void **stream, int first_cu, int n_cus)
 
 AMC_API int amc3d_stream_create_dedicated(void **stream) { return amc3d_stream_create_masked(stream, 0, 0); }
 
+// the same with an arbitrary mask: word i, bit j enables CU 32 i + j
+AMC_API int amc3d_stream_create_cu_mask(void **stream, const unsigned int *mask, int words)
+{
+    if (!stream || !mask || words <= 0 || words > 32) return amc::bad_arg("amc3d_stream_create_cu_mask: bad argument");
+    hipStream_t s = nullptr;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
+    if (e != hipSuccess) { amc::set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e)); return (int)e; }
+    *stream = (void *)s;
+    return 0;
+}
+
+// Diagnostic for planning CU masks: out[b] = the XCD (HW_REG_XCC_ID, 0-7) workgroup b of an nblocks-wide launch on `stream`
+// ran on.  Which mask bits belong to which XCD is not documented; a masked stream answers it.
+namespace amc {
+__global__ void probe_xcc_kernel(int *__restrict__ out)
+{
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15);
+    // stay resident for a moment so that the dispatcher has to spread the workgroups over everything the mask allows
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < 20000) {}
+}
+}  // namespace amc
+
+AMC_API int amc3d_probe_xcc_ids(int nblocks, int *out, void *stream)
+{
+    if (nblocks <= 0) return 0;
+    if (!out) return amc::bad_arg("amc3d_probe_xcc_ids: null pointer");
+    hipLaunchKernelGGL(amc::probe_xcc_kernel, dim3(nblocks), dim3(64), 0, (hipStream_t)stream, out);
+    return amc::launch_status("amc3d_probe_xcc_ids");
+}
+
 AMC_API int amc3d_stream_destroy(void *stream)
 {
     if (!stream) return 0;

@@ -47,6 +47,10 @@ const char *amc3d_last_error(void);
 int amc3d_stream_create_dedicated(void **stream);
 /* the same with a CU mask that enables bits [first_cu, first_cu + n_cus) only (n_cus <= 0: every CU) */
 int amc3d_stream_create_masked(void **stream, int first_cu, int n_cus);
+/* the same with an arbitrary mask (word i, bit j enables CU 32 i + j), and a diagnostic for planning such masks:
+ * out[b] = the XCD (0-7) workgroup b of an nblocks-wide launch on `stream` ran on */
+int amc3d_stream_create_cu_mask(void **stream, const unsigned int *mask, int words);
+int amc3d_probe_xcc_ids(int nblocks, int *out, void *stream);
 int amc3d_stream_destroy(void *stream);
 
 /* ---- pointnet2_batch surface ------------------------------------------------ */
