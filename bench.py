@@ -440,7 +440,8 @@ def main():
         # AMC3D_CU_MASK="" turns the masks off.
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
         # (measured for the two-lane configuration only: with more lanes -- 64k / 120k-point clouds -- no mask by default)
-        geo_cus = (9 * ncu // 16 if (a2_rides or fps_all) else 3 * ncu // 4) if lanes == 2 else 0
+        # (re-swept at the end of round 2, after the 3-NN / residual-branch changes: 9/16 7.22, 10/16 7.17, 12/16 7.24)
+        geo_cus = (10 * ncu // 16 if (a2_rides or fps_all) else 3 * ncu // 4) if lanes == 2 else 0
         cum = {k: (int(a), int(b)) for k, a, b in
                (v.split(":") for v in os.environ.get("AMC3D_CU_MASK", f"geo:0:{geo_cus}").split(",") if v)}
         q = {k: _ops.dedicated_stream(dev, *cum.get(k, (0, 0))) for k in qplan.split(",")}
