@@ -428,3 +428,49 @@ AMC_API int amc3d_bias_grad(int b, int c, long P, const float *dy, float *dbias,
     hipLaunchKernelGGL(pw_bias_grad_kernel, dim3(c), dim3(1024), 0, (hipStream_t)stream, b, c, P, dy, dbias, vec);
     return launch_status("amc3d_bias_grad");
 }
+
+// ---- a 1x1-conv weight cut into two column blocks, and the two gradient blocks joined again, one launch each ------------
+// (the neighbourhood layers' W = [W_dp | W_f], pointnext_AA.py:57-63 after get_aggregation_feautres' concatenation, and the
+// FeaturePropagation conv's [W_skip | W_up], :210-226: as tensor slices that is two copies forward and a concatenation
+// backward per layer, 36 + 18 launches per PointNeXt-L step)
+namespace amc {
+__global__ void split_columns_kernel(long total, int c1, int c2, const float *__restrict__ w, float *__restrict__ a,
+                                     float *__restrict__ b)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long r = i / (c1 + c2);
+    const int c = (int)(i - r * (c1 + c2));
+    if (c < c1) a[r * c1 + c] = w[i]; else b[r * c2 + (c - c1)] = w[i];
+}
+
+__global__ void join_columns_kernel(long total, int c1, int c2, const float *__restrict__ a, const float *__restrict__ b,
+                                    float *__restrict__ w)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long r = i / (c1 + c2);
+    const int c = (int)(i - r * (c1 + c2));
+    w[i] = c < c1 ? a[r * c1 + c] : b[r * c2 + (c - c1)];
+}
+}  // namespace amc
+
+// w (rows, c1 + c2) -> a (rows, c1), b (rows, c2)
+AMC_API int amc3d_split_columns(int rows, int c1, int c2, const float *w, float *a, float *b, void *stream)
+{
+    if (rows <= 0 || c1 < 0 || c2 < 0 || c1 + c2 == 0) return 0;
+    if (!w || (c1 && !a) || (c2 && !b)) return bad_arg("amc3d_split_columns: null pointer");
+    const long total = (long)rows * (c1 + c2);
+    hipLaunchKernelGGL(split_columns_kernel, dim3(div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, total, c1, c2, w, a, b);
+    return launch_status("amc3d_split_columns");
+}
+
+// a (rows, c1), b (rows, c2) -> w (rows, c1 + c2)
+AMC_API int amc3d_join_columns(int rows, int c1, int c2, const float *a, const float *b, float *w, void *stream)
+{
+    if (rows <= 0 || c1 < 0 || c2 < 0 || c1 + c2 == 0) return 0;
+    if (!w || (c1 && !a) || (c2 && !b)) return bad_arg("amc3d_join_columns: null pointer");
+    const long total = (long)rows * (c1 + c2);
+    hipLaunchKernelGGL(join_columns_kernel, dim3(div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, total, c1, c2, a, b, w);
+    return launch_status("amc3d_join_columns");
+}

@@ -1046,7 +1046,7 @@ class LocalAggregationFused(Function):
         dev = f.device
         lib = _lib.load()
         w2 = weight.reshape(C, Cin + 3)
-        w_dp, w_f = w2[:, :3].contiguous(), w2[:, 3:].contiguous()
+        w_dp, w_f = _split_columns(w2, 3)
         g_cm = torch.empty(B, C, N, dtype=torch.float32, device=dev)
         g_pm = torch.empty(B, N, C, dtype=torch.float32, device=dev)
         pooled = torch.empty(B, C, M, dtype=torch.float32, device=dev)
@@ -1129,7 +1129,7 @@ class LocalAggregationFused(Function):
                              2.0 * B * N * Cin * C * (1 + int(need_f))):
                 _lib.check(pw_bwd(B, Cin, C, N, _ptr(f), _ptr(w_f), _ptr(dg_cm), _ptr(df) if need_f else None, _ptr(dw_f),
                                   _ptr(work2), wb2, _stream(f)), "pointwise_conv_backward")
-        dw = torch.cat((dw_dp, dw_f), dim=1).view(ctx.wshape)
+        dw = _join_columns(dw_dp, dw_f).view(ctx.wshape)
         return df, None, None, None, dw, dgamma, dbeta, None, None, None, None
 
 
@@ -1154,7 +1154,7 @@ class GroupedConvBN(Function):
         lib = _lib.load()
         ctx.csr = csr  # (rev_start, rev_edge) of ops.group_csr, or None: backward then scatters with float atomics
         w2 = weight.reshape(C, Cin + 3)
-        w_dp, w_f = w2[:, :3].contiguous(), w2[:, 3:].contiguous()
+        w_dp, w_f = _split_columns(w2, 3)
         g_cm = torch.empty(B, C, N, dtype=torch.float32, device=dev)
         g_pm = torch.empty(B, N, C, dtype=torch.float32, device=dev)
         x1 = torch.empty(B, C, M, K, dtype=torch.float32, device=dev)
@@ -1243,7 +1243,7 @@ class GroupedConvBN(Function):
                              2.0 * B * N * Cin * C * (1 + int(need_f))):
                 _lib.check(pw_bwd(B, Cin, C, N, _ptr(f), _ptr(w_f), _ptr(dg_cm), _ptr(df) if need_f else None, _ptr(dw_f),
                                   _ptr(work2), wb2, _stream(f)), "pointwise_conv_backward")
-        dw = torch.cat((dw_dp, dw_f), dim=1).view(ctx.wshape)
+        dw = _join_columns(dw_dp, dw_f).view(ctx.wshape)
         return df, None, None, None, dw, dgamma, dbeta, None, None, None, None, None
 
 
@@ -1257,7 +1257,7 @@ def grouped_conv_bn_eval(f, dp, idx, weight, bn, relu):
     dev = f.device
     lib = _lib.load()
     w2 = weight.reshape(C, Cin + 3)
-    w_dp, w_f = w2[:, :3].contiguous(), w2[:, 3:].contiguous()
+    w_dp, w_f = _split_columns(w2, 3)
     g_cm = torch.empty(B, C, N, dtype=torch.float32, device=dev)
     g_pm = torch.empty(B, N, C, dtype=torch.float32, device=dev)
     x1 = torch.empty(B, C, M, K, dtype=torch.float32, device=dev)
@@ -1285,7 +1285,7 @@ def local_aggregation_eval(f, dp, idx, weight, bn, relu):
     dev = f.device
     lib = _lib.load()
     w2 = weight.reshape(C, Cin + 3)
-    w_dp, w_f = w2[:, :3].contiguous(), w2[:, 3:].contiguous()
+    w_dp, w_f = _split_columns(w2, 3)
     g_cm = torch.empty(B, C, N, dtype=torch.float32, device=dev)
     g_pm = torch.empty(B, N, C, dtype=torch.float32, device=dev)
     pooled = torch.empty(B, C, M, dtype=torch.float32, device=dev)
@@ -1357,6 +1357,27 @@ def pointwise_conv(x, weight, bias=None, bf16=False):
     return PointwiseConv.apply(x, weight, bias, bf16)
 
 
+def _split_columns(w2, c1):
+    """w2 (rows, c1 + c2) fp32 on the GPU -> contiguous (rows, c1), (rows, c2) in one launch (no autograd)"""
+    w2 = w2.detach().contiguous()
+    rows, c2 = w2.shape[0], w2.shape[1] - c1
+    a = torch.empty(rows, c1, dtype=torch.float32, device=w2.device)
+    b = torch.empty(rows, c2, dtype=torch.float32, device=w2.device)
+    with torch.cuda.device(w2.device):
+        _lib.check(_lib.load().amc3d_split_columns(rows, c1, c2, _ptr(w2), _ptr(a), _ptr(b), _stream(w2)), "split_columns")
+    return a, b
+
+
+def _join_columns(a, b):
+    """(rows, c1), (rows, c2) -> (rows, c1 + c2) in one launch"""
+    a, b = a.contiguous(), b.contiguous()
+    rows, c1, c2 = a.shape[0], a.shape[1], b.shape[1]
+    w = torch.empty(rows, c1 + c2, dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().amc3d_join_columns(rows, c1, c2, _ptr(a), _ptr(b), _ptr(w), _stream(a)), "join_columns")
+    return w
+
+
 class SplitWeight(Function):
     """(w[:, :c1], w[:, c1:]) of a 1x1-conv weight (Cout, C1+C2, 1) as two contiguous (Cout, C) matrices -- the two halves of a
     FeaturePropogation conv applied to the skip features and to the coarse features separately.  As torch slices the
@@ -1367,10 +1388,14 @@ class SplitWeight(Function):
     def forward(ctx, weight, c1):
         w = weight.reshape(weight.shape[0], -1)
         ctx.wshape = tuple(weight.shape)
+        if w.is_cuda and w.dtype == torch.float32:
+            return _split_columns(w, c1)
         return w[:, :c1].contiguous(), w[:, c1:].contiguous()
 
     @staticmethod
     def backward(ctx, g1, g2):
+        if g1.is_cuda and g1.dtype == torch.float32 and g2.dtype == torch.float32:
+            return _join_columns(g1, g2).view(ctx.wshape), None
         return torch.cat((g1, g2), dim=1).view(ctx.wshape), None
 
 

@@ -266,6 +266,10 @@ int amc3d_pointwise_conv_backward(int b, int cin, int cout, long P, const float 
                                   const float *dy, float *dx, float *dweight, void *workspace,
                                   size_t workspace_bytes, void *stream);
 
+/* a weight matrix cut into two column blocks / two gradient blocks joined (the [W_dp | W_f] weight of a neighbourhood layer,
+ * the [W_skip | W_up] weight of a FeaturePropagation conv): w (rows, c1 + c2) <-> a (rows, c1), b (rows, c2), one launch */
+int amc3d_split_columns(int rows, int c1, int c2, const float *w, float *a, float *b, void *stream);
+int amc3d_join_columns(int rows, int c1, int c2, const float *a, const float *b, float *w, void *stream);
 /* dbias (c) = sum_{b,p} dy (b,c,P): bias gradient of a 1x1 convolution with bias (the stem conv and the head's last conv,
  * base_seg.py:236-252, pointnext_AA.py:104-127 with is_head), summed in a fixed order */
 int amc3d_bias_grad(int b, int c, long P, const float *dy, float *dbias, void *stream);
