@@ -19,6 +19,10 @@ def tm(fn, n=10):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(s); g.replay(); g.replay(); b.record(s); torch.cuda.synchronize()
     return a.elapsed_time(b) / (2 * n) * 1000
+if len(sys.argv) > 1 and sys.argv[1] == "xl":  # the pointwise convs of PointNeXt-XL's InvResMLP blocks at 2 x 64000 / 1 x 120000 points
+    shapes = [(2, 64, 256, 16000), (2, 256, 64, 16000), (2, 128, 512, 4000), (2, 512, 128, 4000), (2, 256, 1024, 1000),
+              (2, 1024, 256, 1000), (2, 512, 2048, 250), (2, 2048, 512, 250), (1, 64, 256, 30000), (1, 128, 512, 7500),
+              (1, 512, 128, 7500), (1, 256, 1024, 1875), (1, 512, 2048, 468), (2, 64, 64, 16000), (2, 128, 128, 4000)]
 for B, Ci, Co, P in shapes:
     x = torch.randn(B, Ci, P, device=DEV); w = torch.randn(Co, Ci, 1, device=DEV); go = torch.randn(B, Co, P, device=DEV)
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
