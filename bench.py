@@ -21,7 +21,8 @@ Besides the contract fields the line carries
   roofline_step  the whole step against both roofs: SURVEY 8(d)'s algorithmic bytes and dense FLOPs per step /
                  the measured step time, and the HBM bytes the PMC passes under profiles/ measured
   latency_chain  the FPS chain (runs two steps ahead on a queue of its own): microseconds per dependent iteration
-  ms_per_step_no_overlap   the same parts replayed back to back on one stream
+  ms_per_step_no_overlap   the same parts replayed back to back on one stream (a joint FPS launch once per J steps)
+  single_batch_latency_ms  sum of the parts alone: what ONE batch takes from raw points to updated weights
   cpu_baseline   the oracle's CPU restatement of the SAME step (oracle/model_ref.py on oracle/pointops_ref.c,
                  OpenMP + torch CPU threads) on this box's host cores, rank 0 and N = 1 only: 1 warm-up + 3 timed
                  steps (median, forward / loss / backward split) at 2 clouds, 2 timed steps at the full batch
@@ -391,7 +392,11 @@ def main():
         # eager feature half).  The margin is wide on purpose: a third lane means a fourth dedicated queue, and with more
         # hardware queues than the 4 the runtime schedules natively the S step takes 17 ms instead of 8.7 (measured).
         if t_fps <= 1.5 * t_feat:
-            lanes = 2
+            # (until the end of round 2: two lanes, levels 2-4 as a stage of their own.)  Four batches per joint launch, all
+            # four sampling levels in it (10 ms of chain every fourth step): the sampling queue is busy 2.5 instead of 6 ms per
+            # step and the levels-2-4 stage with its buffers and hand-down is gone -- S 7.17 -> 6.96, L 10.8 -> 10.6,
+            # S-MM 10.0 -> 9.9 ms/step (scratch/ab_lanes.sh; three lanes: 7.01)
+            lanes = 4
         else:
             # long sampling chains (64k / 120k-point clouds): the joint launch runs every level of J batches once per J steps
             # and has to fit into J steps next to a busy chip (the L2-resident kernel slows down there): all levels timed,
@@ -441,7 +446,8 @@ def main():
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
         # (measured for the two-lane configuration only: with more lanes -- 64k / 120k-point clouds -- no mask by default)
         # (re-swept at the end of round 2, after the 3-NN / residual-branch changes: 9/16 7.22, 10/16 7.17, 12/16 7.24)
-        geo_cus = (10 * ncu // 16 if (a2_rides or fps_all) else 3 * ncu // 4) if lanes == 2 else 0
+        # clouds of <= 24576 points (register-resident FPS kernel: the configurations the mask was measured on), any lane count
+        geo_cus = (10 * ncu // 16 if (a2_rides or fps_all) else 3 * ncu // 4) if (lanes == 2 or args.points <= 24576) else 0
         cum = {k: (int(a), int(b)) for k, a, b in
                (v.split(":") for v in os.environ.get("AMC3D_CU_MASK", f"geo:0:{geo_cus}").split(",") if v)}
         q = {k: _ops.dedicated_stream(dev, *cum.get(k, (0, 0))) for k in qplan.split(",")}
@@ -780,6 +786,28 @@ def main():
             torch.cuda.synchronize()
             norms.append(round(float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params if p.grad is not None))), 4))
         print("gradient norms per step:", norms, file=sys.stderr)
+    if os.environ.get("AMC3D_CHECK_BATCHES") and rank == 0 and use_graph and overlap and handover["inputs"] is not None:
+        # diagnostic: after every step, the set the feature half just read must hold ONE batch -- its first-level FPS picks
+        # index ITS points (new_p == pos[fps_idx]), all four sampling levels chain, and the batches come round-robin from the pool
+        seen = []
+        for n in range(4 * period + 8):
+            v = schedule.variants(step_no[0] % period, True)[0]
+            step()
+            torch.cuda.synchronize()
+            batch, fps = handover["inputs"][v]
+            pts = batch["pos"]
+            for lvl in fps:
+                if lvl.get("fps_idx") is None:
+                    continue
+                want = torch.gather(pts, 1, lvl["fps_idx"].unsqueeze(-1).expand(-1, -1, 3))
+                assert torch.equal(want, lvl["new_p"]), f"step {n}: the sampling plan does not belong to the batch the feature half read"
+                pts = lvl["new_p"]
+            seen.append(round(float(batch["pos"].double().sum()), 3))
+        tail = seen[8:]
+        distinct = sorted(set(tail))
+        assert len(distinct) == npool and all(tail[i] == tail[i + npool] for i in range(len(tail) - npool)), seen
+        print(f"batch check: {len(seen)} steps, {len(distinct)} distinct batches round-robin, every step's sampling plan "
+              f"indexes its own points (lanes {lanes}, period {period})", file=sys.stderr)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -967,12 +995,17 @@ def main():
             lvl1 = parts["fps_level1_ms"] if parts else None
             fv = kernels["furthest_point_sampling"]
             its = args.points // 4
+            # all-levels joint launch: the replayed graph is the whole chain of a cloud (n/4 + n/16 + ... iterations)
+            its_timed = sum(args.points // 4 ** k for k in range(1, nlevels)) if fps_all else its
             latency_chain = {"kernel": "furthest_point_sampling", "level1_iterations": its,
-                             "level1_ms": lvl1, "us_per_iteration": round(lvl1 * 1e3 / its, 3) if lvl1 else None,
+                             ("all_levels_ms" if fps_all else "level1_ms"): lvl1, "iterations_timed": its_timed,
+                             "us_per_iteration": round(lvl1 * 1e3 / its_timed, 3) if lvl1 else None,
                              "all_levels_ms_per_step": round(fv["total_ms"] / args.steps, 3),
                              "cus_busy": args.batch, "hbm_bytes_per_launch": traffic.get("furthest_point_sampling", {}).get("bytes_per_launch"),
-                             "note": "serial arg-max chain, off the critical path: the first level of two future batches runs as one launch every "
-                                     "second step on the sampling queue, levels 2-4 every step ahead of it"}
+                             "note": (f"serial arg-max chain, off the critical path: all sampling levels of {lanes} future batches run as one "
+                                      f"launch every {lanes} steps on the sampling queue" if fps_all else
+                                      "serial arg-max chain, off the critical path: the first level of two future batches runs as one launch "
+                                      "every second step on the sampling queue, levels 2-4 every step ahead of it")}
         # the whole step against both roofs (SURVEY 8(d) algorithmic work)
         roofline_step = None
         if args.variant in ALGORITHMIC_PER_POINT and not args.mm:
@@ -1001,7 +1034,11 @@ def main():
                        "global_batch": args.batch * world, "points": args.points,
                        "parallelism": f"dp{world}" + ("+syncbn+ddp" if use_ddp else "+syncbn" if sync_bn else ""),
                        "launch": "hipGraph replay (fwd+loss+bwd | clip+AdamW)" if use_graph else "eager",
-                       "pipeline": (("3 queues: sampling (FPS levels 2-4 of batch t+2 every step, then level 1 of batches t+3 and "
+                       "pipeline": ((f"3 queues: sampling (all FPS levels of {lanes} future batches as one launch every {lanes} steps) | "
+                                     "neighbourhood + loss geometry of batch t+1 (CU-masked) | features of batch t; geometry handed "
+                                     "over without copies (two captured variants each)")
+                                    if (joint and pingpong and fps_all) else
+                                    ("3 queues: sampling (FPS levels 2-4 of batch t+2 every step, then level 1 of batches t+3 and "
                                      "t+4 as one launch every second step) | neighbourhood + loss geometry of batch t+1 (CU-masked) | "
                                      "features of batch t; geometry handed over without copies (two captured variants each)")
                                     if (joint and pingpong) else
@@ -1011,6 +1048,9 @@ def main():
             "loss": round(final_loss, 6),
             "replicas_in_sync": replicas_in_sync,
             "ms_per_step_no_overlap": no_overlap_ms,
+            # one batch through every stage with nothing else on the chip: its sampling chain (all levels; a joint launch takes
+            # as long for J clouds as for one), its neighbourhood / loss geometry, its feature half and update
+            "single_batch_latency_ms": (round(sum(v for v in parts.values() if v), 3) if parts else None),
             "resident_batches": npool,
             "roofline": roofline,
             "roofline_step": roofline_step,
