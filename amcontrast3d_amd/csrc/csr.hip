@@ -114,8 +114,9 @@ __device__ __forceinline__ float csr_bn(float x, float mean, float invstd, float
 //   q[g][c] = sum_e d(e, c),  d = dx1_pm[position e][c] * [relu: bn(G[g][c] + W_dp[c] . dp_e) > 0]
 //   partial sums per channel {sum d, sum d xhat, sum d dp_j}.  dx1_pm is the POSITION-major gradient (b, P, C).
 // grid (point groups, channel chunks of 64, 1); a workgroup takes PTS consecutive source points per wave-group
+constexpr int CSR_BS = 1024;  // threads per workgroup: 1024 / CT point groups share one partial
 template <int CT>
-__global__ __launch_bounds__(256) void csr_collapse_kernel(int C, int n, long P, long G, int relu, const float *__restrict__ dx1_pm,
+__global__ __launch_bounds__(CSR_BS) void csr_collapse_kernel(int C, int n, long P, long G, int relu, const float *__restrict__ dx1_pm,
                                                            const float *__restrict__ g_pm, const int *__restrict__ rev_start,
                                                            const int *__restrict__ rev_edge, const float *__restrict__ dp,
                                                            const float *__restrict__ w_dp, const float *__restrict__ mean,
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void csr_collapse_kernel(int C, int n, long P,
                                                            const float *__restrict__ beta, float *__restrict__ Q,
                                                            double *__restrict__ partial, int pts_per_group)
 {
-    constexpr int GROUPS = 256 / CT;  // point groups per workgroup
+    constexpr int GROUPS = CSR_BS / CT;  // point groups per workgroup
     __shared__ double red[GROUPS][CT][5];
     const int c0 = blockIdx.y * 64;
     const int cl = threadIdx.x % CT, grp = threadIdx.x / CT;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void csr_collapse_kernel(int C, int n, long P,
     }
     red[grp][cl][0] = a0; red[grp][cl][1] = a1; red[grp][cl][2] = a2; red[grp][cl][3] = a3; red[grp][cl][4] = a4;
     __syncthreads();
-    for (int t = threadIdx.x; t < CT * 5; t += 256) {
+    for (int t = threadIdx.x; t < CT * 5; t += CSR_BS) {
         const int k = t / 5, v = t - k * 5;
         double sum = 0.0;
         for (int gq = 0; gq < GROUPS; ++gq) sum += red[gq][k][v];
@@ -307,7 +308,9 @@ AMC_API int amc3d_group_moments_csr(int b, int n, int npoints, int nsample, cons
 
 static int csr_pts_per_group(long G, int groups_per_wg)
 {
-    // ~2048 workgroups
+    // ~2048 workgroups of 1024 threads: a group walks its points one after the other (three dependent round trips each:
+    // list bounds, edge ids, rows), so what counts is FEW points per group -- 3 at SA1 instead of 12: 265 -> 160 us -- while
+    // the number of partial sums (one per workgroup) stays where the finalize kernel reads them quickly
     long per = (G + 2048L * groups_per_wg - 1) / (2048L * groups_per_wg);
     return (int)(per < 1 ? 1 : per);
 }
@@ -316,7 +319,7 @@ namespace amc {
 size_t csr_partials(int b, int cout, int n)
 {
     const int ct = cout < 64 ? cout : 64;
-    const int groups = 256 / ct;
+    const int groups = CSR_BS / ct;
     const long G = (long)b * n;
     const int per = csr_pts_per_group(G, groups);
     return (size_t)div_up(G, (long)groups * per);
@@ -334,12 +337,12 @@ int csr_collapse(int b, int cout, int n, int npoints, int nsample, int relu, con
 {
     const long P = (long)npoints * nsample, G = (long)b * n;
     const int ct = cout < 64 ? cout : 64;
-    const int groups = 256 / ct;
+    const int groups = CSR_BS / ct;
     const int per = csr_pts_per_group(G, groups);
     const int wgs = div_up(G, (long)groups * per);
     *nparts = wgs;
 #define AMC_CSR(CTV)                                                                                                          \
-    hipLaunchKernelGGL(csr_collapse_kernel<CTV>, dim3(wgs, cout / ct), dim3(256), 0, stream, cout, n, P, G, relu, dx1_pm, g_pm, \
+    hipLaunchKernelGGL(csr_collapse_kernel<CTV>, dim3(wgs, cout / ct), dim3(CSR_BS), 0, stream, cout, n, P, G, relu, dx1_pm, g_pm, \
                        rev_start, rev_edge, dp, w_dp, mean, invstd, gamma, beta, Q, partial, per)
     switch (ct) { case 8: AMC_CSR(8); break; case 16: AMC_CSR(16); break; case 32: AMC_CSR(32); break; default: AMC_CSR(64); }
 #undef AMC_CSR

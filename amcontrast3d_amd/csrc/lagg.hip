@@ -405,10 +405,23 @@ __global__ __launch_bounds__(256) void lagg_bwd_finalize_kernel(int C, int npart
     const int c = blockIdx.x;
     double a[5] = {0, 0, 0, 0, 0};
     if (mode == 2) nparts = 1;  // slot 0 holds this rank's reduced sums
-    for (int k = threadIdx.x; k < nparts; k += 256) {
-        const double *p = partial + ((size_t)k * C + c) * 5;
+    {   // four partials in flight per thread (the reverse-list collapse writes up to 8192 of them: a chain of 32 dependent
+        // round trips per thread otherwise); four interleaved sub-sums added in a fixed order
+        double a1[5] = {0, 0, 0, 0, 0}, a2[5] = {0, 0, 0, 0, 0}, a3[5] = {0, 0, 0, 0, 0};
+        int k = threadIdx.x;
+        for (; k + 768 < nparts; k += 1024) {
+            const double *p0 = partial + ((size_t)k * C + c) * 5, *p1 = p0 + (size_t)256 * C * 5, *p2 = p1 + (size_t)256 * C * 5,
+                         *p3 = p2 + (size_t)256 * C * 5;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) a[j] += p[j];
+            for (int j = 0; j < 5; ++j) { a[j] += p0[j]; a1[j] += p1[j]; a2[j] += p2[j]; a3[j] += p3[j]; }
+        }
+        for (; k < nparts; k += 256) {
+            const double *p = partial + ((size_t)k * C + c) * 5;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) a[j] += p[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) a[j] = (a[j] + a1[j]) + (a2[j] + a3[j]);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
