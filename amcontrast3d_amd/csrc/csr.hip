@@ -69,9 +69,16 @@ __global__ void csr_moments_kernel(int n, long P, long G, const int *__restrict_
     const int s = rev_start[g], e = rev_start[g + 1];
     const float *d0 = dp + b * 3 * P, *d1 = d0 + P, *d2 = d1 + P;
     double x = 0.0, y = 0.0, z = 0.0;
-    for (int i = s; i < e; ++i) {
-        const int p = rev_edge[i];
-        x += (double)d0[p]; y += (double)d1[p]; z += (double)d2[p];
+    for (int i = s; i < e; i += 4) {  // four edges' loads in flight (the walk is a chain of dependent round trips otherwise);
+        int p[4];                     // the sums keep the list order
+        float vx[4], vy[4], vz[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = rev_edge[min(i + u, e - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { vx[u] = d0[p[u]]; vy[u] = d1[p[u]]; vz[u] = d2[p[u]]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u < e) { x += (double)vx[u]; y += (double)vy[u]; z += (double)vz[u]; }
     }
     cnt[g] = e - s;
     dfx[g * 3 + 0] = __double2ll_rn(x * CSR_FX_D);
