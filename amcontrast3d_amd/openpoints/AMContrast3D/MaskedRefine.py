@@ -55,6 +55,18 @@ class RefinementMethod:
             neighbor_idx, _ = pointops.knnquery(self.sample_k, xyz, xyz, o, o)  # (b*n, K), one segment
             neighbor_idx = neighbor_idx[..., 1:].contiguous()
         D = self.feature.shape[1]
+        import os
+        if (self.fusion == 'MIN' and self.feature.is_cuda and self.feature.dtype == torch.float32
+                and self.ambiguity.dtype == torch.float32 and neighbor_idx.dtype == torch.int32 and self.feature.dim() == 3
+                and not os.environ.get("AMC3D_NO_FUSED_REFINE")):
+            # the whole rule as two kernels (csrc/refine.hip): same values, same reinterpretations
+            from amcontrast3d_amd import ops
+            self.sample_k -= 1
+            self.feature, count = ops.MaskedRefineDual.apply(self.feature, self.ambiguity, neighbor_idx, self.threshold,
+                                                             self.threshold_max, self.gamma)
+            if RATE_ON_DEVICE or torch.cuda.is_current_stream_capturing():
+                return self.feature, count.to(torch.float32) / self.ambiguity.numel() * 100
+            return self.feature, (count.item() / self.ambiguity.numel()) * 100
         f_rows = self.feature.view(-1, D)      # memory reinterpretation, see the module docstring
         a_rows = self.ambiguity.view(-1, 1)
         self.sample_k -= 1                      # drop the self match

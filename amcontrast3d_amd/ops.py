@@ -1403,6 +1403,50 @@ def split_weight(weight, c1):
     return SplitWeight.apply(weight, c1)
 
 
+class MaskedRefineDual(Function):
+    """RefinementMethod.DualMasks with fusion 'MIN' (openpoints/AMContrast3D/MaskedRefine.py:55-131) on csrc/refine.hip: two
+    launches forward, two backward, instead of ~25 tensor operations per decoder level.  feature (B,D,n) fp32, ambiguity
+    (B,1,n) or (B*n,[1]) fp32 (no gradient: it only enters comparisons and an arg-min), neighbor_idx (B*n, K-1) int32 (a view
+    with a row stride is fine).  -> (refined feature, count of refined points as a 0-dim int32 tensor)."""
+
+    @staticmethod
+    def forward(ctx, feature, ambiguity, neighbor_idx, threshold, threshold_max, gamma):
+        _need_gpu(feature, ambiguity, neighbor_idx)
+        _need_dtype(torch.float32, feature=feature, ambiguity=ambiguity)
+        _need_dtype(torch.int32, neighbor_idx=neighbor_idx)
+        f = feature.contiguous()
+        a = ambiguity.detach().contiguous().view(-1)
+        B, D, n = f.shape
+        assert a.numel() == B * n and neighbor_idx.dim() == 2 and neighbor_idx.shape[0] == B * n
+        nptr, k, stride, keep = _nbr_view(neighbor_idx)
+        dev = f.device
+        lib = _lib.load()
+        out = torch.empty_like(f)
+        best = torch.empty(B * n, dtype=torch.int32, device=dev)
+        mask = torch.empty(B * n, dtype=torch.uint8, device=dev)
+        count = torch.empty((), dtype=torch.int32, device=dev)
+        work = torch.empty(max(int(lib.amc3d_masked_refine_workspace_ints(B * n)), 1), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev), timing.span("masked_refine_forward", f.numel() * 12 + B * n * (4 * k + 13)):
+            _lib.check(lib.amc3d_masked_refine_forward(B, D, n, k, stride, _ptr(f), _ptr(a), nptr, float(threshold),
+                                                       float(threshold_max), float(gamma), _ptr(out), _ptr(best), _ptr(mask),
+                                                       _ptr(count), _ptr(work), _stream(f)), "masked_refine_forward")
+        ctx.save_for_backward(best, mask)
+        ctx.gamma = float(gamma)
+        ctx.mark_non_differentiable(count)
+        return out, count
+
+    @staticmethod
+    def backward(ctx, dout, _dcount):
+        best, mask = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, D, n = dout.shape
+        df = torch.empty_like(dout)
+        with torch.cuda.device(dout.device), timing.span("masked_refine_backward", dout.numel() * 12):
+            _lib.check(_lib.load().amc3d_masked_refine_backward(B, D, n, ctx.gamma, _ptr(dout), _ptr(best), _ptr(mask), _ptr(df),
+                                                                _stream(dout)), "masked_refine_backward")
+        return df, None, None, None, None, None
+
+
 class SAResidual(Function):
     """out = relu(y + skipconv(f[:, :, fps_idx])): the residual branch of a strided SetAbstraction block with use_res
     (pointnext_AA.py:157-168: torch.gather -> Conv1d with bias -> add -> ReLU) on csrc/sa_res.hip -- one launch forward;

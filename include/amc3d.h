@@ -505,6 +505,22 @@ int amc3d_bn_residual_backward(int B, int C, long L, const float *x, const float
                                const float *invstd, const float *gamma, const float *beta, float *dx, float *dres,
                                float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- masked refinement of AMContrast3D++, the DualMasks rule with fusion 'MIN' (openpoints/AMContrast3D/MaskedRefine.py:55-131,
+ * called per decoder level by models/backbone/pointnext_MM.py:541-560): points whose predicted ambiguity a lies in
+ * [threshold, threshold_max] take the feature row of their least ambiguous neighbour,
+ *     out = gamma * (f * ~mask + f_rows[best] * mask) + (1 - gamma) * f,
+ * with the reference's two reinterpretations kept (f (B,D,n) viewed as (B*n, D) rows for the gather, the mask (B,1,n) broadcast
+ * in the (B,D,n) indexing).  f, out, dout, df (B,D,n) fp32; a (B*n) fp32; nbr (B*n, k) int32 with row stride nbr_stride (self
+ * match dropped); outputs kept for the backward: best (B*n) int32, mask (B*n) bytes; count (1) int32 = refined points.
+ * Backward: df = (gamma * dout) * ~mask + (1 - gamma) * dout, plus gamma * dout of the masked elements added to row best[r]
+ * (float atomics, like torch's index_add). */
+size_t amc3d_masked_refine_workspace_ints(int m);
+int amc3d_masked_refine_forward(int B, int D, int n, int k, int nbr_stride, const float *f, const float *a, const int *nbr,
+                                float threshold, float threshold_max, float gamma, float *out, int *best, unsigned char *mask,
+                                int *count, int *workspace, void *stream);
+int amc3d_masked_refine_backward(int B, int D, int n, float gamma, const float *dout, const int *best, const unsigned char *mask,
+                                 float *df, void *stream);
+
 /* ---- gradient-norm clipping + AdamW over all parameter tensors in two launches ---------------------
  * Replaces  torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm, norm_type=2); optimizer.step()  with
  * torch.optim.AdamW (examples/segmentation/main_AA.py:586-592; optimizer built by openpoints/optim/optim_factory.py:160-230).
