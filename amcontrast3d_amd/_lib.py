@@ -73,6 +73,8 @@ SIGNATURES = {
     "amc3d_masked_refine_workspace_ints": (_sz, [_i]),
     "amc3d_masked_refine_forward": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_masked_refine_backward": (_i, [_i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_bn_sigmoid_forward": (_i, [_i, _i, _l, _f, _f] + [_vp] * 10 + [_vp, _sz, _vp]),
+    "amc3d_bn_sigmoid_backward": (_i, [_i, _i, _l] + [_vp] * 10 + [_vp, _sz, _vp]),
     "amc3d_bias_grad": (_i, [_i, _i, _l, _vp, _vp, _vp]),
     "amc3d_sa_residual_forward": (_i, [_i, _i, _i, _i, _i] + [_vp] * 8),
     "amc3d_sa_residual_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -91,6 +91,8 @@ __global__ void bn_finalize_kernel(int C, int nchunks, double count, float eps, 
     var_unbiased[c] = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
 }
 
+__device__ __forceinline__ float bn_sigmoid(float v) { return __fdiv_rn(1.f, __fadd_rn(1.f, expf(-v))); }
+
 __device__ __forceinline__ float bn_val(float x, float mean, float invstd, float gamma, float beta)
 {
     return __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(x, mean), invstd), gamma), beta);
@@ -176,14 +178,16 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_kernel(int C, long L, int r
                 const float4 r4 = *reinterpret_cast<const float4 *>(rr + i);
                 v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
             }
-            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (relu == 2) {  // sigmoid (the APM towers of AMContrast3D++: Linear -> BatchNorm1d -> Sigmoid)
+                v.x = bn_sigmoid(v.x); v.y = bn_sigmoid(v.y); v.z = bn_sigmoid(v.z); v.w = bn_sigmoid(v.w);
+            } else if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             *reinterpret_cast<float4 *>(yr + i) = v;
         }
     } else {
         for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < L; i += (long)gridDim.x * BN_THREADS) {
             float v = bn_val(xr[i], m, is, g, bt);
             if (rr) v += rr[i];
-            yr[i] = relu ? fmaxf(v, 0.f) : v;
+            yr[i] = relu == 2 ? bn_sigmoid(v) : (relu ? fmaxf(v, 0.f) : v);
         }
     }
 }
@@ -297,7 +301,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_kernel(
     // ymask (mode 0): the layer's OUTPUT y = relu(bn(x) + residual); the ReLU passed where y > 0
     auto term_y = [&](float d, float xv, float yv) {
         const float xh = __fmul_rn(__fsub_rn(xv, m), is);
-        if (!(yv > 0.f)) d = 0.f;
+        if (relu == 2) d = d * (yv * (1.f - yv));  // sigmoid: dy * y (1 - y), y = the layer's output
+        else if (!(yv > 0.f)) d = 0.f;
         sa += (double)d;
         sb += (double)d * (double)xh;
     };
@@ -372,26 +377,30 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
     };
     if (ymask) {  // mode 0 with a residual: mask from the layer's output, the masked gradient is also the residual's
         const float *yr = ymask + (size_t)bc * L, *dyr = dy + (size_t)bc * L;
-        float *rr = dres + (size_t)bc * L;
+        float *rr = dres ? dres + (size_t)bc * L : nullptr;
         auto one_y = [&](float xv, float d) { return gi * (d - ma - __fmul_rn(__fsub_rn(xv, m), is) * mb); };
         if (vec) {
             for (long i = ((long)blockIdx.x * BN_THREADS + threadIdx.x) * 4; i < L; i += (long)gridDim.x * BN_THREADS * 4) {
                 const float4 x4 = *reinterpret_cast<const float4 *>(xr + i);
                 const float4 y4 = *reinterpret_cast<const float4 *>(yr + i);
                 float4 d4 = *reinterpret_cast<const float4 *>(dyr + i);
-                if (!(y4.x > 0.f)) d4.x = 0.f;
-                if (!(y4.y > 0.f)) d4.y = 0.f;
-                if (!(y4.z > 0.f)) d4.z = 0.f;
-                if (!(y4.w > 0.f)) d4.w = 0.f;
-                *reinterpret_cast<float4 *>(rr + i) = d4;
+                if (relu == 2) {
+                    d4.x *= y4.x * (1.f - y4.x); d4.y *= y4.y * (1.f - y4.y); d4.z *= y4.z * (1.f - y4.z); d4.w *= y4.w * (1.f - y4.w);
+                } else {
+                    if (!(y4.x > 0.f)) d4.x = 0.f;
+                    if (!(y4.y > 0.f)) d4.y = 0.f;
+                    if (!(y4.z > 0.f)) d4.z = 0.f;
+                    if (!(y4.w > 0.f)) d4.w = 0.f;
+                }
+                if (dres) *reinterpret_cast<float4 *>(rr + i) = d4;
                 float4 o;
                 o.x = one_y(x4.x, d4.x); o.y = one_y(x4.y, d4.y); o.z = one_y(x4.z, d4.z); o.w = one_y(x4.w, d4.w);
                 *reinterpret_cast<float4 *>(dr + i) = o;
             }
         } else {
             for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < L; i += (long)gridDim.x * BN_THREADS) {
-                const float d = yr[i] > 0.f ? dyr[i] : 0.f;
-                rr[i] = d;
+                const float d = relu == 2 ? dyr[i] * (yr[i] * (1.f - yr[i])) : (yr[i] > 0.f ? dyr[i] : 0.f);
+                if (dres) rr[i] = d;
                 dr[i] = one_y(xr[i], d);
             }
         }
@@ -836,6 +845,64 @@ AMC_API int amc3d_bn_residual_backward(int B, int C, long L, const float *x, con
                        (const unsigned char *)nullptr, mean, invstd, gamma, beta, (const double *)partial, sp.nchunks,
                        (double)B * (double)L, (const double *)nullptr, dgamma, dbeta, dx, y, dres);
     return launch_status("amc3d_bn_residual_backward");
+}
+
+// y = sigmoid(bn(x)) with batch statistics (the APM towers of AMContrast3D++, openpoints/AMContrast3D/APM/concatenation.py:
+// nn.Linear -> nn.BatchNorm1d -> nn.Sigmoid six times per tower) in the two launches of a plain BatchNorm layer, and its backward
+// (dq = dy * y (1 - y) from the saved output, then BatchNorm backward) in two
+AMC_API int amc3d_bn_sigmoid_forward(int B, int C, long L, float eps, float momentum, const float *x, const float *gamma,
+                                     const float *beta, float *y, float *mean, float *invstd, float *var_unbiased,
+                                     float *running_mean, float *running_var, long long *num_batches_tracked, void *workspace,
+                                     size_t workspace_bytes, void *stream_)
+{
+    if (B <= 0 || C <= 0 || L <= 0) return 0;
+    if (!x || !gamma || !beta || !y || !mean || !invstd || !var_unbiased || !workspace ||
+        workspace_bytes < amc3d_bn_workspace_bytes(C) || (running_mean && (!running_var || !num_batches_tracked)))
+        return bad_arg("amc3d_bn_sigmoid_forward: bad argument");
+    if ((L % 4 == 0) && !(aligned16(x) && aligned16(y))) return bad_arg("amc3d_bn_sigmoid_forward: x and y must be 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    const BnSplit sp = bn_split(B, C, L);
+    const int vec = (L % 4 == 0) && aligned16(x);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(sp.nchunks, C), dim3(BN_THREADS), 0, stream, B, C, L, sp, vec, x,
+                       (double *)workspace);
+    BnFused f{};
+    f.partial = (const double *)workspace;
+    f.nchunks = sp.nchunks;
+    f.count = (double)B * (double)L;
+    f.eps = eps;
+    f.momentum = momentum;
+    f.mean_out = mean; f.invstd_out = invstd; f.var_out = var_unbiased;
+    f.running_mean = running_mean; f.running_var = running_var; f.tracked = num_batches_tracked;
+    const long per_block = BN_THREADS * 4 * 4;
+    const int gx = (int)min((L + per_block - 1) / per_block, (long)4096);
+    hipLaunchKernelGGL(bn_act_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, stream, C, L, 2, x, mean, invstd, gamma, beta, y, f,
+                       (const float *)nullptr);
+    if (running_mean && momentum < 0.f)
+        hipLaunchKernelGGL(bn_running_kernel, dim3(1), dim3(1024), 0, stream, C, momentum, mean, var_unbiased, running_mean,
+                           running_var, num_batches_tracked);
+    return launch_status("amc3d_bn_sigmoid_forward");
+}
+
+AMC_API int amc3d_bn_sigmoid_backward(int B, int C, long L, const float *x, const float *y, const float *dy, const float *mean,
+                                      const float *invstd, const float *gamma, const float *beta, float *dx, float *dgamma,
+                                      float *dbeta, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    if (B <= 0 || C <= 0 || L <= 0) return 0;
+    if (!x || !y || !dy || !mean || !invstd || !gamma || !beta || !dx || !dgamma || !dbeta || !workspace ||
+        workspace_bytes < amc3d_bn_workspace_bytes(C))
+        return bad_arg("amc3d_bn_sigmoid_backward: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const BnSplit sp = bn_split(B, C, L);
+    const int vec = (L % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(dy) && aligned16(dx) && L < (1L << 31);
+    double *partial = (double *)workspace;
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(sp.nchunks, C), dim3(BN_THREADS), 0, stream, 0, B, C, L, 1, 2, sp, vec, x, dy,
+                       (const unsigned char *)nullptr, mean, invstd, gamma, beta, partial, y);
+    const long per_block = BN_THREADS * 16;
+    const int gx = (int)min((L + per_block - 1) / per_block, (long)4096);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, B * C), dim3(BN_THREADS), 0, stream, 0, C, L, 1, 2, vec, x, dy,
+                       (const unsigned char *)nullptr, mean, invstd, gamma, beta, (const double *)partial, sp.nchunks,
+                       (double)B * (double)L, (const double *)nullptr, dgamma, dbeta, dx, y, (float *)nullptr);
+    return launch_status("amc3d_bn_sigmoid_backward");
 }
 
 // running_mean / running_var / num_batches_tracked update of nn.BatchNorm in training mode; momentum < 0 = None

@@ -48,14 +48,25 @@ class APM_pf_ConCate(nn.Module):
         (rows = points, BatchNorm1d over the rows) without flatten / permute copies and without handing
         (B*n) x 35 -> 32 -> ... -> 1 products to a GEMM library (hipBLASLt spends ~4 ms per step on them at
         B*n = 192000).  -> (B*n, 1)"""
-        from amcontrast3d_amd.ops import BatchNormAct, mixed_precision, pointwise_conv
+        import os
+        from amcontrast3d_amd.ops import BatchNormAct, BatchNormSigmoid, mixed_precision, pointwise_conv
         from openpoints.models.layers.blocks import _fusable_bn
         x = torch.cat((p.transpose(1, 2), f), dim=1).contiguous()
-        for mod in tower:
+        mods = list(tower)
+        fuse = not os.environ.get("AMC3D_NO_BN_SIGMOID")
+        skip = False
+        for i, mod in enumerate(mods):
+            if skip:  # the Sigmoid that the BatchNorm in front of it has already applied
+                skip = False
+                continue
             if isinstance(mod, nn.Linear):
                 x = pointwise_conv(x, mod.weight.unsqueeze(-1), mod.bias, mixed_precision())
             elif isinstance(mod, nn.BatchNorm1d):
-                x = BatchNormAct.apply(x, mod.weight, mod.bias, mod.eps, False, mod)[0] if _fusable_bn(mod, x) else mod(x)
+                if _fusable_bn(mod, x) and fuse and i + 1 < len(mods) and type(mods[i + 1]) is nn.Sigmoid:
+                    x = BatchNormSigmoid.apply(x, mod.weight, mod.bias, mod.eps, mod)[0]  # BatchNorm + Sigmoid, two launches
+                    skip = True
+                else:
+                    x = BatchNormAct.apply(x, mod.weight, mod.bias, mod.eps, False, mod)[0] if _fusable_bn(mod, x) else mod(x)
             else:  # Dropout (p = 0 in the shipped configs), Sigmoid
                 x = mod(x)
         return x.reshape(-1, 1)  # (B,1,n) -> (B*n,1): same memory order as the flattened rows

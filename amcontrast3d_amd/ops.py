@@ -698,6 +698,50 @@ class BatchNormResidualAct(Function):
         return dx, dres, dgamma, dbeta, None, None
 
 
+class BatchNormSigmoid(Function):
+    """y = sigmoid(batch_norm(x)) with batch statistics: nn.BatchNorm1d -> nn.Sigmoid of the APM towers of AMContrast3D++
+    (openpoints/AMContrast3D/APM/concatenation.py:20-60) in the two launches of a plain BatchNorm layer; backward from the saved
+    output (dy * y (1 - y), then BatchNorm backward), two launches.  Returns (y, mean, unbiased variance)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, bn=None):
+        _need_gpu(x, gamma, beta)
+        _need_dtype(torch.float32, x=x, gamma=gamma, beta=beta)
+        x = x.contiguous()
+        B, C = x.shape[0], x.shape[1]
+        L = x.numel() // (B * C)
+        dev = x.device
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty_like(mean)
+        var_u = torch.empty_like(mean)
+        y = torch.empty_like(x)
+        work, wb = _bn_ws(C, dev)
+        mom, rm, rv, nbt = _bn_running_args(bn)
+        with torch.cuda.device(dev), timing.span("bn_sigmoid_forward", x.numel() * 12):
+            _lib.check(_lib.load().amc3d_bn_sigmoid_forward(B, C, L, float(eps), mom, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y),
+                                                            _ptr(mean), _ptr(invstd), _ptr(var_u), rm, rv, nbt, _ptr(work), wb,
+                                                            _stream(x)), "bn_sigmoid_forward")
+        ctx.save_for_backward(x, y, gamma, beta, mean, invstd)
+        ctx.mark_non_differentiable(mean, var_u)
+        ctx.set_materialize_grads(False)
+        return y, mean, var_u
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, y, gamma, beta, mean, invstd = ctx.saved_tensors
+        B, C = x.shape[0], x.shape[1]
+        L = x.numel() // (B * C)
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        work, wb = _bn_ws(C, x.device, extra=C * 8)
+        with torch.cuda.device(x.device), timing.span("bn_sigmoid_backward", x.numel() * 24):
+            _lib.check(_lib.load().amc3d_bn_sigmoid_backward(B, C, L, _ptr(x), _ptr(y), _ptr(dy), _ptr(mean), _ptr(invstd),
+                                                             _ptr(gamma), _ptr(beta), _ptr(dx), _ptr(dgamma), _ptr(dbeta),
+                                                             _ptr(work), wb, _stream(x)), "bn_sigmoid_backward")
+        return dx, dgamma, dbeta, None, None
+
+
 @torch.no_grad()
 def bn_update_running(bn, mean, var_unbiased):
     """nn.BatchNorm's training-mode buffer update (num_batches_tracked, running_mean, running_var) in one launch."""

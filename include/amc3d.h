@@ -521,6 +521,17 @@ int amc3d_masked_refine_forward(int B, int D, int n, int k, int nbr_stride, cons
 int amc3d_masked_refine_backward(int B, int D, int n, float gamma, const float *dout, const int *best, const unsigned char *mask,
                                  float *df, void *stream);
 
+/* y = sigmoid(batch_norm(x)) with batch statistics -- nn.BatchNorm1d -> nn.Sigmoid of the APM towers of AMContrast3D++
+ * (openpoints/AMContrast3D/APM/concatenation.py:20-60) -- in the two launches of a plain BatchNorm layer; backward from the saved
+ * output: dq = dy * y (1 - y), then BatchNorm backward.  Layout and workspace as amc3d_bn_forward. */
+int amc3d_bn_sigmoid_forward(int B, int C, long L, float eps, float momentum, const float *x, const float *gamma,
+                             const float *beta, float *y, float *mean, float *invstd, float *var_unbiased,
+                             float *running_mean, float *running_var, long long *num_batches_tracked, void *workspace,
+                             size_t workspace_bytes, void *stream);
+int amc3d_bn_sigmoid_backward(int B, int C, long L, const float *x, const float *y, const float *dy, const float *mean,
+                              const float *invstd, const float *gamma, const float *beta, float *dx, float *dgamma, float *dbeta,
+                              void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- gradient-norm clipping + AdamW over all parameter tensors in two launches ---------------------
  * Replaces  torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm, norm_type=2); optimizer.step()  with
  * torch.optim.AdamW (examples/segmentation/main_AA.py:586-592; optimizer built by openpoints/optim/optim_factory.py:160-230).

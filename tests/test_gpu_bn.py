@@ -79,6 +79,34 @@ def test_bn_residual_act_matches_torch(shape):
     assert torch.allclose(mean, x.mean(dims), atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(8, 32, 6000), (8, 1, 1500), (2, 2, 93), (3, 16, 375), (8, 4, 24000)])
+def test_bn_sigmoid_matches_torch(shape):
+    """sigmoid(bn(x)): BatchNorm1d -> Sigmoid of the APM towers (APM/concatenation.py:20-60)"""
+    from amcontrast3d_amd.ops import BatchNormSigmoid
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(shape, generator=g) * 2 + 0.5).to(DEV)
+    C = shape[1]
+    gamma = (torch.rand(C, generator=g) + 0.3).to(DEV)
+    beta = torch.randn(C, generator=g).to(DEV)
+    go = torch.randn(shape, generator=g).to(DEV)
+
+    def ref(dtype):
+        leaves = [t.to(dtype).requires_grad_(True) for t in (x, gamma, beta)]
+        y = torch.sigmoid(torch.nn.functional.batch_norm(leaves[0], None, None, leaves[1], leaves[2], True, 0.1, 1e-5))
+        y.backward(go.to(dtype))
+        return [y.detach()] + [t.grad for t in leaves]
+
+    leaves = [t.clone().requires_grad_(True) for t in (x, gamma, beta)]
+    y, mean, var_u = BatchNormSigmoid.apply(leaves[0], leaves[1], leaves[2], 1e-5)
+    y.backward(go)
+    r64, r32 = ref(torch.float64), ref(torch.float32)
+    for got, a64, a32 in zip([y] + [t.grad for t in leaves], r64, r32):
+        err = float((got.double() - a64).abs().max())
+        err_torch = float((a32.double() - a64).abs().max())
+        scale = max(1.0, float(a64.abs().max()))
+        assert err <= max(2 * err_torch, 1e-5 * scale), (err, err_torch)
+
+
 def test_invresmlp_fused_residual_equals_unfused(monkeypatch):
     import amcontrast3d_amd
     amcontrast3d_amd.activate()
