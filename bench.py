@@ -399,11 +399,16 @@ def main():
             lanes = 4
         else:
             # long sampling chains (64k / 120k-point clouds): the joint launch runs every level of J batches once per J steps
-            # and has to fit into J steps next to a busy chip (the L2-resident kernel slows down there): all levels timed,
-            # half an eager feature half allowed per batch, at most 8 batches per launch
+            # and has to fit into J steps next to a busy chip (the L2-resident kernel runs 2-3x slower there): all levels
+            # timed, 0.35 eager feature halves allowed per batch, at most 12 batches per launch.  (Until the end of round 2:
+            # half a feature half, at most 8 -- XL-MM at 1 x 120000 points was bound by the chain: 8 batches 25.4, 12 20.9,
+            # 16 22.1 ms/step; 2 x 64000 points: 5 batches 21.0, 8 20.4.)
             nlev = len(list((model.module if hasattr(model, "module") else model).encoder.encoder))
             t_all = _ms(lambda: geometry.precompute_fps_levels(model, data["pos"], 0, nlev), 1)
-            lanes = int(min(8, max(3, -(-t_all // max(0.5 * t_feat, 1e-3)))))
+            lanes = int(min(12, max(3, -(-t_all // max(0.35 * t_feat, 1e-3)))))
+        if rank == 0:
+            print(f"bench.py: sampling chain {t_fps:.1f} ms (first level), eager feature half {t_feat:.1f} ms -> {lanes} batches per "
+                  f"joint FPS launch", file=sys.stderr)
     lanes = max(1, lanes)
     # First-level FPS of TWO future batches as one launch every second step (16 workgroups instead of 8: the kernel is a
     # latency chain, more clouds cost nothing) instead of one launch per step: the sampling queue then delivers a batch
@@ -790,7 +795,8 @@ def main():
         # diagnostic: after every step, the set the feature half just read must hold ONE batch -- its first-level FPS picks
         # index ITS points (new_p == pos[fps_idx]), all four sampling levels chain, and the batches come round-robin from the pool
         seen = []
-        for n in range(4 * period + 8):
+        drain = 4 * lanes + 8  # the initial contents of the in-flight buffers
+        for n in range(3 * period + drain):
             v = schedule.variants(step_no[0] % period, True)[0]
             step()
             torch.cuda.synchronize()
@@ -803,7 +809,7 @@ def main():
                 assert torch.equal(want, lvl["new_p"]), f"step {n}: the sampling plan does not belong to the batch the feature half read"
                 pts = lvl["new_p"]
             seen.append(round(float(batch["pos"].double().sum()), 3))
-        tail = seen[8:]
+        tail = seen[drain:]
         distinct = sorted(set(tail))
         assert len(distinct) == npool and all(tail[i] == tail[i + npool] for i in range(len(tail) - npool)), seen
         print(f"batch check: {len(seen)} steps, {len(distinct)} distinct batches round-robin, every step's sampling plan "

@@ -352,7 +352,8 @@ def test_reference_overlay_and_native_module_registration():
 @pytest.mark.parametrize("lanes,joint,npool,all_levels", [
     (2, True, 4, False), (2, False, 4, False), (2, True, 3, False), (3, False, 4, False), (2, True, 5, False), (1, False, 4, False),
     (3, True, 4, False), (4, True, 4, False), (4, True, 6, False),
-    (3, True, 4, True), (4, True, 4, True), (6, True, 4, True)])   # all_levels: the joint launch runs every sampling level
+    (3, True, 4, True), (4, True, 4, True), (6, True, 4, True),
+    (7, True, 4, True), (12, True, 4, True)])   # all_levels: the joint launch runs every sampling level
 def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, joint, npool, all_levels):
     """bench.py's pipelined loop replayed with batch ids instead of tensors (amcontrast3d_amd/schedule.py holds its index
     arithmetic): at every step the feature half must see ONE batch -- its points, its four FPS levels and its neighbourhood /
@@ -371,11 +372,11 @@ def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, joint
         in_a = [[(3 + lanes * j + t) % npool for t in range(lanes)] for j in range(2)]
         full = (lambda b: (fps1(b), fps2(fps1(b)))) if all_levels else fps1
         a1_out = [[full(b) for b in row] for row in in_a]
-        launched = [[-10] * lanes, [-10] * lanes]
+        launched = [[-10 - lanes] * lanes, [-10 - lanes] * lanes]  # primed before step 0
     else:
         in_a = [(3 + l) % npool for l in range(lanes)]
         a1_out = [fps1(b) for b in in_a]
-        launched = [-10] * lanes
+        launched = [-10 - lanes] * lanes
     a1_stable = fps1(in_a1s)
     a2_out = fps2(a1_stable)
     a_stable = (fps1(in_b), fps2(fps1(in_b)))
