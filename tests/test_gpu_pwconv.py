@@ -156,3 +156,36 @@ def test_pointwise_conv_bf16_compute(B, ci, co, P):
         assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (name, err)
     y32 = torch.einsum("oc,bcp->bop", w.detach().double()[..., 0], x.detach().double()) + bias.detach().double()[None, :, None]
     assert float((y.double() - y32).abs().max()) <= 2 ** -7 * float(y32.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("rows,c1,c2", [(64, 3, 32), (512, 128, 256), (5, 1, 7), (32, 3, 0 + 61)])
+def test_split_and_join_columns(rows, c1, c2):
+    """amc3d_split_columns / amc3d_join_columns: the [W_dp | W_f] and [W_skip | W_up] weight blocks, one launch each way"""
+    from amcontrast3d_amd import ops
+    g = torch.Generator().manual_seed(rows + c1)
+    w = torch.randn(rows, c1 + c2, generator=g).to(DEV)
+    a, b = ops._split_columns(w, c1)
+    assert torch.equal(a, w[:, :c1]) and torch.equal(b, w[:, c1:]) and a.is_contiguous() and b.is_contiguous()
+    assert torch.equal(ops._join_columns(a, b), w)
+    wl = w.clone().reshape(rows, c1 + c2, 1).requires_grad_(True)
+    x, y = ops.split_weight(wl, c1)
+    (x.sum() * 2 + (y * y).sum()).backward()
+    want = torch.cat((torch.full_like(a, 2.0), 2 * b), 1).view(rows, c1 + c2, 1)
+    assert torch.equal(wl.grad, want)
+
+
+@pytest.mark.parametrize("shape", [(8, 32, 24000), (2, 13, 777), (3, 1, 5), (1, 257, 96)])
+def test_bias_grad(shape):
+    import ctypes
+    from amcontrast3d_amd import _lib
+    g = torch.Generator().manual_seed(shape[1])
+    dy = torch.randn(shape, generator=g).to(DEV)
+    db = torch.empty(shape[1], device=DEV)
+    _lib.check(_lib.load().amc3d_bias_grad(shape[0], shape[1], shape[2], ctypes.c_void_p(dy.data_ptr()), ctypes.c_void_p(db.data_ptr()),
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "bias_grad")
+    want = dy.double().sum((0, 2))
+    assert float((db.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    db2 = torch.empty_like(db)
+    _lib.check(_lib.load().amc3d_bias_grad(shape[0], shape[1], shape[2], ctypes.c_void_p(dy.data_ptr()), ctypes.c_void_p(db2.data_ptr()),
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "bias_grad")
+    assert torch.equal(db, db2)  # fixed summation order
