@@ -13,8 +13,9 @@
 //                            (and written once as fi for the weight gradient), the residual, bias and ReLU sit in the epilogue.
 //  * sa_res_mask_kernel      g = dout * (out > 0) (the gradient of BOTH branches), per-cloud bias-gradient sums, and the
 //                            zero-fill of df (only the sampled columns receive a gradient).
-//  * sa_res_bwd_data_kernel  df[:, idx] = W^T . g: the scatter is the epilogue's store (FPS picks of a cloud are distinct:
-//                            plain stores, no atomics); its first workgroup finishes the bias gradient in a fixed order.
+//  * sa_res_bwd_data_kernel  df[:, idx] += W^T . g: the scatter is the epilogue's add into the zero-filled df (repeated picks
+//                            sum, as torch.gather's backward does; one add per address -- deterministic -- where the picks
+//                            are distinct); its first workgroup finishes the bias gradient in a fixed order.
 //  * the weight gradient dW = sum g fi^T is amc3d_pointwise_conv_backward on (g, fi) (deterministic partial sums).
 //
 // The products are tiny (K = 32..256, 744..48000 positions): a 64 x 64 register-blocked fp32 tile per workgroup keeps
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void sa_res_mask_kernel(int cout, int m, const
     }
 }
 
-// df[b][ci][idx[b][p]] = sum_co w[co][ci] g[b][co][p];  workgroup (0,0,0) also sums the bias gradient over the clouds
+// df[b][ci][idx[b][p]] += sum_co w[co][ci] g[b][co][p] (df zero-filled by sa_res_mask_kernel);  workgroup (0,0,0) also sums the bias gradient over the clouds
 template <int KG>
 __global__ __launch_bounds__(256 * KG) void sa_res_bwd_data_kernel(int nb, int cin, int cout, int n, int m,
                                                                    const float *__restrict__ g, const int *__restrict__ idx,
@@ -246,7 +247,10 @@ __global__ __launch_bounds__(256 * KG) void sa_res_bwd_data_kernel(int nb, int c
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = cols[tx * 4 + j];
-            if (col >= 0) row[col] = acc[i][j];
+            // FPS re-picks a point when a cloud holds fewer distinct points than picks (crop_pc pads small rooms by
+            // repetition, data_util.py:161-167): torch.gather's backward sums over repeated indices, so does this -- an add
+            // into the zero-filled df (one add per address, hence still deterministic, wherever the picks are distinct)
+            if (col >= 0) atomicAdd(row + col, acc[i][j]);
         }
     }
 }

@@ -24,8 +24,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # RCCL prints a version banner to STDOUT under NCCL_DEBUG=VERSION/INFO; rank 0's stdout is the one JSON line
-        os.environ["NCCL_DEBUG"] = os.environ.get("AMC3D_NCCL_DEBUG", "WARN")
+        # RCCL prints a version banner to STDOUT under NCCL_DEBUG=VERSION/INFO; rank 0's stdout is the one JSON line.
+        # (A value the user set is kept.)
+        os.environ.setdefault("NCCL_DEBUG", os.environ.get("AMC3D_NCCL_DEBUG", "WARN"))
         if backend is None:  # AMC3D_DIST_BACKEND=gloo: rehearse the multi-rank control flow on a one-GPU box
             backend = os.environ.get("AMC3D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

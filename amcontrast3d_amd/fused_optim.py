@@ -112,14 +112,26 @@ class FusedAdamW(torch.optim.Optimizer):
                                                     ctypes.c_void_p(self._norm.data_ptr()), stream), "adamw_step")
         return self._norm[0] if max_grad_norm else loss
 
+    def zero_grad(self, set_to_none=False):
+        """Zero the gradients IN PLACE by default (torch's default drops the tensors): the device table holds every .grad
+        address, and fresh tensors after each backward would rebuild it -- a host stall and two blocking copies per step"""
+        return super().zero_grad(set_to_none=set_to_none)
+
     # ---- checkpoints: torch's layout in, the flat buffers stay the storage ------------------------
     def load_state_dict(self, state_dict):
         flat = {id(p): (st["exp_avg"], st["exp_avg_sq"], st["step"]) for p, st in self.state.items()}
         super().load_state_dict(state_dict)  # replaces the per-parameter state tensors by the loaded ones
-        for p, st in self.state.items():
-            m, v, step = flat[id(p)]
-            m.copy_(st["exp_avg"])
-            v.copy_(st["exp_avg_sq"])
-            step.copy_(torch.as_tensor(st["step"], dtype=torch.float32))
-            st["exp_avg"], st["exp_avg_sq"], st["step"] = m, v, step
+        # every parameter of the groups, not only those the checkpoint has state for: torch.optim.AdamW creates state lazily,
+        # so a parameter that never received a gradient has no entry in its checkpoints -- its moments restart from zero
+        for g in self.param_groups:
+            for p in g["params"]:
+                m, v, step = flat[id(p)]
+                st = self.state.get(p)
+                if st:
+                    m.copy_(st["exp_avg"])
+                    v.copy_(st["exp_avg_sq"])
+                    step.copy_(torch.as_tensor(st["step"], dtype=torch.float32))
+                else:
+                    m.zero_(); v.zero_(); step.zero_()
+                self.state[p] = {"step": step, "exp_avg": m, "exp_avg_sq": v}
         self._key = None  # learning rates / decays of the groups may have changed

@@ -276,8 +276,8 @@ int amc3d_bias_grad(int b, int c, long P, const float *dy, float *dbias, void *s
 
 /* ---- residual branch of a strided SetAbstraction block (openpoints/models/backbone/pointnext_AA.py:157-168, use_res):
  *     fi = torch.gather(f, -1, idx...); identity = self.skipconv(fi); ...; f = self.act(f + identity)
- * forward:  out (b,cout,m) = relu(y + weight . f[:, :, fps_idx] + bias), f (b,cin,n), fps_idx (b,m) int32 (the FPS picks:
- *           distinct within a cloud), weight (cout,cin), bias (cout) or NULL, y (b,cout,m) = the pooled main branch;
+ * forward:  out (b,cout,m) = relu(y + weight . f[:, :, fps_idx] + bias), f (b,cin,n), fps_idx (b,m) int32 (the FPS picks;
+ *           repeats allowed: their gradients sum, as torch.gather's backward does), weight (cout,cin), bias (cout) or NULL, y (b,cout,m) = the pooled main branch;
  *           fi (b,cin,m) or NULL = the gathered columns, kept for the weight gradient.
  * backward: g (b,cout,m) = dout * (out > 0) -- the gradient w.r.t. y AND w.r.t. the skip conv's output;
  *           df (b,cin,n) or NULL = weight^T . g at the sampled columns, zero elsewhere (written whole: no pre-zeroing);

@@ -140,3 +140,40 @@ def test_replays_in_a_hip_graph():
     torch.cuda.synchronize()
     for p, q in zip(a, b):
         assert float((p - q).abs().max()) <= 3e-6 * max(1.0, float(p.abs().max()))
+
+
+def test_resume_from_a_torch_checkpoint_with_a_stateless_parameter_and_zero_grad_keeps_addresses():
+    """torch.optim.AdamW creates state lazily: a parameter that never had a gradient has no entry in its checkpoints
+    (ADVICE r2).  The fused optimizer restarts that parameter's moments from zero and keeps stepping; zero_grad() zeroes in
+    place, so the device table (which holds every .grad address) is not rebuilt from step to step."""
+    from amcontrast3d_amd.fused_optim import FusedAdamW
+    a, b = _params(9), _params(9)
+    ref = torch.optim.AdamW(_groups(a), lr=1e-2)
+    g = torch.Generator().manual_seed(10)
+    for _ in range(2):
+        for i, p in enumerate(a):
+            p.grad = None if i == 4 else torch.randn(p.shape, generator=g).to(DEV)
+        ref.step()
+    sd = copy.deepcopy(ref.state_dict())
+    assert len(sd["state"]) == len(a) - 1
+    for p, q in zip(a, b):
+        q.data.copy_(p.data)
+    got = FusedAdamW(_groups(b), lr=1e-2)
+    got.load_state_dict(sd)
+    tables = []
+    for _ in range(3):
+        grads = [torch.randn(p.shape, generator=g).to(DEV) for p in a]
+        for p, q, gr in zip(a, b, grads):
+            p.grad = gr.clone()
+            if q.grad is None:
+                q.grad = gr.clone()
+            else:
+                q.grad.copy_(gr)
+        ref.step()
+        got.step()
+        tables.append(got._table.data_ptr())
+        got.zero_grad()
+        assert all(q.grad is not None and float(q.grad.abs().max()) == 0.0 for q in b)
+    assert len(set(tables)) == 1, "the device table was rebuilt although no gradient tensor moved"
+    for p, q in zip(a, b):
+        assert float((p - q).abs().max()) <= 2e-6 * max(1.0, float(p.abs().max()))

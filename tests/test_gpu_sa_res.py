@@ -50,6 +50,28 @@ def test_sa_residual_matches_torch(B, Cin, Cout, N, M):
     assert float(got[2].abs().amax(1)[~hit].max() if (~hit).any() else 0.0) == 0.0
 
 
+def test_sa_residual_sums_over_repeated_picks():
+    """A cloud with fewer distinct points than picks (crop_pc pads small rooms by repetition, dataset/data_util.py:161-167) makes
+    FPS return an index more than once; torch.gather's backward sums the gradient over repeated indices and the fused branch
+    must too (plain stores kept one racing writer's value)."""
+    from amcontrast3d_amd import ops
+    g = torch.Generator().manual_seed(77)
+    B, Cin, Cout, N, M = 2, 32, 64, 600, 300
+    y = torch.randn(B, Cout, M, generator=g).to(DEV)
+    f = torch.randn(B, Cin, N, generator=g).to(DEV)
+    idx = torch.randint(0, 40, (B, M), generator=g).to(torch.int32).to(DEV)  # 300 picks among 40 points: every one repeated
+    w = (torch.randn(Cout, Cin, 1, generator=g) * (1.0 / Cin ** 0.5)).to(DEV)
+    b = (torch.randn(Cout, generator=g) * 0.3).to(DEV)
+    gout = torch.randn(B, Cout, M, generator=g).to(DEV)
+    leaves = [t.clone().requires_grad_(True) for t in (y, f, w, b)]
+    out = ops.sa_residual(leaves[0], leaves[1], idx, leaves[2], leaves[3])
+    out.backward(gout)
+    r64 = reference(y, f, idx, w, b, gout, torch.float64)
+    for name, a, t64 in zip(("out", "dy", "df", "dw", "db"), [out.detach()] + [t.grad for t in leaves], r64):
+        scale = float(t64.abs().max()) + 1e-30
+        assert float((a.double() - t64).abs().max()) / scale <= 1e-5, name
+
+
 def test_sa_residual_is_deterministic_and_graph_safe():
     from amcontrast3d_amd import ops
     g = torch.Generator().manual_seed(5)
