@@ -37,11 +37,21 @@ def _bn(x, sd, prefix, training, eps=1e-5):
                         sd[prefix + ".bias"], False, 0.1, eps)
 
 
-def _convblock(x, sd, prefix, norm, act, training):
+# Tests only: a callable (key, values) that sees every ReLU's pre-activation -- `key` names the per-channel additive
+# parameter in front of it (a BatchNorm's bias, a skip conv's bias), `values` (B,C,...) are the pre-activations whose sign
+# decides where gradient flows (for a ReLU that feeds a max over the neighbours: the row maxima).  tests/test_gpu_layers.py
+# uses it to move those parameters until no pre-activation lies within rounding of zero: at such an element two correct
+# fp32 evaluations disagree on the mask and the gradients differ by a whole term.
+RELU_PROBE = None
+
+
+def _convblock(x, sd, prefix, norm, act, training, pooled_next=False):
     """conv -> [BN] -> [ReLU]  (conv.py:24-102, order 'conv-norm-act')."""
     x = _conv(x, sd, prefix + ".0")
     if norm:
         x = _bn(x, sd, prefix + ".1", training)
+    if act and RELU_PROBE is not None:
+        RELU_PROBE(prefix + (".1.bias" if norm else ".0.bias"), x.detach().amax(-1) if pooled_next else x.detach())
     return F.relu(x) if act else x
 
 
@@ -134,18 +144,86 @@ class PoolRouting:
     in forward order to an arg-max tensor (B,C,M); such a pool returns x gathered at those neighbours instead of
     torch.max's own pick, so the gradient is routed exactly as in the run the indices were taken from (near-ties
     between two neighbours flip under any fp32 reassociation; with the routing held fixed, gradients of two correct
-    implementations agree to rounding).  ``record`` receives torch.max's own indices."""
+    implementations agree to rounding).  ``record`` receives torch.max's own indices.
 
-    def __init__(self, override=None):
-        self.override, self.record, self.seq = override or {}, {}, 0
+    ``compare`` (same mapping) does NOT change the forward: the pool returns its own maximum, and for every pick of
+    ``compare`` that differs from torch.max's own the shortfall  max_k x - x[pick]  is kept relative to the range of the
+    pooled tensor (max |x|; the rows themselves are mostly zeros behind a ReLU, so a row's own spread can be as small as
+    the shortfall): ``flips[i]`` = count, ``gaps[i]`` = the relative shortfalls.  A pick that is not a near-tie of the
+    maximum -- a wrong neighbour -- shows up as a shortfall of the order of the rows' typical spread, 0.1 .. 1 of the range."""
+
+    def __init__(self, override=None, compare=None):
+        self.override, self.compare, self.record, self.seq = override or {}, compare or {}, {}, 0
+        self.flips, self.gaps, self.total = {}, {}, 0
 
     def __call__(self, x):
         i, self.seq = self.seq, self.seq + 1
         val, arg = torch.max(x, dim=-1)
         self.record[i] = arg
+        if i in self.compare:
+            pick = self.compare[i].long()
+            diff = pick != arg
+            self.total += arg.numel()
+            self.flips[i] = int(diff.sum())
+            if self.flips[i]:
+                with torch.no_grad():
+                    short = (val - x.gather(-1, pick.unsqueeze(-1)).squeeze(-1))[diff]
+                    self.gaps[i] = (short / x.abs().max().clamp_min(1e-30)).detach()
         if i in self.override:
             return x.gather(-1, self.override[i].long().unsqueeze(-1)).squeeze(-1)
         return val
+
+
+def set_abstraction(sd, pre, p, f, stride, radius, nsample, sa_layers, use_res, normalize_dp, training=True, pool=None):
+    """SetAbstraction.forward of a strided stage (pointnext_AA.py:139-170): FPS -> gather -> ball query + group -> cat ->
+    [Conv2d 1x1, BN, ReLU] x sa_layers -> max over the neighbours (-> + skip conv of the sampled features, ReLU).
+    ``pre`` = state-dict prefix of the block ('encoder.encoder.{i}.0'); -> (new_p, new_f)."""
+    pool = pool or PoolRouting()
+    idx = K.furthest_point_sample(p, p.shape[1] // stride).long()
+    po = torch.gather(p, 1, idx.unsqueeze(-1).expand(-1, -1, 3))
+    if use_res:
+        fsel = torch.gather(f, -1, idx.unsqueeze(1).expand(-1, f.shape[1], -1))
+        identity = _convblock(fsel, sd, pre + ".skipconv", norm=False, act=False, training=training) \
+            if (pre + ".skipconv.0.weight") in sd else fsel
+    dp, fj, _ = query_and_group(radius, nsample, po.contiguous(), p, f, normalize_dp)
+    x = torch.cat([dp, fj], 1)  # get_aggregation_feautres 'dp_fj' (group.py:323-325)
+    for k in range(sa_layers):
+        last = k == sa_layers - 1
+        x = _convblock(x, sd, f"{pre}.convs.{k}", norm=True, act=not (last and use_res), training=training, pooled_next=last)
+    fo = pool(x)
+    if use_res:
+        fo = fo + identity
+        if RELU_PROBE is not None and (pre + ".skipconv.0.bias") in sd:
+            RELU_PROBE(pre + ".skipconv.0.bias", fo.detach())
+        fo = F.relu(fo)
+    return po, fo
+
+
+def inv_res_mlp(sd, bp, p, f, radius, nsample, normalize_dp, training=True, pool=None):
+    """InvResMLP.forward (pointnext_AA.py:296-307) around LocalAggregation.forward (:57-63): ball query of the cloud on itself
+    -> group -> Conv2d(C+3 -> C) + BN + ReLU -> max -> Conv1d C -> 4C -> C (BN, ReLU after the first) -> + f -> ReLU."""
+    pool = pool or PoolRouting()
+    dp, fj, _ = query_and_group(radius, nsample, p.contiguous(), p.contiguous(), f, normalize_dp)
+    x = _convblock(torch.cat([dp, fj], 1), sd, bp + ".convs.convs.0", norm=True, act=True, training=training, pooled_next=True)
+    x = pool(x)
+    x = _convblock(x, sd, bp + ".pwconv.0", norm=True, act=True, training=training)
+    x = _convblock(x, sd, bp + ".pwconv.1", norm=True, act=False, training=training)
+    x = x + f
+    if RELU_PROBE is not None:
+        RELU_PROBE(bp + ".pwconv.1.1.bias", x.detach())
+    return F.relu(x)
+
+
+def feature_propagation(sd, dpre, p_fine, f_fine, p_coarse, f_coarse, training=True):
+    """FeaturePropogation.forward (pointnext_AA.py:210-226): 3-NN interpolation of the coarse features onto the fine cloud,
+    concatenation with the skip features, [Conv1d, BN1d, ReLU] x layers.  ``dpre`` = 'decoder.decoder.{j}.0'."""
+    up = three_interpolation(p_fine, p_coarse, f_coarse)
+    x = torch.cat((f_fine, up), dim=1)
+    k = 0
+    while f"{dpre}.convs.{k}.0.weight" in sd:
+        x = _convblock(x, sd, f"{dpre}.convs.{k}", norm=True, act=True, training=training)
+        k += 1
+    return x
 
 
 def model_forward(sd, cfg, data, training=True, pool=None):
@@ -173,31 +251,10 @@ def model_forward(sd, cfg, data, training=True, pool=None):
             # stem: point-wise conv, no norm / act (pointnext_AA.py:119-127, 141-142)
             fo, po = _convblock(fi_in, sd, pre + ".convs.0", norm=False, act=False, training=training), pi
         else:
-            # SetAbstraction.forward (pointnext_AA.py:139-170)
-            idx = K.furthest_point_sample(pi, pi.shape[1] // stride).long()
-            po = torch.gather(pi, 1, idx.unsqueeze(-1).expand(-1, -1, 3))
-            use_res = sa_res
-            if use_res:
-                fsel = torch.gather(fi_in, -1, idx.unsqueeze(1).expand(-1, fi_in.shape[1], -1))
-                identity = _convblock(fsel, sd, pre + ".skipconv", norm=False, act=False, training=training) \
-                    if (pre + ".skipconv.0.weight") in sd else fsel
-            dp, fj, _ = query_and_group(radii[i][0], nsamples[i][0], po.contiguous(), pi, fi_in, normalize_dp)
-            x = torch.cat([dp, fj], 1)  # get_aggregation_feautres 'dp_fj' (group.py:323-325)
-            for k in range(sa_layers):
-                last = k == sa_layers - 1
-                x = _convblock(x, sd, f"{pre}.convs.{k}", norm=True, act=not (last and use_res), training=training)
-            fo = pool(x)
-            if use_res:
-                fo = F.relu(fo + identity)
-        # InvResMLP blocks (pointnext_AA.py:269-277, LocalAggregation :57-63)
-        for j in range(1, enc["blocks"][i]):
-            bp = f"encoder.encoder.{i}.{j}"
-            dp, fj, _ = query_and_group(radii[i][j], nsamples[i][j], po.contiguous(), po.contiguous(), fo, normalize_dp)
-            x = _convblock(torch.cat([dp, fj], 1), sd, bp + ".convs.convs.0", norm=True, act=True, training=training)
-            x = pool(x)
-            x = _convblock(x, sd, bp + ".pwconv.0", norm=True, act=True, training=training)
-            x = _convblock(x, sd, bp + ".pwconv.1", norm=True, act=False, training=training)
-            fo = F.relu(x + fo)
+            po, fo = set_abstraction(sd, pre, pi, fi_in, stride, radii[i][0], nsamples[i][0], sa_layers, sa_res,
+                                     normalize_dp, training, pool)
+        for j in range(1, enc["blocks"][i]):  # InvResMLP blocks (pointnext_AA.py:269-277)
+            fo = inv_res_mlp(sd, f"encoder.encoder.{i}.{j}", po, fo, radii[i][j], nsamples[i][j], normalize_dp, training, pool)
         p.append(po)
         f.append(fo)
         if i != nstage - 1:  # pointnext_AA.py:458-462
@@ -210,16 +267,10 @@ def model_forward(sd, cfg, data, training=True, pool=None):
         stage["ambiguity"] = [apm_tower(sd, s, p[s + 1], f[s + 1], training) for s in range(4)]
     rates = []
 
-    # decoder (pointnext_AA.py:508-522; FeaturePropogation.forward :210-226)
+    # decoder (pointnext_AA.py:508-522)
     ndec = 4
     for i in range(-1, -ndec - 1, -1):
-        dpre = f"decoder.decoder.{ndec + i}.0"
-        up = three_interpolation(p[i - 1], p[i], f[i])
-        x = torch.cat((f[i - 1], up), dim=1)
-        k = 0
-        while f"{dpre}.convs.{k}.0.weight" in sd:
-            x = _convblock(x, sd, f"{dpre}.convs.{k}", norm=True, act=True, training=training)
-            k += 1
+        x = feature_propagation(sd, f"decoder.decoder.{ndec + i}.0", p[i - 1], f[i - 1], p[i], f[i], training)
         f[i - 1] = x
         stage["up"][i]["f_out"] = x.transpose(1, 2).reshape(-1, x.shape[1])
         if apm is not None:  # pointnext_MM.py:546-558: refine AFTER the contrastive embedding was taken
@@ -340,6 +391,18 @@ def train_step(sd, cfg, data, target, num_classes, ignore_index, args, pool=None
     grads = {k: v.grad for k, v in leaf.items() if isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None}
     return {"loss": loss.detach(), "ce": ce.detach(), "contrast": [x.detach() for x in parts], "ambiguity": amb,
             "logits": logits.detach(), "grads": grads, "stage": stage}
+
+
+@torch.no_grad()
+def forward_loss(sd, cfg, data, target, num_classes, ignore_index, args, pool=None, mm=False):
+    """forward + loss only, outside autograd (the un-forced forward of the full-size parity tests: the pools return their
+    own maxima; ``pool`` may carry ``compare`` picks)."""
+    logits, stage = model_forward(sd, cfg, data, training=True, pool=pool)
+    if mm:
+        seg, ce, contrast, reg = criterion_mm(logits, target, stage, num_classes, ignore_index, args)
+        return {"loss": seg + reg, "logits": logits, "stage": stage}
+    loss, ce, parts, amb = criterion(logits, target, stage, num_classes, ignore_index, args)
+    return {"loss": loss, "logits": logits, "stage": stage, "contrast": parts, "ambiguity": amb}
 
 
 def criterion_mm(logits, target, stage, num_classes, ignore_index, args):

@@ -3,15 +3,23 @@ restatement of the same train step (forward + CrossEntropyAce / CrossEntropyAceP
 batch, at BASELINE.json's configurations:
 
     cfg 2   PointNeXt-S,  8 x 24000 points (and 2 x 24000, the bench's cpu_baseline sample)
-    cfg 3   PointNeXt-L (width 32, blocks [1,3,5,3,3]), 2 x 24000 points per step of the oracle (the per-GPU batch of 8 is
-            the same kernels on 4x the positions; 2 clouds keep the CPU side at ~10 s)
-    cfg 4   PointNeXt-XL + AMContrast3D++ (MM), 1 x 64000 points (ScanNet-sized cloud, voxel 0.02)
+    cfg 3   PointNeXt-L (width 32, blocks [1,3,5,3,3]), 8 x 24000 points (the per-GPU batch) and 2 x 24000
+    cfg 4   PointNeXt-XL + AMContrast3D++ (MM), 2 x 64000 points (the per-GPU batch; ScanNet-sized clouds, voxel 0.02) and 1 x 64000
+    cfg 5   the same model under bf16 autocast: 1 x 16000 against the oracle under torch.autocast(cpu, bf16); 1 x 120000 by properties
 
 Kernel dispatch is size dependent (blocks._pw_pays, amc3d_sa_tail_pays, grid vs all-pairs searches, library GEMMs
 below 65536 positions), so every case also asserts WHICH operators ran (timing.count_calls): the fused paths the
 bench's numbers come from are the ones compared here.
 
 Tolerances: sampled coordinates (FPS picks) bit-exact; logits, loss, decoder embeddings within 1e-4 (north star).
+
+Forward (round 3): logits, loss and decoder embeddings are compared with the oracle's OWN forward --
+its max-pools return their own maxima, nothing of the product is fed to it.  The arg-max the product used at every pool
+is only COMPARED there (model_ref.PoolRouting(compare=...)): the share of picks that differ from torch.max's must stay
+below FLIP_RATE, and at each differing pick the oracle's maximum may exceed the value at the product's pick by no more
+than a near-tie on the scale on which the two runs' activations differ (a wrong neighbour is a shortfall of 0.1 .. 1 of
+the tensor's range).  Only the gradient comparison below uses the routed oracle.  Per-layer parity at these widths with
+identical layer inputs, where the end-to-end conditioning plays no part, is tests/test_gpu_layers.py.
 
 Gradients.  Two things limit how closely two correct fp32 evaluations of this step agree, and the test removes both
 instead of widening the tolerance (tests/test_gpu_model.py's 3e-2):
@@ -37,6 +45,8 @@ from amcontrast3d_amd import configs
 pytestmark = pytest.mark.gpu
 
 NOISE_FACTOR = 6.0
+FLIP_RATE = 1e-4        # share of max-pool picks that may differ from torch.max's own (measured: S 1e-6, L 1.5e-5)
+FLIP_RATE_XL = 3e-4     # PointNeXt-XL (58 BatchNorm layers deep: the runs' activations differ by 1e-3 .. 1e-2; measured 1.0e-4)
 
 
 def _easy(d):
@@ -94,35 +104,45 @@ def _step(variant, B, N, mm, voxel):
     threads = min(len(os.sched_getaffinity(0)), 16)
     pointops_ref.set_threads(threads)
     torch.set_num_threads(threads)
-    pool = model_ref.PoolRouting({i: a.cpu() for i, a in log.items()})
+    picks = {i: a.cpu() for i, a in log.items()}
+    # (1) the oracle's own forward: nothing of the product enters it; the product's picks are compared, not used
+    watch = model_ref.PoolRouting(compare=picks)
+    own = model_ref.forward_loss(sd, cfg, cpu, cpu["y"], 13, None, aa, pool=watch, mm=mm)
+    assert len(log) == watch.seq, "every max-pool of the model reported its arg-max"
+    # (2) gradients: the routed oracle in fp32 and in fp64
+    pool = model_ref.PoolRouting(picks)
     step = model_ref.train_step_mm if mm else model_ref.train_step
     want = step(sd, cfg, cpu, cpu["y"], 13, None, aa, pool=pool)
-    assert len(log) == pool.seq, "every max-pool of the model reported its arg-max"
     sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd.items()}
     cpu64 = dict(cpu)
     cpu64["x"] = cpu["x"].double()
     truth = step(sd64, cfg, cpu64, cpu["y"], 13, None, aa, pool=model_ref.PoolRouting(pool.override))
     want["grads64"] = truth["grads"]
     want["logits64"], want["loss64"] = truth["logits"], float(truth["loss"])
-    flips = sum(int((pool.record[i] != pool.override[i].long()).sum()) for i in log)
-    total = sum(a.numel() for a in log.values())
-    print(f"[{variant} {B}x{N}{' MM' if mm else ''}] max-pool picks differing from the CPU run's own: {flips} of {total}")
+    want["own"] = own
+    flips = sum(watch.flips.values())
+    gaps = torch.cat(list(watch.gaps.values())) if watch.gaps else torch.zeros(1)
+    want["flips"], want["picks"], want["gap_max"] = flips, watch.total, float(gaps.max())
+    print(f"[{variant} {B}x{N}{' MM' if mm else ''}] max-pool picks differing from the oracle's own: {flips} of {watch.total} "
+          f"({flips / watch.total:.2e}); shortfall at those picks relative to the tensor's range: max {float(gaps.max()):.2e}, "
+          f"median {float(gaps.median()):.2e}")
     return got, want, calls
 
 
-def _compare(got, want, mm):
+def _compare(got, want, mm, flip_rate=FLIP_RATE):
+    own = want["own"]
     for i in range(4):  # FPS picks -> sampled clouds: exact
-        np.testing.assert_array_equal(got["p_out"][i].numpy(), want["stage"]["up"][i]["p_out"].numpy())
-    # logits: 1e-4 (north star) wherever fp32 can deliver it; on the deep variants the CPU oracle's own fp32 run is
-    # further than that from its fp64 run, and the band widens to NOISE_FACTOR x that distance
-    scale = max(1.0, float(want["logits"].abs().max()))
-    dg = (got["logits"] - want["logits"]).abs()
+        np.testing.assert_array_equal(got["p_out"][i].numpy(), own["stage"]["up"][i]["p_out"].numpy())
+    # logits against the oracle's OWN forward: 1e-4 (north star) wherever fp32 can deliver it; on the deep variants the CPU
+    # oracle's fp32 run is further than that from its fp64 run, and the band widens to NOISE_FACTOR x that distance
+    scale = max(1.0, float(own["logits"].abs().max()))
+    dg = (got["logits"] - own["logits"]).abs()
     dc = (want["logits"].double() - want["logits64"]).abs()
     dg64 = (got["logits"].double() - want["logits64"]).abs()
     q = lambda t, f: float(torch.quantile(t.flatten()[:: max(1, t.numel() // 4000000)].double(), f))
-    print(f"logits |GPU-CPU32| max {float(dg.max()):.2e} p99.99 {q(dg, 0.9999):.2e} | |CPU32-CPU64| max {float(dc.max()):.2e} "
+    print(f"logits |GPU-CPU32 own forward| max {float(dg.max()):.2e} p99.99 {q(dg, 0.9999):.2e} | |CPU32-CPU64| max {float(dc.max()):.2e} "
           f"p99.99 {q(dc, 0.9999):.2e} | |GPU-CPU64| max {float(dg64.max()):.2e}; elements over 1e-4*scale: "
-          f"{int((dg > 1e-4 * scale).sum())} of {dg.numel()}; loss {got['loss']:.6f} / {float(want['loss']):.6f} / {want['loss64']:.6f}")
+          f"{int((dg > 1e-4 * scale).sum())} of {dg.numel()}; loss {got['loss']:.6f} / {float(own['loss']):.6f} / {want['loss64']:.6f}")
     band = max(1e-4 * scale, NOISE_FACTOR * float(dc.max()))
     if mm:
         # the masked refinement replaces a point's features when its PREDICTED ambiguity crosses a threshold
@@ -134,13 +154,20 @@ def _compare(got, want, mm):
         assert pts_g <= 1e-4 * dg.shape[0] * dg.shape[2], ("logits", pts_g)
     else:
         assert float(dg.max()) <= band, ("logits", float(dg.max()), band)
-    assert abs(got["loss"] - float(want["loss"])) <= max(1e-4, NOISE_FACTOR * abs(float(want["loss"]) - want["loss64"])) * max(1.0, abs(float(want["loss"])))
+    assert abs(got["loss"] - float(own["loss"])) <= max(1e-4, NOISE_FACTOR * abs(float(want["loss"]) - want["loss64"])) * max(1.0, abs(float(own["loss"])))
+    e_rel = float(dg.max()) / scale
     for i in range(4):
-        ref = want["stage"]["up"][i]["f_out"].detach()
+        ref = own["stage"]["up"][i]["f_out"].detach()
         e = float((got["f_out"][i] - ref).abs().max())
-        print(f"f_out/{i}: max |GPU-CPU32| {e:.2e} (range {float(ref.abs().max()):.2f})")
+        rng = max(1.0, float(ref.abs().max()))
+        e_rel = max(e_rel, e / rng)
+        print(f"f_out/{i}: max |GPU-CPU32 own forward| {e:.2e} (range {float(ref.abs().max()):.2f})")
         if not mm:
-            assert e <= max(1e-4 * max(1.0, float(ref.abs().max())), band), (f"f_out/{i}", e)
+            assert e <= max(1e-4 * rng, band), (f"f_out/{i}", e)
+    # the product's max-pool picks against torch.max's own in the oracle's forward: few differ, and those that do are near-ties
+    # on the scale the two runs' activations differ by (e_rel, measured above on logits and embeddings; >= 16 ulp)
+    assert want["flips"] <= flip_rate * want["picks"], ("max-pool picks", want["flips"], want["picks"])
+    assert want["gap_max"] <= 16 * max(e_rel, 2e-6), ("a max-pool pick of the product is not a near-tie of the maximum", want["gap_max"], e_rel)
     gmax = max(float(g.norm()) for g in want["grads64"].values())
     rows = []
     for k, g64 in want["grads64"].items():
@@ -176,8 +203,9 @@ def test_cfg2_pointnext_s_24000(B):
     assert lib.amc3d_knnquery_uses_grid(B * 24000, 24, B * 24000, 1) == 1  # the loss's stage-0 k-NN runs on the cell grid
 
 
-def test_cfg3_pointnext_l_24000():
-    got, want, calls = _step("L", 2, 24000, False, 0.04)
+@pytest.mark.parametrize("B", [2, 8])
+def test_cfg3_pointnext_l_24000(B):
+    got, want, calls = _step("L", B, 24000, False, 0.04)
     _compare(got, want, False)
     # every SetAbstraction (4) / LocalAggregation (2 + 4 + 2 + 2) layer of L runs convolve-before-gather (csrc/lagg.hip);
     # grouping_operation is left with the relative positions of the geometry plan only (one per ball query)
@@ -186,24 +214,66 @@ def test_cfg3_pointnext_l_24000():
     assert calls.get("group_points", 0) == calls.get("ball_query", 0) and calls.get("group_points_grad", 0) == 0, calls
 
 
-def test_cfg4_pointnext_xl_mm_64000():
-    got, want, calls = _step("XL", 1, 64000, True, 0.02)
-    _compare(got, want, True)
+@pytest.mark.parametrize("B", [1, 2])
+def test_cfg4_pointnext_xl_mm_64000(B):
+    """B = 2 is the per-GPU batch of BASELINE config 4 (cfgs/scannet/default.yaml:24) that bench.py times"""
+    got, want, calls = _step("XL", B, 64000, True, 0.02)
+    _compare(got, want, True, FLIP_RATE_XL)
     assert calls.get("local_aggregation_forward", 0) == 4 + (3 + 6 + 3 + 3), calls  # XL: blocks [1,4,7,4,4]
     assert calls.get("group_points", 0) == calls.get("ball_query", 0) and calls.get("group_points_grad", 0) == 0, calls
 
 
-def test_cfg5_pointnext_xl_mm_120000_bf16():
-    """BASELINE config 5: PointNeXt-XL + AMContrast3D++ on a 120000-point whole room (voxel 0.02), one cloud per GPU, bf16
-    mixed precision.  The CPU oracle needs minutes at this size, so the comparison is between two runs of the product: the
-    fp32 step (the kernels test_cfg4 checks against the oracle at 64000 points) and the same step under
-    torch.autocast(bfloat16), where every 1x1 convolution (all of XL's dense work, with the grouped convs convolved before
-    the gather) runs on the bf16 MFMA.  Bounds: sampled coordinates identical (the searches stay fp32), loss within 2e-2,
-    gradients finite.  The logits themselves are only reported: at random initialisation the 58 batch-normalised layers of
-    XL amplify rounding by ~1e5 (test_cfg4: the CPU's fp32 and fp64 runs already differ by 6e-3 on logits of size 1), so
-    8-bit operands decorrelate individual logits (relative L2 ~0.5) while the loss moves by 5e-4; on PointNeXt-S, where the
-    comparison is meaningful, this path is twice as close to fp32 as the reference's autocast arithmetic
-    (tests/test_gpu_model.py::test_bf16_mixed_precision_step_on_the_hip_path)."""
+def test_cfg5_bf16_against_the_oracle_under_autocast():
+    """BASELINE config 5's arithmetic (PointNeXt-XL + AMContrast3D++, bf16 mixed precision) at a size the CPU oracle
+    finishes: 1 x 16000 points.  Yardstick = the reference's own mixed-precision arithmetic, i.e. the oracle under
+    torch.autocast('cpu', bfloat16) (main_AA.py:389-394 use_amp: bf16 convolutions and bf16 activations).  Bounds, all
+    against the oracle's fp32 forward on the same weights and batch:
+      * sampled coordinates identical (searches stay fp32);
+      * the product's bf16 logits are no further from the fp32 oracle (relative L2) than the autocast oracle's are;
+      * loss within 2e-2 (relative) of the fp32 oracle's;  gradients finite."""
+    from amcontrast3d_amd import synthetic, timing
+    from oracle import model_ref, pointops_ref
+    import os
+    dev = torch.device("cuda:0")
+    cfg = configs.model_cfg_mm("XL", dropout=0)
+    model, crit = _build(cfg, True, dev)
+    aa = configs.ambiguity_args_mm("s3dis")
+    nb = synthetic.make_batch(1, 16000, first_id=410, voxel_size=0.02)
+    cpu = {k: torch.from_numpy(v) for k, v in nb.items()}
+    data = {k: v.to(dev) for k, v in cpu.items()}
+    with timing.count_calls() as calls:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits, stage, _ = model(data)
+            seg, _, _, reg = crit(logits, data["y"], stage, 13, None, _easy(aa))
+        (seg + reg).backward()
+        torch.cuda.synchronize()
+    assert calls["local_aggregation_forward"] == 4 + (3 + 6 + 3 + 3) and calls.get("group_points_grad", 0) == 0, dict(calls)
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    pointops_ref.set_threads(threads)
+    torch.set_num_threads(threads)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ref32 = model_ref.forward_loss(sd, cfg, cpu, cpu["y"], 13, None, aa, mm=True)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ref_amp = model_ref.forward_loss(sd, cfg, cpu, cpu["y"], 13, None, aa, mm=True)
+    for a, b in zip(ref32["stage"]["up"], stage["up"]):
+        assert torch.equal(a["p_out"], b["p_out"].cpu())
+    n32 = float(ref32["logits"].norm())
+    rel = float((logits.detach().float().cpu() - ref32["logits"]).norm()) / n32
+    rel_amp = float((ref_amp["logits"].float() - ref32["logits"]).norm()) / n32
+    l32, lamp, lgpu = float(ref32["loss"]), float(ref_amp["loss"]), float(seg + reg)
+    print(f"[XL-MM 1x16000 bf16] logits relative L2 to the fp32 oracle: product {rel:.3e}, oracle under autocast {rel_amp:.3e}; "
+          f"loss product {lgpu:.5f} / oracle autocast {lamp:.5f} / oracle fp32 {l32:.5f}")
+    assert rel <= rel_amp, (rel, rel_amp)
+    assert abs(lgpu - l32) <= 2e-2 * abs(l32), (lgpu, l32)
+    assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+
+
+def test_cfg5_pointnext_xl_mm_120000_bf16_runs_at_full_size():
+    """BASELINE config 5 at its own size: PointNeXt-XL + AMContrast3D++ on a 120000-point whole room (voxel 0.02), one
+    cloud per GPU, bf16 mixed precision.  The CPU oracle needs minutes here, so the NUMERIC bound of this arithmetic is
+    test_cfg5_bf16_against_the_oracle_under_autocast (1 x 16000) and this case checks what depends on the size: the
+    dispatch (every grouped layer convolved before the gather, bf16 GEMM route), sampled coordinates identical to the fp32
+    step's (the searches stay fp32), loss within 2e-2 of the product's fp32 step, finite gradients, memory."""
     from amcontrast3d_amd import synthetic, timing
     dev = torch.device("cuda:0")
     cfg = configs.model_cfg_mm("XL", dropout=0)
@@ -213,8 +283,8 @@ def test_cfg5_pointnext_xl_mm_120000_bf16():
     logits32, stage32, _ = model(data)
     seg32, _, _, reg32 = crit(logits32, data["y"], stage32, 13, None, aa)
     p32 = [s["p_out"].clone() for s in stage32["up"]]
-    logits32, loss32 = logits32.detach(), float(seg32 + reg32)
-    del stage32, seg32, reg32
+    loss32 = float(seg32 + reg32)
+    del stage32, seg32, reg32, logits32
     model.zero_grad()
     with timing.count_calls() as calls:
         with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -222,12 +292,11 @@ def test_cfg5_pointnext_xl_mm_120000_bf16():
             seg, _, _, reg = crit(logits, data["y"], stage, 13, None, aa)
         (seg + reg).backward()
         torch.cuda.synchronize()
-    assert logits.dtype == torch.float32 and calls.get("group_points_grad", 0) == 0
+    assert calls.get("group_points_grad", 0) == 0
     assert calls["local_aggregation_forward"] == 4 + (3 + 6 + 3 + 3) and calls["pointwise_conv_forward"] >= 30, dict(calls)
     for a, b in zip(p32, stage["up"]):
         assert torch.equal(a, b["p_out"])
-    rel = float((logits.detach() - logits32).norm() / logits32.norm())
-    print(f"[XL-MM 1x120000 bf16] logits relative L2 to the fp32 step {rel:.3e}; loss {float(seg + reg):.5f} vs {loss32:.5f}; "
+    print(f"[XL-MM 1x120000 bf16] loss {float(seg + reg):.5f} vs fp32 {loss32:.5f}; "
           f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
-    assert rel <= 1.0 and abs(float(seg + reg) - loss32) <= 2e-2 * abs(loss32)
+    assert abs(float(seg + reg) - loss32) <= 2e-2 * abs(loss32)
     assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in model.parameters())
