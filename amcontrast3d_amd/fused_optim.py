@@ -12,9 +12,9 @@ the unclipped gradients is returned as a device scalar, like clip_grad_norm_ doe
 
 The moments of all parameters live in one flat buffer each (the per-parameter state tensors are views), the tensors are
 described to the kernels by a table in device memory that is rebuilt only when a .grad tensor moves, and the learning rates
-are part of that table: a scheduler's new lr is copied into it by the next eager `step()`; a step captured in a hipGraph keeps
-the lr it was captured with (re-capture, or update `table` yourself, when the schedule changes it -- as with torch's
-capturable optimizers and a python-float lr).  GPU fp32 parameters only; one value of betas / eps for all groups."""
+are part of that table: a scheduler's new lr is copied into it by the next eager `step()`; a step captured in a hipGraph reads
+the table at every replay, so `sync_hyperparameters()` between two replays (what pipeline.GraphPipeline does whenever a
+group's lr changed) is all a schedule needs.  GPU fp32 parameters only; one value of betas / eps for all groups."""
 import ctypes
 
 import torch
@@ -77,6 +77,25 @@ class FusedAdamW(torch.optim.Optimizer):
         self._map = torch.tensor(blocks, dtype=torch.int32).reshape(-1).to(self._dev)
         self._partial = torch.empty(len(blocks), dtype=torch.float64, device=self._dev)
         self._nblocks = len(blocks)
+
+    def sync_hyperparameters(self):
+        """Write the groups' current lr / weight_decay into the device table IN PLACE (same tensor, so a hipGraph that
+        captured step() reads the new values at its next replay) -- what a scheduler's step needs between two replays of a
+        captured update.  A no-op while nothing changed; the tensors themselves must not have moved (else: prepare())."""
+        if self._table is None:
+            return False
+        entries = self._entries()
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), lr, wd) for p, lr, wd in entries)
+        if key == self._key:
+            return False
+        if self._key is None or [k[:2] for k in key] != [k[:2] for k in self._key]:
+            raise RuntimeError("FusedAdamW.sync_hyperparameters: a parameter or .grad tensor moved; call prepare()")
+        table, nmap, partial = self._table, self._map, self._partial
+        self._build(entries)  # same sizes: copy the fresh table into the old tensor and keep the old tensors (a graph holds them)
+        table.copy_(self._table)
+        self._table, self._map, self._partial = table, nmap, partial
+        self._key = key
+        return True
 
     def prepare(self):
         """Describe the current parameter / .grad tensors and learning rates to the kernels now (no update is made).  Call it

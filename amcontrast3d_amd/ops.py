@@ -484,7 +484,7 @@ def ambiguity(p, posmask, neighbor_idx, cctype, beta):
     wbytes = int(lib.amc3d_ambiguity_workspace_bytes(m))
     work = torch.empty(wbytes, dtype=torch.uint8, device=p.device)
     a = torch.empty(m, dtype=torch.float32, device=p.device)
-    with torch.cuda.device(p.device), timing.span("ambiguity", m * (12 + 4) + m * k * (4 + 1 + 12)):
+    with torch.cuda.device(p.device), timing.span("ambiguity", m * (12 + 4) + m * k * (4 + 1), moved=m * (12 + 4) + m * k * (4 + 1 + 12)):
         _lib.check(lib.amc3d_ambiguity(m, k, stride, _CCTYPE[cctype], float(beta), _ptr(p), _ptr(posmask), nptr,
                                        _ptr(a), _ptr(work), wbytes, _stream(p)), "ambiguity")
     return a
@@ -545,7 +545,7 @@ class ContrastStage(Function):
         sim = torch.empty(m, k, dtype=torch.float32, device=dev)
         loss_pt = torch.empty(m, dtype=torch.float32, device=dev)
         mean_cnt = torch.empty(2, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), timing.span("contrast_forward", m * C * 4 * (1 + k) + m * k * 9 + m * 12):
+        with torch.cuda.device(dev), timing.span("contrast_forward", m * C * 4 + m * k * 9 + m * 12, moved=m * C * 4 * (1 + k) + m * k * 9 + m * 12):
             _lib.check(_lib.load().amc3d_contrast_forward(m, C, k, stride, _ptr(f), nptr, _ptr(posmask), _ptr(a),
                                                           _ptr(anchors) if anchors is not None else None,
                                                           float(mu), float(nu), float(temperature), _ptr(norm),
@@ -569,14 +569,14 @@ class ContrastStage(Function):
         if rev is not None and lib.amc3d_contrast_backward_csr_supported(C):
             grad_f = torch.empty_like(f)  # every row is written
             gco = torch.empty(m * k, dtype=torch.float32, device=f.device)
-            with torch.cuda.device(f.device), timing.span("contrast_backward_csr", m * C * 4 * (2 + 2 * k) + m * k * 17):
+            with torch.cuda.device(f.device), timing.span("contrast_backward_csr", m * C * 8 + m * k * 17, moved=m * C * 4 * (2 + 2 * k) + m * k * 17):
                 _lib.check(lib.amc3d_contrast_backward_csr(m, C, k, stride, _ptr(f), _ptr(norm), nptr, _ptr(posmask),
                                                            _ptr(a), _ptr(anchors), _ptr(rev), mu, nu, temperature,
                                                            _ptr(sim), _ptr(mean_cnt), _ptr(g), _ptr(gco), _ptr(grad_f),
                                                            _stream(f)), "contrast_backward_csr")
             return grad_f, None, None, None, None, None, None, None, None
         grad_f = torch.zeros_like(f)
-        with torch.cuda.device(f.device), timing.span("contrast_backward", m * C * 4 * (1 + 2 * k) + m * k * 9):
+        with torch.cuda.device(f.device), timing.span("contrast_backward", m * C * 8 + m * k * 9 + m * 8, moved=m * C * 4 * (1 + 2 * k) + m * k * 9):
             _lib.check(_lib.load().amc3d_contrast_backward(m, C, k, stride, _ptr(f), _ptr(norm), nptr, _ptr(posmask),
                                                            _ptr(a), _ptr(anchors) if anchors is not None else None,
                                                            mu, nu, temperature, _ptr(sim), _ptr(mean_cnt),
@@ -624,7 +624,7 @@ class BatchNormAct(Function):
         work, wb = _bn_ws(C, dev)
         lib = _lib.load()
         mom, rm, rv, nbt = _bn_running_args(bn)
-        with torch.cuda.device(dev), timing.span("bn_act_forward", x.numel() * 12):
+        with torch.cuda.device(dev), timing.span("bn_act_forward", x.numel() * 8, moved=x.numel() * 12):
             _lib.check(lib.amc3d_bn_forward(B, C, L, 0, int(bool(relu)), float(eps), mom, _ptr(x), _ptr(gamma), _ptr(beta),
                                             _ptr(y), None, _ptr(mean), _ptr(invstd), _ptr(var_u), rm, rv, nbt,
                                             _ptr(work), wb, _stream(x)), "bn_forward")
@@ -644,7 +644,7 @@ class BatchNormAct(Function):
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(beta)
         work, wb = _bn_ws(C, x.device, extra=C * 8)
-        with torch.cuda.device(x.device), timing.span("bn_act_backward", x.numel() * 20):
+        with torch.cuda.device(x.device), timing.span("bn_act_backward", x.numel() * 12, moved=x.numel() * 20):
             _lib.check(_lib.load().amc3d_bn_backward(B, C, L, 1, int(ctx.relu), _ptr(x), _ptr(dy), None, _ptr(mean),
                                                      _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dx), _ptr(dgamma),
                                                      _ptr(dbeta), _ptr(work), wb, _stream(x)), "bn_backward")
@@ -671,7 +671,7 @@ class BatchNormResidualAct(Function):
         y = torch.empty_like(x)
         work, wb = _bn_ws(C, dev)
         mom, rm, rv, nbt = _bn_running_args(bn)
-        with torch.cuda.device(dev), timing.span("bn_residual_forward", x.numel() * 16):
+        with torch.cuda.device(dev), timing.span("bn_residual_forward", x.numel() * 12, moved=x.numel() * 16):
             _lib.check(_lib.load().amc3d_bn_residual_forward(B, C, L, float(eps), mom, _ptr(x), _ptr(res), _ptr(gamma), _ptr(beta),
                                                              _ptr(y), _ptr(mean), _ptr(invstd), _ptr(var_u), rm, rv, nbt,
                                                              _ptr(work), wb, _stream(x)), "bn_residual_forward")
@@ -691,7 +691,7 @@ class BatchNormResidualAct(Function):
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(beta)
         work, wb = _bn_ws(C, x.device, extra=C * 8)
-        with torch.cuda.device(x.device), timing.span("bn_residual_backward", x.numel() * 28):
+        with torch.cuda.device(x.device), timing.span("bn_residual_backward", x.numel() * 20, moved=x.numel() * 28):
             _lib.check(_lib.load().amc3d_bn_residual_backward(B, C, L, _ptr(x), _ptr(y), _ptr(dy), _ptr(mean), _ptr(invstd),
                                                               _ptr(gamma), _ptr(beta), _ptr(dx), _ptr(dres), _ptr(dgamma),
                                                               _ptr(dbeta), _ptr(work), wb, _stream(x)), "bn_residual_backward")
@@ -717,7 +717,7 @@ class BatchNormSigmoid(Function):
         y = torch.empty_like(x)
         work, wb = _bn_ws(C, dev)
         mom, rm, rv, nbt = _bn_running_args(bn)
-        with torch.cuda.device(dev), timing.span("bn_sigmoid_forward", x.numel() * 12):
+        with torch.cuda.device(dev), timing.span("bn_sigmoid_forward", x.numel() * 8, moved=x.numel() * 12):
             _lib.check(_lib.load().amc3d_bn_sigmoid_forward(B, C, L, float(eps), mom, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y),
                                                             _ptr(mean), _ptr(invstd), _ptr(var_u), rm, rv, nbt, _ptr(work), wb,
                                                             _stream(x)), "bn_sigmoid_forward")
@@ -735,7 +735,7 @@ class BatchNormSigmoid(Function):
         dx = torch.empty_like(x)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
         work, wb = _bn_ws(C, x.device, extra=C * 8)
-        with torch.cuda.device(x.device), timing.span("bn_sigmoid_backward", x.numel() * 24):
+        with torch.cuda.device(x.device), timing.span("bn_sigmoid_backward", x.numel() * 16, moved=x.numel() * 24):
             _lib.check(_lib.load().amc3d_bn_sigmoid_backward(B, C, L, _ptr(x), _ptr(y), _ptr(dy), _ptr(mean), _ptr(invstd),
                                                              _ptr(gamma), _ptr(beta), _ptr(dx), _ptr(dgamma), _ptr(dbeta),
                                                              _ptr(work), wb, _stream(x)), "bn_sigmoid_backward")
@@ -770,7 +770,7 @@ class BatchNormMax(Function):
         work, wb = _bn_ws(C, dev)
         lib = _lib.load()
         mom, rm, rv, nbt = _bn_running_args(bn)
-        with torch.cuda.device(dev), timing.span("bn_max_forward", x.numel() * 8 + y.numel() * 5):
+        with torch.cuda.device(dev), timing.span("bn_max_forward", x.numel() * 4 + y.numel() * 5, moved=x.numel() * 8 + y.numel() * 5):
             _lib.check(lib.amc3d_bn_forward(B, C, M * K, K, int(bool(relu)), float(eps), mom, _ptr(x), _ptr(gamma),
                                             _ptr(beta), _ptr(y), _ptr(arg), _ptr(mean), _ptr(invstd), _ptr(var_u), rm, rv,
                                             nbt, _ptr(work), wb, _stream(x)), "bn_forward")
@@ -791,7 +791,7 @@ class BatchNormMax(Function):
         dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(beta)
         work, wb = _bn_ws(C, x.device, extra=C * 8)
-        with torch.cuda.device(x.device), timing.span("bn_max_backward", x.numel() * 8 + dy.numel() * 5):
+        with torch.cuda.device(x.device), timing.span("bn_max_backward", x.numel() * 4 + dy.numel() * 9, moved=x.numel() * 8 + dy.numel() * 5):
             _lib.check(_lib.load().amc3d_bn_backward(B, C, M * K, K, int(ctx.relu), _ptr(x), _ptr(dy), _ptr(arg),
                                                      _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dx),
                                                      _ptr(dgamma), _ptr(dbeta), _ptr(work), wb, _stream(x)),
@@ -1116,7 +1116,8 @@ class LocalAggregationFused(Function):
             with timing.span("pointwise_conv_forward", 4 * B * N * (Cin + C), 2.0 * B * N * Cin * C):
                 _pw_forward(lib, ctx.bf16, B, Cin, C, N, f, w_f, None, g_cm)
             # algorithmic bytes: G read (statistics) + the gathered rows, idx, dp + the pooled outputs
-            with timing.span("local_aggregation_forward", 8 * B * N * C + B * M * K * (4 * C + 16) + 9 * B * M * C):
+            with timing.span("local_aggregation_forward", 4 * B * N * C + 16 * B * M * K + 5 * B * M * C,
+                             moved=8 * B * N * C + B * M * K * (4 * C + 16) + 9 * B * M * C):
                 if group is None:
                     call(0)
                 else:
@@ -1162,15 +1163,15 @@ class LocalAggregationFused(Function):
                 "local_aggregation_backward")
 
         with torch.cuda.device(dev):
-            with timing.span("local_aggregation_backward", 17 * B * M * C + 12 * B * N * C):
+            with timing.span("local_aggregation_backward", 5 * B * M * C + 8 * B * N * C + 16 * B * M * K, moved=17 * B * M * C + 12 * B * N * C + 16 * B * M * K):
                 if ctx.group is None:
                     call(0)
                 else:
                     call(1)
                     _sync(ctx.group, dsums)
                     call(2)
-            with timing.span("pointwise_conv_backward", 4 * B * N * (Cin + C) * (1 + int(need_f)),
-                             2.0 * B * N * Cin * C * (1 + int(need_f))):
+            with timing.span("pointwise_conv_backward", 4 * B * N * (Cin + C + Cin * int(need_f)),
+                             2.0 * B * N * Cin * C * (1 + int(need_f)), moved=4 * B * N * (Cin + C) * (1 + int(need_f))):
                 _lib.check(pw_bwd(B, Cin, C, N, _ptr(f), _ptr(w_f), _ptr(dg_cm), _ptr(df) if need_f else None, _ptr(dw_f),
                                   _ptr(work2), wb2, _stream(f)), "pointwise_conv_backward")
         dw = _join_columns(dw_dp, dw_f).view(ctx.wshape)
@@ -1220,7 +1221,7 @@ class GroupedConvBN(Function):
         with torch.cuda.device(dev):
             with timing.span("pointwise_conv_forward", 4 * B * N * (Cin + C), 2.0 * B * N * Cin * C):
                 _pw_forward(lib, ctx.bf16, B, Cin, C, N, f, w_f, None, g_cm)
-            with timing.span("grouped_conv_bn_forward", 8 * B * N * C + B * M * K * (8 * C + 16)):
+            with timing.span("grouped_conv_bn_forward", 4 * B * N * C + B * M * K * (4 * C + 16), moved=8 * B * N * C + B * M * K * (8 * C + 16)):
                 if group is None:
                     call(0)
                 else:
@@ -1276,15 +1277,15 @@ class GroupedConvBN(Function):
                     _ptr(dbeta), phase, _ptr(dsums), count, _ptr(work), wb, _stream(f)), "grouped_conv_bn_backward")
 
         with torch.cuda.device(dev):
-            with timing.span("grouped_conv_bn_backward", B * M * K * (8 * C + 16) + 12 * B * N * C):
+            with timing.span("grouped_conv_bn_backward", B * M * K * (8 * C + 16) + 4 * B * N * C, moved=B * M * K * (8 * C + 16) + 12 * B * N * C):
                 if ctx.group is None:
                     call(0)
                 else:
                     call(1)
                     _sync(ctx.group, dsums)
                     call(2)
-            with timing.span("pointwise_conv_backward", 4 * B * N * (Cin + C) * (1 + int(need_f)),
-                             2.0 * B * N * Cin * C * (1 + int(need_f))):
+            with timing.span("pointwise_conv_backward", 4 * B * N * (Cin + C + Cin * int(need_f)),
+                             2.0 * B * N * Cin * C * (1 + int(need_f)), moved=4 * B * N * (Cin + C) * (1 + int(need_f))):
                 _lib.check(pw_bwd(B, Cin, C, N, _ptr(f), _ptr(w_f), _ptr(dg_cm), _ptr(df) if need_f else None, _ptr(dw_f),
                                   _ptr(work2), wb2, _stream(f)), "pointwise_conv_backward")
         dw = _join_columns(dw_dp, dw_f).view(ctx.wshape)
@@ -1386,7 +1387,8 @@ class PointwiseConv(Function):
         work = torch.empty(max(wb, 4), dtype=torch.uint8, device=dev)
         flops = 2.0 * B * P * Cin * Cout * (int(need_x) + int(need_w))
         with torch.cuda.device(dev), timing.span("pointwise_conv_backward",
-                                                 4 * B * P * ((Cin + Cout) * int(need_x) + (Cin + Cout) * int(need_w)), flops):
+                                                 4 * B * P * (Cout + Cin * int(need_x) + Cin * int(need_w)), flops,
+                                                 moved=4 * B * P * ((Cin + Cout) * int(need_x) + (Cin + Cout) * int(need_w))):
             _lib.check(bwd(B, Cin, Cout, P, _ptr(x), _ptr(w2), _ptr(dy), _ptr(dx) if need_x else None,
                            _ptr(dw) if need_w else None, _ptr(work), wb, _stream(dy)), "pointwise_conv_backward")
         db = None
@@ -1687,7 +1689,7 @@ class SATail(Function):
         work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
         mom2, rm2, rv2, nbt2 = _bn_running_args(bn2)
         flops = 2.0 * B * M * K * C1 * C2 * 2  # the 1x1 conv is evaluated twice (statistics pass, max pass)
-        with torch.cuda.device(dev), timing.span("sa_tail_forward", y1.numel() * 4 * 3 + pooled.numel() * 5, flops):
+        with torch.cuda.device(dev), timing.span("sa_tail_forward", y1.numel() * 4 + pooled.numel() * 5, flops, moved=y1.numel() * 4 * 3 + pooled.numel() * 5):
             _lib.check(lib.amc3d_bn_stats(B, C1, M * K, float(eps1), _ptr(y1), _ptr(mean1), _ptr(invstd1), _ptr(var1),
                                           _ptr(work1), wb1, _stream(y1)), "bn_stats")
             _lib.check(lib.amc3d_sa_tail_forward(B, C1, C2, M, K, _ptr(y1), _ptr(mean1), _ptr(invstd1), _ptr(g1), _ptr(b1),
@@ -1723,7 +1725,7 @@ class SATail(Function):
         if ctx.pool_seq is not None and _pool_log is not None:  # tests: the forward pass keeps no arg-max, backward re-derives it
             arg = _pool_log[ctx.pool_seq] = torch.empty(B, C2, M, dtype=torch.uint8, device=dev)
         flops = 2.0 * B * M * K * C1 * C2 * 4  # recompute twice + dx1 + dW2
-        with torch.cuda.device(dev), timing.span("sa_tail_backward", y1.numel() * 4 * 6 + dpooled.numel() * 10, flops):
+        with torch.cuda.device(dev), timing.span("sa_tail_backward", y1.numel() * 4 * 2 + dpooled.numel() * 10, flops, moved=y1.numel() * 4 * 6 + dpooled.numel() * 10):
             _lib.check(lib.amc3d_sa_tail_backward(B, C1, C2, M, K, _ptr(y1), _ptr(mean1), _ptr(invstd1), _ptr(g1), _ptr(b1),
                                                   _ptr(w2f), _ptr(mean2), _ptr(invstd2), _ptr(g2), _ptr(b2), int(ctx.relu2),
                                                   _ptr(dpooled), _ptr(dx1), 0, _ptr(dw2), _ptr(dg2), _ptr(db2),
@@ -1799,8 +1801,8 @@ class SATailActivated(Function):
         arg = None
         if ctx.pool_seq is not None and _pool_log is not None:
             arg = _pool_log[ctx.pool_seq] = torch.empty(B, C2, M, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev), timing.span("sa_tail_backward", x1.numel() * 4 * 3 + dpooled.numel() * 10,
-                                                 2.0 * B * M * K * C1 * C2 * 4):
+        with torch.cuda.device(dev), timing.span("sa_tail_backward", x1.numel() * 4 * 2 + dpooled.numel() * 10,
+                                                 2.0 * B * M * K * C1 * C2 * 4, moved=x1.numel() * 4 * 3 + dpooled.numel() * 10):
             _lib.check(lib.amc3d_sa_tail_backward(B, C1, C2, M, K, _ptr(x1), _ptr(zeros), _ptr(ones), _ptr(ones), _ptr(zeros),
                                                   _ptr(w2f), _ptr(mean2), _ptr(invstd2), _ptr(g2), _ptr(b2), int(ctx.relu2),
                                                   _ptr(dpooled), _ptr(dx1_buf), int(pm), _ptr(dw2), _ptr(dg2), _ptr(db2),

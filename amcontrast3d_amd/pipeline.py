@@ -1,4 +1,12 @@
-"""Geometry prefetching for a training loop (the reference's `train_one_epoch`, examples/segmentation/main_AA.py:370-428).
+"""The pipelined train step of the hot path (the reference's `train_one_epoch`, examples/segmentation/main_AA.py:370-428).
+
+Two schedulers of the same computation live here:
+
+    GraphPipeline        hipGraph replays on three hardware queues -- what `train.train_one_epoch` and `bench.py` run
+    GeometryPrefetcher   the eager form (kernel-by-kernel launches on pooled streams) -- the fallback for loops the
+                         graphs cannot express (gradient accumulation, GradScaler, DDP-wrapped models, ragged batches)
+
+Both rest on the geometry / feature split (amcontrast3d_amd/geometry.py).  GeometryPrefetcher first:
 
 Half of a train step depends only on coordinates and labels: the four FPS levels, ball queries, relative
 positions, 3-NN weights and the loss's k-NN / class votes / positive masks / ambiguities
@@ -130,3 +138,401 @@ class GeometryPrefetcher:
         data["_geometry"] = plan
         self._fill()  # launch the geometry of a later batch before the caller's model call is enqueued
         return data
+
+
+_queues = {}  # (device, CU mask of the geometry queue) -> (sampling queue, geometry queue)
+
+
+def _dedicated_queues(dev, geometry_cus):
+    """One pair of dedicated hardware queues per device and CU mask for every GraphPipeline of the process (pipelines of one
+    process never run at the same time).  The runtime schedules four hardware queues natively; with a pair per pipeline a
+    second pipeline would be the fifth and sixth queue, and the very same step then takes 17 ms instead of 7 (measured in
+    round 2 with one queue per FPS lane)."""
+    from . import ops
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(geometry_cus))
+    if key not in _queues:
+        fps = next((q[0] for k, q in _queues.items() if k[0] == key[0]), None) or ops.dedicated_stream(dev)
+        _queues[key] = (fps, ops.dedicated_stream(dev, 0, geometry_cus))
+    return _queues[key]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class GraphPipeline:
+    """A software pipeline of hipGraphs over successive batches of fixed shape:
+
+        sampling queue   ALL FPS levels of J future batches as ONE launch every J ticks (a workgroup per cloud: the chain
+                         is latency-bound, more clouds per launch cost nothing); two J-batch buffers used in turn
+        geometry queue   hand-down copies, then the neighbourhood + loss geometry (ball queries, relative positions,
+                         reverse edge lists, 3-NN, the loss's k-NN / votes / masks / ambiguities / anchor lists) of the
+                         batch that trains NEXT tick; CU-masked; two captured variants filling two result sets in turn
+        main stream      features of the current batch: forward + loss + backward (+ gradient all-reduce) + clip + optimizer
+                         step; two captured variants, variant v reading the very input set and result set the geometry
+                         variant v worked on one tick earlier -- nothing is copied on the main stream between two steps
+
+    Every batch goes through exactly the computation of the eager loop, once; the pipeline decides WHEN its coordinate-only
+    half runs (1 .. 2J ticks ahead).  Batches come out in the order they went in.
+
+        pipe = GraphPipeline(model, step_loss, head, optimizer, example, num_classes, ignore_index, ambiguity_args)
+        for out in pipe.run(batches):       # batches: iterable of dicts of DEVICE tensors shaped like `example`
+            out["loss"], out["logits"], out["target"], out["parts"]   # static tensors, valid until the next-but-one batch
+
+    `step_loss(data) -> (logits, loss, parts)` is the model + criterion call (parts: extra scalars to report);
+    `head` = criterion.contrast_head.  The optimizer step is captured when the optimizer can be (FusedAdamW, or torch's
+    capturable ones), else it runs eagerly after the feature graph.  Building the pipeline runs three warm-up steps on
+    `example`; parameters, buffers and optimizer state are restored afterwards (`keep_state=True`) so that training starts
+    from the state it was given.  With `flat_grads` (N > 1) the gradient exchange is one all-reduce between the feature
+    graph and the update; SyncBatchNorm layers cut the feature graph at their collectives (graphs.SegmentedGraph).
+    The current stream at construction must not be the legacy default stream (graphs are captured on it)."""
+
+    def __init__(self, model, step_loss, head, optimizer, example, num_classes, ignore_index, ambiguity_args, *,
+                 lanes=0, max_grad_norm=None, flat_grads=None, sync_bn=False, keep_state=True, geometry_cus=None,
+                 amp_dtype=None, verbose=False):
+        from . import ops
+        self.model, self.step_loss, self.head, self.opt = model, step_loss, head, optimizer
+        self.ncls, self.ignore, self.aargs = num_classes, ignore_index, ambiguity_args
+        self.clip, self.flatg, self.sync_bn, self.amp_dtype = max_grad_norm, flat_grads, sync_bn, amp_dtype
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.dev = example["pos"].device
+        self.B, self.N = example["pos"].shape[:2]
+        self.keys = [k for k, v in example.items() if torch.is_tensor(v)]
+        self.main = torch.cuda.current_stream(self.dev)
+        assert self.main != torch.cuda.default_stream(self.dev), "GraphPipeline captures on the current stream: make a side stream current"
+        self.nlevels = len(list(geometry._unwrap(model).encoder.encoder))
+        snapshot = self._snapshot() if keep_state else None
+        self.lanes = J = max(2, lanes if lanes > 0 else self._choose_lanes(example, verbose))
+        # hardware queues of their own for the two background chains (ordinary streams share four queues round-robin and
+        # whatever shares a queue with a running FPS kernel waits milliseconds for it); the geometry queue is confined
+        # to 10/16 of the CUs for clouds the register-resident FPS kernel handles (<= 24576 points; measured: its kernels
+        # are background work with slack and slow the feature half more than they gain when they spread over the chip)
+        ncu = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        if geometry_cus is None:
+            geometry_cus = 10 * ncu // 16 if self.N <= 24576 else 0
+        self.s_fps, self.s_geo = _dedicated_queues(self.dev, geometry_cus)
+        self.geometry_cus = geometry_cus
+        self.ev_lane = [torch.cuda.Event(), torch.cuda.Event()]
+        self.ev_geo, self.ev_main, self.ev_rot = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        self._build(example)
+        if snapshot is not None:
+            self._restore(snapshot)
+        self.tick = 0
+        self._set_valid = [False, False]
+        self._lane_valid = [[False] * J, [False] * J]
+        self._lr = tuple(g["lr"] for g in optimizer.param_groups)
+
+    # -- pieces of a step --------------------------------------------------------------------------------------------
+    def _fps_all(self, batch):
+        return geometry.precompute_fps_levels(self.model, batch["pos"], 0, self.nlevels)
+
+    def _rest(self, batch, fps):
+        return geometry.precompute_rest(self.model, self.head, batch, fps, self.ncls, self.ignore, self.aargs)
+
+    def _fwd_bwd(self, data, out):
+        if self.flatg is not None:
+            self.flatg.zero()
+        with torch.autocast("cuda", dtype=self.amp_dtype or torch.bfloat16, enabled=self.amp_dtype is not None):
+            logits, loss, parts = self.step_loss(data)
+        loss.backward()
+        if self.flatg is not None:
+            self.flatg.gather()
+        out.update(logits=logits, loss=loss, parts=parts)
+
+    def _update(self):
+        if type(self.opt).__name__ == "FusedAdamW":  # clip_grad_norm_ + AdamW as two launches (csrc/optim.hip)
+            self.opt.step(max_grad_norm=self.clip)
+        else:
+            if self.clip:
+                torch.nn.utils.clip_grad_norm_(self.params, self.clip, norm_type=2)
+            self.opt.step()
+
+    def _copy_batch(self, dst, src):
+        torch._foreach_copy_([dst[k] for k in self.keys], [src[k] for k in self.keys])
+
+    def _ms(self, fn, reps):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def _choose_lanes(self, example, verbose):
+        """batches per joint FPS launch: 4 where the first-level chain is about a feature half long (24k-point clouds: the
+        launch then runs 10 ms every fourth tick); for long chains (64k / 120k-point clouds in batches of 1-2) as many as
+        make the chain of ALL levels fit into J ticks next to a busy chip, at most 12"""
+        data = dict(example)
+        t_fps = self._ms(lambda: geometry.precompute_fps_levels(self.model, data["pos"], 0, 2), 1)
+        data["_geometry"] = geometry.precompute(self.model, self.head, data, self.ncls, self.ignore, self.aargs)
+        out = {}
+
+        def feat():
+            self._fwd_bwd(data, out)
+            if self.flatg is None:
+                for p in self.params:
+                    p.grad = None
+        t_feat = self._ms(feat, 2)
+        if t_fps <= 1.5 * t_feat:
+            lanes = 4
+        else:
+            t_all = self._ms(lambda: self._fps_all(data), 1)
+            lanes = int(min(12, max(3, -(-t_all // max(0.35 * t_feat, 1e-3)))))
+        if verbose:
+            import sys
+            print(f"GraphPipeline: sampling chain {t_fps:.1f} ms (first level), eager feature half {t_feat:.1f} ms -> {lanes} "
+                  f"batches per joint FPS launch", file=sys.stderr)
+        return lanes
+
+    # -- state kept across the warm-up --------------------------------------------------------------------------------
+    def _snapshot(self):
+        sd = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        ost = {id(t): t.detach().clone() for st in self.opt.state.values() for t in st.values() if torch.is_tensor(t)}
+        return sd, ost, torch.cuda.get_rng_state(self.dev)
+
+    def _restore(self, snapshot):
+        sd, ost, rng = snapshot
+        with torch.no_grad():
+            for k, v in self.model.state_dict().items():
+                v.copy_(sd[k])
+            for st in self.opt.state.values():  # in place: the captured update reads these tensors
+                for t in st.values():
+                    if torch.is_tensor(t):
+                        t.copy_(ost[id(t)]) if id(t) in ost else t.zero_()
+        torch.cuda.set_rng_state(rng, self.dev)
+
+    # -- capture ------------------------------------------------------------------------------------------------------
+    def _build(self, example):
+        from .graphs import SegmentedGraph, quiesce
+        import torch.distributed as tdist
+        J, B = self.lanes, self.B
+        ex = {k: example[k] for k in self.keys}
+        lane = lambda t, l: t[l * B:(l + 1) * B]
+        # two J-batch buffers of the sampling queue and their outputs (all levels), with per-lane views
+        self.in_J = [{k: torch.cat([v] * J) for k, v in ex.items()} for _ in range(2)]
+        self.fps_J = [self._fps_all(self.in_J[j]) for j in range(2)]
+        self.in_lane = [[{k: lane(v, l) for k, v in self.in_J[j].items()} for l in range(J)] for j in range(2)]
+        self.fps_lane = [[geometry._walk(self.fps_J[j], lambda t, l=l: lane(t, l)) for l in range(J)] for j in range(2)]
+        # two input sets (batch + its FPS picks) shared by geometry variant v and, one tick later, feature variant v
+        self.set_in = [{k: v.clone() for k, v in ex.items()} for _ in range(2)]
+        self.set_fps = [geometry.clone(self.fps_lane[0][0]) for _ in range(2)]
+        self.out = [{}, {}]
+        data0 = dict(self.set_in[0])
+
+        def eager_step():  # everything once, in line: allocator warm-up, lazy initialisations, optimizer state
+            data0["_geometry"] = self._rest(self.set_in[0], self._fps_all(self.set_in[0]))
+            if self.flatg is None:
+                self.opt.zero_grad(set_to_none=True)
+            self._fwd_bwd(data0, self.out[0])
+            if self.flatg is not None:
+                self.flatg.allreduce()
+            self._update()
+        for _ in range(3):
+            eager_step()
+        torch.cuda.synchronize()
+        dist_on = tdist.is_available() and tdist.is_initialized()
+        if dist_on:
+            quiesce()  # c10d's watchdog must not poll an event of a stream that is capturing
+        if self.flatg is None:
+            self.opt.zero_grad(set_to_none=True)
+        mode = "thread_local" if dist_on else "global"
+        self.mode = mode
+        G = torch.cuda.CUDAGraph
+        # geometry variants: their own output tensors are the two result sets
+        self.g_geo, self.rest = [G(), G()], []
+        for v in range(2):
+            with torch.cuda.graph(self.g_geo[v], stream=self.s_geo, capture_error_mode=mode):
+                self.rest.append(geometry.split(self._rest(self.set_in[v], self.set_fps[v]))[1])
+        for v, r in enumerate(self.rest):  # a result set may only alias the inputs of its own variant
+            other = set()
+            geometry._walk([self.set_fps[1 - v], self.set_in[1 - v], self.in_J, self.fps_J], lambda t: other.add(t.untyped_storage().data_ptr()))
+
+            def check(t):
+                assert t.untyped_storage().data_ptr() not in other, "the geometry plan aliases another batch's buffers"
+            geometry._walk(r, check)
+        # feature variants.  The second must deliver its gradients in the FIRST variant's .grad tensors (the update graph
+        # reads those): captured with .grad still set, autograd would accumulate into them, so it runs with .grad = None
+        # and ends with one multi-tensor copy into the first variant's buffers
+        self.g_feat = []
+        for v in range(2):
+            data = dict(self.set_in[v])
+            data["_geometry"] = geometry.join(self.set_fps[v], self.rest[v])
+            keep = [p.grad for p in self.params] if v else None
+
+            def body(data=data, v=v, keep=keep):
+                if keep is not None and self.flatg is None:
+                    for p in self.params:
+                        p.grad = None
+                self._fwd_bwd(data, self.out[v])
+                if keep is not None and self.flatg is None:
+                    pairs = [(g0, p.grad) for g0, p in zip(keep, self.params) if g0 is not None and p.grad is not None]
+                    torch._foreach_copy_([a for a, _ in pairs], [b for _, b in pairs])
+            if self.sync_bn:  # the statistics all-reduces are not captured: a chain of graphs with eager collectives between
+                g = SegmentedGraph(mode).capture(body, stream=self.main)
+            else:
+                g = G()
+                kw = {"pool": self.g_feat[0].pool()} if v else {}  # the variants never run at the same time
+                with torch.cuda.graph(g, stream=self.main, capture_error_mode=mode, **kw):
+                    body()
+            self.g_feat.append(g)
+            if keep is not None and self.flatg is None:
+                assert all((g0 is None) == (p.grad is None) for g0, p in zip(keep, self.params)), "variants disagree on which parameters get gradients"
+                for p, g0 in zip(self.params, keep):
+                    p.grad = g0
+        # the update: captured where the optimizer allows it
+        self.g_update = None
+        fused = type(self.opt).__name__ == "FusedAdamW"
+        if fused or all(g.get("capturable", False) for g in self.opt.param_groups):
+            if fused:
+                self.opt.prepare()  # the .grad tensors are the feature graph's now: rebuild the tensor table before capture
+            self.g_update = G()
+            with torch.cuda.graph(self.g_update, stream=self.main, capture_error_mode=mode):
+                self._update()
+        # hand-down on the geometry queue, one graph per tick of the period 2J: lane (buffer jc, lane l) -> input set v1
+        self.g_side = []
+        from . import schedule
+        for t in range(schedule.period(J)):
+            plan = schedule.tick_plan(t, J)
+            (jc, l), v1 = plan["consume"], plan["fill"]
+            g = G()
+            with torch.cuda.graph(g, stream=self.s_geo, capture_error_mode=mode):
+                geometry.copy_into(self.set_fps[v1], self.fps_lane[jc][l])
+                self._copy_batch(self.set_in[v1], self.in_lane[jc][l])
+            self.g_side.append(g)
+        self.g_fps = [G(), G()]
+        for j in range(2):
+            with torch.cuda.graph(self.g_fps[j], stream=self.s_fps, capture_error_mode=mode):
+                geometry.copy_into(self.fps_J[j], self._fps_all(self.in_J[j]))
+        torch.cuda.synchronize()
+
+    # -- running ------------------------------------------------------------------------------------------------------
+    @property
+    def depth(self):
+        """ticks between a batch entering the pipeline and its train step: J + 1 for the first lane of a launch .. 2J"""
+        return 2 * self.lanes
+
+    def _critical_path(self, v0):
+        self.g_feat[v0].replay()
+        if self.flatg is not None:
+            self.flatg.allreduce()
+        if self.g_update is not None:
+            lr = tuple(g["lr"] for g in self.opt.param_groups)
+            if lr != self._lr:  # a scheduler stepped: the captured update reads its learning rates from device memory
+                if hasattr(self.opt, "sync_hyperparameters"):
+                    self.opt.sync_hyperparameters()
+                self._lr = lr
+            self.g_update.replay()
+        else:
+            self._update()
+
+    def _tick(self, it):
+        """one tick: train the batch in input set v0 (if it holds one), prepare the next one's geometry, every J ticks
+        load J new batches and launch their sampling.  -> (result dict or None, pipeline still holds batches)"""
+        from . import schedule
+        J, t = self.lanes, self.tick % (2 * self.lanes)
+        self.tick += 1
+        plan = schedule.tick_plan(t, J)
+        v0, v1, (jc, l), jl = plan["train"], plan["fill"], plan["consume"], plan["launch"]
+        out = None
+        # the main stream goes first: the side launches below take the host 0.3-0.5 ms
+        self.main.wait_event(self.ev_geo)   # result set v0 is complete
+        self.ev_main.record(self.main)      # ... and everything earlier on the main stream has read set v1
+        if self._set_valid[v0]:
+            self._critical_path(v0)
+            out = dict(self.out[v0], target=self.set_in[v0]["y"], data=self.set_in[v0])
+        with torch.cuda.stream(self.s_geo):
+            self.s_geo.wait_event(self.ev_main)
+            self.s_geo.wait_event(self.ev_lane[jc])
+            self.g_side[t].replay()
+            self._set_valid[v1], self._lane_valid[jc][l] = self._lane_valid[jc][l], False
+            launch = False
+            if jl is not None:  # J new batches into the buffer whose lanes were all consumed J ticks ago
+                got = 0
+                if it is not None:
+                    for k in range(J):
+                        b = next(it, None)  # (a loader's host-to-device copies and feature assembly run here, on this queue)
+                        if b is None:
+                            break
+                        assert b["pos"].shape[:2] == (self.B, self.N), "GraphPipeline: batches must keep the shape it was built for"
+                        self._copy_batch(self.in_lane[jl][k], b)
+                        got += 1
+                self._lane_valid[jl] = [k < got for k in range(J)]
+                launch = got > 0
+            self.ev_rot.record(self.s_geo)
+        if launch:
+            with torch.cuda.stream(self.s_fps):
+                self.s_fps.wait_event(self.ev_rot)
+                self.g_fps[jl].replay()
+                self.ev_lane[jl].record(self.s_fps)
+        with torch.cuda.stream(self.s_geo):
+            self.g_geo[v1].replay()
+            self.ev_geo.record(self.s_geo)
+        return out, self._set_valid[v1] or any(self._lane_valid[0]) or any(self._lane_valid[1])
+
+    def run(self, batches):
+        """Generator: feeds `batches` (an iterable of device batch dicts) through the pipeline and yields one result per
+        batch, in order: {'loss', 'logits', 'parts', 'target', 'data'} -- static tensors of the variant that just ran (read
+        them on the current stream before taking the next-but-one result).  Ends when every batch has trained; an endless
+        iterable makes an endless generator (bench.py)."""
+        it = iter(batches)
+        # start at a launch tick with empty buffers
+        self.tick = 0
+        self._set_valid = [False, False]
+        self._lane_valid = [[False] * self.lanes, [False] * self.lanes]
+        busy = True
+        while busy:
+            out, busy = self._tick(it)
+            if out is not None:
+                yield out
+
+    # -- measurements (bench.py) ----------------------------------------------------------------------------------------
+    def parts_alone(self, reps=5):
+        """ms of each pipeline part replayed back to back on its own stream with nothing else on the chip: what the overlap
+        has to hide.  (Leaves stale batches in the buffers: call after the timed run.)"""
+        import time
+
+        def alone(fn, stream):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            with torch.cuda.stream(stream):
+                for _ in range(reps):
+                    fn()
+            torch.cuda.synchronize()
+            return round((time.perf_counter() - t) / reps * 1e3, 3)
+        return {"features_ms": alone(self.g_feat[0].replay, self.main),
+                "update_ms": alone(self.g_update.replay if self.g_update is not None else self._update, self.main),
+                "fps_all_levels_joint_launch_ms": alone(self.g_fps[0].replay, self.s_fps),
+                "neighbourhood_geometry_ms": alone(self.g_geo[0].replay, self.s_geo),
+                "hand_down_ms": alone(self.g_side[0].replay, self.s_geo)}
+
+    def serial_ms(self, reps=5):
+        """the same step with nothing overlapped: every part replayed on its stream with a host wait after each (a joint
+        FPS launch once per J steps)"""
+        import time
+        J = self.lanes
+        t = 0.0
+        for r in range(-1, reps):
+            if r == 0:
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+            for fn, st in ((self.g_side[r % (2 * J)].replay, self.s_geo),
+                           (self.g_fps[(r // J) % 2].replay if r % J == 0 else (lambda: None), self.s_fps),
+                           (self.g_geo[r % 2].replay, self.s_geo), (self.g_feat[r % 2].replay, self.main)):
+                with torch.cuda.stream(st):
+                    fn()
+                st.synchronize()
+            if self.flatg is not None:
+                self.flatg.allreduce()
+            (self.g_update.replay if self.g_update is not None else self._update)()
+            self.main.synchronize()
+        return round((time.perf_counter() - t) / reps * 1e3, 3)
+
+    def describe(self):
+        J = self.lanes
+        seg = getattr(self.g_feat[0], "segments", 1)
+        return {"launch": "hipGraph replay", "batches_per_joint_fps_launch": J, "look_ahead_batches": [J + 1, 2 * J],
+                "geometry_queue_cus": self.geometry_cus or "all", "feature_graph_segments": seg,
+                "collectives_per_step": getattr(self.g_feat[0], "collectives", 0) + (1 if self.flatg is not None else 0),
+                "update": "captured" if self.g_update is not None else "eager",
+                "pipeline": (f"3 queues: sampling (all FPS levels of {J} future batches as one launch every {J} steps) | neighbourhood + "
+                             "loss geometry of the next batch (CU-masked) | features of this batch; geometry handed over without "
+                             "copies (two captured variants each)")}

@@ -1,45 +1,29 @@
-"""Index arithmetic of the pipelined training loop (bench.py): which buffers a step consumes, reloads and launches.
+"""Index arithmetic of the pipelined training loop (pipeline.GraphPipeline): which buffers a tick trains on, fills, consumes
+and launches.  Kept apart from the streams and graphs so that the hand-down can be replayed with batch ids instead of tensors
+(tests/test_host_logic.py).
 
-The loop keeps four batches in flight:
-    first-level FPS of batches t+3..   ->  FPS levels 2-4 of batch t+2  ->  neighbourhood / loss geometry of batch t+1  ->  features of t
-and hands their inputs and results down one stage per step.  Two layouts of the first stage:
-    lanes   `lanes` single-batch buffers, one launched per step (lane = step % lanes), consumed `lanes` steps later
-    joint   two J-batch buffers (J = lanes), launched alternately every J steps; lane l of a launch is consumed J + l steps
-            later -- the sampling queue then needs one launch every J steps
-Kept apart from bench.py so that the hand-down can be replayed with batch ids instead of tensors (tests/test_host_logic.py)."""
-import math
-
-
-def period(lanes, npool, pingpong, joint):
-    """Number of distinct step shapes (graphs are captured per shape): the lane and the pool index repeat after lcm(lanes,
-    npool) steps, the ping-pong result sets after 2, the joint launches after 2 * lanes."""
-    p = lanes * npool // math.gcd(lanes, npool)
-    if pingpong and p % 2:
-        p *= 2
-    if joint:
-        p = p * (2 * lanes) // math.gcd(p, 2 * lanes)
-    return p
+Buffers:
+    joint[j], j = 0, 1      two J-batch input buffers of the sampling queue with their FPS results (all levels); buffer j is
+                            loaded and launched every 2J ticks, J ticks apart from the other one
+    set[v],  v = 0, 1       one batch + its FPS picks + (written by geometry variant v) its neighbourhood / loss geometry;
+                            read by feature variant v one tick after geometry variant v filled it
+A tick t (mod 2J):
+    train    set[t % 2]                                   (main stream)
+    consume  lane (jc, l) -> set[(t + 1) % 2]             (geometry queue; jc = the buffer launched J..2J-1 ticks ago, l = t % J)
+    launch   buffer jl, after loading J new batches into it, when l == 0     (sampling queue; has J ticks to finish)
+so a batch loaded at a launch tick t0 into lane l is consumed at t0 + J + l and trains at t0 + J + l + 1: batches leave in the
+order they entered, 1 .. J ticks after their sampling finished at the latest."""
 
 
-def side_step(s, lanes, joint, npool):
-    """Step s (mod period) on the side queues -> dict
-         consume  index into the first-level buffers whose result and inputs move down now: (buffer, lane) or (lane,)
-         wait     the first-level launch (event index) that must have finished before that
-         load     [(buffer index, pool index)]: inputs (re)loaded for the launch below
-         launch   first-level launch started after the hand-down, or None
-    joint: J = lanes batches per launch, one launch every J steps into buffer (s // J) % 2; lane l of a launch is consumed
-    J + l steps after it was started (so a launch has J steps to finish)."""
-    lane = s % lanes
-    if joint:
-        J = lanes
-        assert J >= 2
-        jc, jl = 1 - (s // J) % 2, (s // J) % 2
-        first = lane == 0
-        return {"consume": (jc, lane), "wait": jc, "launch": jl if first else None,
-                "load": [((jl, t), (s + 2 * J + 1 + t) % npool) for t in range(J)] if first else []}
-    return {"consume": (lane,), "wait": lane, "launch": lane, "load": [((lane,), (s + lanes + 3) % npool)]}
+def tick_plan(t, lanes):
+    """-> {'train': set index, 'fill': set index, 'consume': (joint buffer, lane), 'launch': joint buffer or None}"""
+    J = lanes
+    assert J >= 2
+    t %= 2 * J
+    jl = (t // J) % 2
+    return {"train": t % 2, "fill": (t + 1) % 2, "consume": (1 - jl, t % J), "launch": jl if t % J == 0 else None}
 
 
-def variants(s, pingpong):
-    """(result set the feature half of step s reads, result set stream B fills during step s)"""
-    return (s % 2, (s + 1) % 2) if pingpong else (0, 0)
+def period(lanes):
+    """distinct tick shapes (hand-down graphs are captured per shape)"""
+    return 2 * lanes

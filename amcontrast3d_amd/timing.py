@@ -2,15 +2,23 @@
 
 bench.py switches this on for the timed region: every C-ABI launch made through
 amcontrast3d_amd.ops is bracketed by two events recorded on torch's current stream (the
-stream the kernel is enqueued on), tagged with the operator name and the algorithmic bytes
-of that launch.  Nothing synchronises until ``collect()``.
+stream the kernel is enqueued on), tagged with the operator name and two byte counts:
+
+    bytes   ALGORITHMIC bytes of the launch in the sense of SURVEY.md section 8(d): every input read once, every output
+            written once -- the compulsory HBM traffic of the operator however it is implemented
+    moved   what THIS implementation asks the memory system for: re-reads of a multi-pass kernel, gathered neighbour rows,
+            rows added by float atomics.  Most of the excess is served by L2 / Infinity Cache; it is reported next to the
+            algorithmic figure, never instead of it (round 2's bench line priced the loss backward with it: 0.38 claimed,
+            0.021 by section 8(d))
+
+Nothing synchronises until ``collect()``.
 """
 import collections
 
 import torch
 
 _enabled = False
-_records = []  # (name, start_event, end_event, algorithmic_bytes, flops)
+_records = []  # (name, start_event, end_event, algorithmic_bytes, flops, moved_bytes)
 calls = None   # a collections.Counter while count_calls() is active: operator name -> launches (dispatch evidence)
 
 
@@ -49,10 +57,11 @@ def note(name):
 
 class span:
     """with timing.span('knnquery', bytes): launch(...)"""
-    __slots__ = ("name", "nbytes", "flops", "start")
+    __slots__ = ("name", "nbytes", "flops", "moved", "start")
 
-    def __init__(self, name, nbytes=0, flops=0.0):
+    def __init__(self, name, nbytes=0, flops=0.0, moved=None):
         self.name, self.nbytes, self.flops, self.start = name, nbytes, flops, None
+        self.moved = nbytes if moved is None else moved
         if calls is not None:
             calls[name] += 1
 
@@ -66,19 +75,20 @@ class span:
         if self.start is not None:
             end = torch.cuda.Event(enable_timing=True)
             end.record()
-            _records.append((self.name, self.start, end, self.nbytes, self.flops))
+            _records.append((self.name, self.start, end, self.nbytes, self.flops, self.moved))
         return False
 
 
 def collect():
-    """-> {name: {'launches', 'total_ms', 'avg_ms', 'bytes_per_launch'}}; call after a device sync."""
+    """-> {name: {'launches', 'total_ms', 'avg_ms', 'bytes', 'moved', 'flops', 'bytes_per_launch'}}; call after a device sync."""
     out = collections.OrderedDict()
-    for name, s, e, nbytes, flops in _records:
-        d = out.setdefault(name, {"launches": 0, "total_ms": 0.0, "bytes": 0, "flops": 0.0})
+    for name, s, e, nbytes, flops, moved in _records:
+        d = out.setdefault(name, {"launches": 0, "total_ms": 0.0, "bytes": 0, "flops": 0.0, "moved": 0})
         d["launches"] += 1
         d["total_ms"] += s.elapsed_time(e)
         d["bytes"] += nbytes
         d["flops"] += flops
+        d["moved"] += moved
     for d in out.values():
         d["avg_ms"] = d["total_ms"] / d["launches"]
         d["bytes_per_launch"] = d["bytes"] / d["launches"]

@@ -3,8 +3,14 @@ caller of model + criterion, with the same arguments, the same per-iteration ord
 value (loss average, mIoU, mAcc, OA, per-class IoU / accuracy of the training predictions).
 
 What differs from the reference's loop, with identical arithmetic per batch:
-  * the coordinate-only half of every step (FPS, ball queries, 3-NN, the loss's k-NN / votes / ambiguities) is computed
-    for the NEXT batches on side queues while the current batch trains (pipeline.GeometryPrefetcher);
+  * the step is pipeline.GraphPipeline: hipGraph replays on three hardware queues -- the coordinate-only half of every step
+    (FPS, ball queries, 3-NN, the loss's k-NN / votes / ambiguities) runs for the NEXT batches on two side queues while the
+    current batch runs forward + loss + backward + clip + optimizer step as captured graphs on the training stream.  The
+    graphs are built once per (model, optimizer, criterion, batch shape) from the first batch -- parameters, buffers and
+    optimizer state are restored after the warm-up -- and reused by later epochs.  Loops the graphs cannot express run
+    eagerly behind pipeline.GeometryPrefetcher, as before: gradient accumulation (step_per_update > 1), use_amp with a
+    GradScaler, DistributedDataParallel-wrapped models, a batch whose shape differs from the first one's,
+    cfg.graph_pipeline = False or AMC3D_EAGER_TRAIN=1;
   * the loss is accumulated on the device and read back once per epoch (the reference calls `loss.item()` every
     iteration, main_AA.py:419, which drains the GPU each step); `print_freq` progress lines therefore show the loss of
     the last *completed* read-back;
@@ -12,10 +18,20 @@ What differs from the reference's loop, with identical arithmetic per batch:
 Data: each batch is the reference's collated dict -- 'pos' (B,N,3), 'y' (B,N) or (B,N,1), and the keys named by
 `cfg.feature_keys` ('x', 'heights', ...) point-major, as its datasets produce them (dataset/data_util.py:177-189).
 """
+import itertools
+import os
+
 import torch
 
 from . import activate
-from .pipeline import GeometryPrefetcher
+from .pipeline import GeometryPrefetcher, GraphPipeline
+
+_PIPELINES = {}  # (model, optimizer, criterion, batch shape) -> (GraphPipeline, its training stream)
+
+
+def release_pipelines():
+    """drop the captured graphs (and the references to the models / optimizers they were built for)"""
+    _PIPELINES.clear()
 
 
 def get_features_by_keys(data, keys="pos,x"):
@@ -71,6 +87,32 @@ def train_one_epoch(model, train_loader, criterion, optimizer, scheduler, scaler
                       step_loss, extras=0)
 
 
+def _cfg(cfg, key, default=None):
+    return cfg.get(key, default) if hasattr(cfg, "get") else getattr(cfg, key, default)
+
+
+def _graph_pipeline(model, criterion, optimizer, cfg, step_loss, first, clip):
+    """the GraphPipeline of this (model, optimizer, criterion, batch shape), built from batch `first` at first use"""
+    import torch.distributed as tdist
+    key = (id(model), id(optimizer), id(criterion), tuple(first["pos"].shape), tuple(sorted(k for k, v in first.items() if torch.is_tensor(v))))
+    hit = _PIPELINES.get(key)
+    if hit is None:
+        dev = first["pos"].device
+        main = torch.cuda.Stream(dev)
+        main.wait_stream(torch.cuda.current_stream(dev))
+        flat, sync_bn = None, False
+        if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+            from .dist import FlatGradients
+            flat = FlatGradients([p for p in model.parameters() if p.requires_grad], accumulate=False)
+            sync_bn = any(isinstance(m, torch.nn.SyncBatchNorm) for m in model.modules())
+        with torch.cuda.stream(main):
+            pipe = GraphPipeline(model, lambda data: step_loss(data, data["y"]), criterion.contrast_head, optimizer, first,
+                                 cfg.num_classes, cfg.ignore_index, cfg.ambiguity_args, max_grad_norm=clip, flat_grads=flat,
+                                 sync_bn=sync_bn, lanes=int(_cfg(cfg, "fps_lanes", 0) or 0))
+        hit = _PIPELINES[key] = (pipe, main)
+    return hit
+
+
 def _run_epoch(model, train_loader, criterion, optimizer, scheduler, scaler, epoch, cfg, prefetch_depth, device, step_loss,
                extras):
     activate()
@@ -80,13 +122,45 @@ def _run_epoch(model, train_loader, criterion, optimizer, scheduler, scaler, epo
     model.train()
     head = getattr(criterion, "contrast_head", None)
     batches = _to_device_batches(train_loader, cfg, device)
-    use_amp = bool(cfg.get("use_amp", False)) if hasattr(cfg, "get") else bool(getattr(cfg, "use_amp", False))
-    if head is not None and prefetch_depth > 0 and not use_amp:
+    use_amp = bool(_cfg(cfg, "use_amp", False))
+    clip = _cfg(cfg, "grad_norm_clip", None)
+    clip = clip if (clip is not None and clip > 0.) else None
+    loss_sum = torch.zeros(1 + extras, dtype=torch.float64, device=device)
+    n_batches = 0
+    graphs_ok = (head is not None and not use_amp and cfg.step_per_update == 1 and _cfg(cfg, "graph_pipeline", True)
+                 and not os.environ.get("AMC3D_EAGER_TRAIN")
+                 and not isinstance(model, (torch.nn.parallel.DistributedDataParallel, torch.nn.DataParallel)))
+    if graphs_ok:
+        first = next(batches, None)
+        if first is None:
+            graphs_ok = False
+            batches = iter(())
+    if graphs_ok:
+        pipe, main = _graph_pipeline(model, criterion, optimizer, cfg, step_loss, first, clip)
+        shape = tuple(first["pos"].shape)
+        odd = []  # batches of another shape (a ragged last batch): trained eagerly after the pipeline has drained
+
+        def same_shape(it):
+            for b in it:
+                if tuple(b["pos"].shape) == shape:
+                    yield b
+                else:
+                    odd.append(b)
+        cur = torch.cuda.current_stream(device)
+        main.wait_stream(cur)
+        with torch.cuda.stream(main):
+            for out in pipe.run(same_shape(itertools.chain([first], batches))):
+                if not cfg.sched_on_epoch:
+                    scheduler.step(epoch)
+                cm.update(out["logits"].argmax(dim=1), out["target"])
+                loss_sum += torch.stack([out["loss"].detach()] + [v.detach() for v in out["parts"]]).double()
+                n_batches += 1
+        cur.wait_stream(main)
+        batches = iter(odd)
+    elif head is not None and prefetch_depth > 0 and not use_amp:
         batches = GeometryPrefetcher(batches, model, head, cfg.num_classes, cfg.ignore_index, cfg.ambiguity_args,
                                      depth=prefetch_depth)
-    clip = cfg.get("grad_norm_clip", None) if hasattr(cfg, "get") else getattr(cfg, "grad_norm_clip", None)
-    loss_sum = torch.zeros(1 + extras, dtype=torch.float64, device=device)
-    n_batches, num_iter = 0, 0
+    num_iter = 0
     for data in batches:
         num_iter += 1
         target = data["y"]
@@ -98,9 +172,8 @@ def _run_epoch(model, train_loader, criterion, optimizer, scheduler, scaler, epo
             loss.backward()
         if num_iter == cfg.step_per_update:
             # (with use_amp the reference clips the still-scaled gradients, main_AA.py:402-409; kept as it is)
-            clipping = clip is not None and clip > 0.
-            folded = clipping and not use_amp and type(optimizer).__name__ == "FusedAdamW"  # clip inside the optimizer's launch
-            if clipping and not folded:
+            folded = clip is not None and not use_amp and type(optimizer).__name__ == "FusedAdamW"  # clip inside the optimizer's launch
+            if clip is not None and not folded:
                 torch.nn.utils.clip_grad_norm_(model.parameters(), clip, norm_type=2)
             num_iter = 0
             if use_amp:

@@ -1,0 +1,173 @@
+"""pipeline.GraphPipeline -- the hipGraph schedule that train.train_one_epoch and bench.py run -- against the plain eager loop
+on the same batches:
+
+  * ownership: with frozen weights (lr = 0) every result the pipeline yields belongs to ONE batch -- the batches come out in
+    the order they went in, the logits are bit-identical to the eager model's on that batch (the searches, sampling and every
+    forward kernel are deterministic) and the loss agrees: the sampling plan, the neighbourhood / loss geometry and the
+    features that met in a feature graph all belonged to the same batch, for every lane, both joint buffers and both
+    ping-pong variants (the former AMC3D_CHECK_BATCHES switch of bench.py as a test);
+  * training: after K FusedAdamW steps the parameters equal the eager loop's.  Not bit for bit: the loss backward and the
+    interpolation backward add rows with float atomics, whose order differs from run to run in BOTH loops (two eager runs
+    differ by as much: measured in the test and used as the yardstick);
+  * a scheduler's new learning rate reaches the captured update (FusedAdamW.sync_hyperparameters);
+  * building the pipeline leaves parameters, BatchNorm buffers and optimizer state as they were.
+"""
+import itertools
+
+import pytest
+import torch
+
+from amcontrast3d_amd import configs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+B, N = 2, 2048
+
+
+def _setup(lr, fused=True, seed=0):
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from openpoints.loss import build_criterion_from_cfg
+    from openpoints.models import build_model_from_cfg
+    from openpoints.optim import build_optimizer_from_cfg
+    from openpoints.utils import EasyConfig
+    torch.manual_seed(seed)
+    c = EasyConfig(); c.update(configs.model_cfg("S", dropout=0, width=16))
+    model = build_model_from_cfg(c).to(DEV).train()
+    cc = EasyConfig(); cc.update(configs.criterion_cfg())
+    crit = build_criterion_from_cfg(cc).to(DEV)
+    aa = EasyConfig(); aa.update(configs.ambiguity_args("s3dis"))
+    opt = (build_optimizer_from_cfg(model, NAME="adamw", lr=lr, weight_decay=1e-4) if fused
+           else torch.optim.SGD(model.parameters(), lr=lr))
+    return model, crit, aa, opt
+
+
+def _batches(n, first=500):
+    from amcontrast3d_amd import synthetic
+    return [{k: torch.from_numpy(v).to(DEV) for k, v in synthetic.make_batch(B, N, first_id=first + 7 * i).items()} for i in range(n)]
+
+
+def _pipeline(model, crit, aa, opt, example, lanes, **kw):
+    from amcontrast3d_amd.pipeline import GraphPipeline
+
+    def step_loss(data):
+        logits, stage = model(data)
+        return logits, crit(logits, data["y"], stage, 13, None, aa), ()
+    main = torch.cuda.Stream()
+    main.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(main):
+        pipe = GraphPipeline(model, step_loss, crit.contrast_head, opt, example, 13, None, aa, lanes=lanes, max_grad_norm=10, **kw)
+    return pipe, main
+
+
+def _eager_step(model, crit, aa, opt, data, clip=10):
+    logits, stage = model(dict(data))
+    loss = crit(logits, data["y"], stage, 13, None, aa)
+    opt.zero_grad()
+    loss.backward()
+    if type(opt).__name__ == "FusedAdamW":
+        opt.step(max_grad_norm=clip)
+    else:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+        opt.step()
+    return logits.detach(), loss.detach()
+
+
+@pytest.mark.parametrize("lanes,nb", [(2, 11), (3, 14), (4, 9)])
+def test_every_result_belongs_to_one_batch_in_order(lanes, nb):
+    model, crit, aa, opt = _setup(0.0, fused=False)
+    src = _batches(nb)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    pipe, main = _pipeline(model, crit, aa, opt, src[0], lanes)
+    for k, v in model.state_dict().items():  # three warm-up steps ran on the example batch: nothing of them may remain
+        assert torch.equal(v, before[k]), k
+    got = []
+    with torch.cuda.stream(main):
+        for out in pipe.run(iter(src)):
+            got.append((out["data"]["pos"].clone(), out["logits"].clone(), float(out["loss"]), out["target"].clone()))
+    torch.cuda.synchronize()
+    assert len(got) == nb
+    model2, crit2, aa2, opt2 = _setup(0.0, fused=False)
+    for i, (pos, logits, loss, target) in enumerate(got):
+        assert torch.equal(pos, src[i]["pos"]) and torch.equal(target, src[i]["y"]), f"result {i} is not batch {i}"
+        want_logits, want_loss = _eager_step(model2, crit2, aa2, opt2, src[i])
+        assert torch.equal(logits, want_logits), f"batch {i}: logits differ from the eager model's (max {float((logits - want_logits).abs().max()):.2e})"
+        assert abs(loss - float(want_loss)) <= 1e-6 * abs(float(want_loss)), (i, loss, float(want_loss))
+    # the BatchNorm running statistics advanced exactly as in the eager loop (every batch normalised once, in order)
+    for (k, a), b in zip(model.state_dict().items(), model2.state_dict().values()):
+        assert torch.equal(a, b), k
+    # a second pass over other batches on the same graphs (the next epoch)
+    src2 = _batches(5, first=900)
+    with torch.cuda.stream(main):
+        outs = [(o["data"]["pos"].clone(), o["logits"].clone()) for o in pipe.run(iter(src2))]
+    assert len(outs) == 5
+    for i, (pos, logits) in enumerate(outs):
+        assert torch.equal(pos, src2[i]["pos"])
+        assert torch.equal(logits, _eager_step(model2, crit2, aa2, opt2, src2[i])[0])
+
+
+def _params_after(loop, steps, fused, lr, seed_batches=300):
+    model, crit, aa, opt = _setup(lr, fused=fused)
+    src = _batches(steps, first=seed_batches)
+    loop(model, crit, aa, opt, src)
+    torch.cuda.synchronize()
+    return [p.detach().clone() for p in model.parameters()]
+
+
+@pytest.mark.parametrize("fused,lr,K", [(False, 0.01, 6), (True, 1e-3, 3)])
+def test_parameters_after_k_steps_match_the_eager_loop(fused, lr, K):
+    """SGD (update launched eagerly after the feature graph) and FusedAdamW (update captured).  AdamW's first steps are
+    ~lr * sign(g), so rounding-level differences of near-zero gradients become 2 * lr differences of single weights in any two
+    runs: the yardstick is two runs of the eager loop"""
+
+    def eager(model, crit, aa, opt, src):
+        for b in src:
+            _eager_step(model, crit, aa, opt, b)
+
+    def piped(model, crit, aa, opt, src):
+        pipe, main = _pipeline(model, crit, aa, opt, src[0], 2)
+        with torch.cuda.stream(main):
+            n = sum(1 for _ in pipe.run(iter(src)))
+        assert n == len(src)
+
+    a, a2, b = _params_after(eager, K, fused, lr), _params_after(eager, K, fused, lr), _params_after(piped, K, fused, lr)
+    # yardstick: two runs of the EAGER loop (float atomics in the loss / interpolation backward reorder their sums)
+    # (a tensor whose true gradient is zero -- a conv bias in front of a BatchNorm -- moves by rounding noise only: every
+    # tensor is judged on a scale of at least 1e-2, the size of the smallest initialised weights)
+    noise = max(float((x - y).abs().max()) / max(float(x.abs().max()), 1e-2) for x, y in zip(a, a2))
+    worst = max(float((x - y).abs().max()) / max(float(x.abs().max()), 1e-2) for x, y in zip(a, b))
+    print(f"parameters after {K} {'AdamW' if fused else 'SGD'} steps: pipeline vs eager {worst:.2e} (relative to each tensor's range); eager vs eager {noise:.2e}")
+    assert worst <= max(4 * noise, 1e-5), (worst, noise)
+
+
+def test_a_schedulers_learning_rate_reaches_the_captured_update():
+    model, crit, aa, opt = _setup(0.01)
+    src = _batches(6, first=40)
+    pipe, main = _pipeline(model, crit, aa, opt, src[0], 2)
+    assert pipe.g_update is not None, "FusedAdamW's step is captured"
+    lrs = [0.01, 0.01, 0.0, 0.0, 0.0, 0.0]   # lr -> 0 after the second step: later steps may only apply weight decay * 0 = nothing
+    snaps = []
+    with torch.cuda.stream(main):
+        for i, out in enumerate(pipe.run(iter(src))):
+            snaps.append([p.detach().clone() for p in model.parameters()])
+            for g in opt.param_groups:
+                g["lr"] = lrs[min(i + 1, len(lrs) - 1)]
+    torch.cuda.synchronize()
+    assert any(not torch.equal(x, y) for x, y in zip(snaps[0], snaps[1])), "step 2 ran with lr 0.01"
+    for later in snaps[2:]:
+        for x, y in zip(snaps[1], later):
+            assert torch.equal(x, y), "a step with lr = 0 moved a parameter: the captured update did not see the new lr"
+
+
+def test_endless_feed_and_describe():
+    model, crit, aa, opt = _setup(0.01)
+    pool = _batches(3, first=70)
+    pipe, main = _pipeline(model, crit, aa, opt, pool[0], 2, keep_state=False)
+    with torch.cuda.stream(main):
+        run = pipe.run(itertools.cycle(pool))
+        losses = [float(next(run)["loss"]) for _ in range(9)]
+    assert all(torch.isfinite(torch.tensor(losses)))
+    d = pipe.describe()
+    assert d["launch"].startswith("hipGraph") and d["batches_per_joint_fps_launch"] == 2 and d["update"] == "captured"
+    parts = pipe.parts_alone(reps=2)
+    assert parts["features_ms"] > 0 and pipe.serial_ms(reps=2) > 0

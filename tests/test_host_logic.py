@@ -349,91 +349,65 @@ def test_reference_overlay_and_native_module_registration():
     sys.modules.pop("pointnet2_batch_cuda"); sys.modules.pop("pointops_cuda")
 
 
-@pytest.mark.parametrize("lanes,joint,npool,all_levels", [
-    (2, True, 4, False), (2, False, 4, False), (2, True, 3, False), (3, False, 4, False), (2, True, 5, False), (1, False, 4, False),
-    (3, True, 4, False), (4, True, 4, False), (4, True, 6, False),
-    (3, True, 4, True), (4, True, 4, True), (6, True, 4, True),
-    (7, True, 4, True), (12, True, 4, True)])   # all_levels: the joint launch runs every sampling level
-def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, joint, npool, all_levels):
-    """bench.py's pipelined loop replayed with batch ids instead of tensors (amcontrast3d_amd/schedule.py holds its index
-    arithmetic): at every step the feature half must see ONE batch -- its points, its four FPS levels and its neighbourhood /
-    loss geometry -- a first-level FPS result must be `lanes` (joint: 2-3) steps old when it is consumed (it takes about a step),
-    no first-level input may be overwritten between launch and consumption, and the batches come round-robin from the pool."""
+@pytest.mark.parametrize("lanes", [2, 3, 4, 7, 12])
+@pytest.mark.parametrize("nbatches", [1, 5, 24, 31])
+def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, nbatches):
+    """pipeline.GraphPipeline's tick loop replayed with batch ids instead of tensors (amcontrast3d_amd/schedule.py holds its index
+    arithmetic): every batch trains exactly once, in the order it entered, on ONE consistent set -- its points, its own FPS
+    result and the neighbourhood / loss geometry computed from both -- a joint FPS launch has `lanes` ticks before its first
+    lane is consumed, no lane is overwritten between its launch and its consumption, and a result set is never refilled
+    before the feature variant that reads it has run."""
     from amcontrast3d_amd import schedule
-    pingpong = True
-    period = schedule.period(lanes, npool, pingpong, joint)
-    assert period % lanes == 0 and period % npool == 0 and period % 2 == 0 and (not joint or period % (2 * lanes) == 0)
-    fps1 = lambda b: ("fps1", b)            # noqa: E731  first FPS level of batch b
-    fps2 = lambda f: ("fps2", f[1])         # noqa: E731  levels 2-4, from the first level
-    geo = lambda b, f: ("geo", b, f)        # noqa: E731  neighbourhoods of batch b computed with the sampling f
-    # bench.py's initial buffers
-    in_b, in_a1s = 1 % npool, 2 % npool
-    if joint:
-        in_a = [[(3 + lanes * j + t) % npool for t in range(lanes)] for j in range(2)]
-        full = (lambda b: (fps1(b), fps2(fps1(b)))) if all_levels else fps1
-        a1_out = [[full(b) for b in row] for row in in_a]
-        launched = [[-10 - lanes] * lanes, [-10 - lanes] * lanes]  # primed before step 0
-    else:
-        in_a = [(3 + l) % npool for l in range(lanes)]
-        a1_out = [fps1(b) for b in in_a]
-        launched = [-10 - lanes] * lanes
-    a1_stable = fps1(in_a1s)
-    a2_out = fps2(a1_stable)
-    a_stable = (fps1(in_b), fps2(fps1(in_b)))
-
-    def at(what, buf):
-        for i in buf:
-            what = what[i]
-        return what
-
-    def put(what, buf, v):
-        for i in buf[:-1]:
-            what = what[i]
-        what[buf[-1]] = v
-
-    n0 = 0
-    # ping-pong: two sets of stream B's inputs (batch, FPS picks) and results; the feature variant of step n reads set
-    # variants(n)[0], which stream B's variant filled -- inputs by rotate_side, results by B -- during step n - 1
-    v0 = schedule.variants(n0 % period, pingpong)[0]
+    J = lanes
+    src = iter(range(nbatches))
+    joint_in = [[None] * J, [None] * J]     # batch id per lane
+    joint_fps = [[None] * J, [None] * J]    # ("fps", id) once launched
+    launched_at = [None, None]
+    lane_valid = [[False] * J, [False] * J]
     sets = [None, None]
-    sets[v0] = {"batch": in_b, "fps": a_stable, "geo": geo(in_b, a_stable)}   # the priming copy + replay of stream B
-    seen = []
-    for n in range(n0, n0 + 6 * period):
-        s = n % period
-        reads, fills = schedule.variants(s, pingpong)
-        assert reads != fills
-        # (nothing moves on the main stream)
-        # rotate_side (geometry queue)
-        plan = schedule.side_step(s, lanes, joint, npool)
-        assert n - at(launched, plan["consume"]) >= lanes, "first-level FPS consumed before it can have finished"
-        if all_levels:  # the consumed lane goes straight into stream B's input set
-            sets[fills] = {"batch": at(in_a, plan["consume"]), "fps": at(a1_out, plan["consume"])}
-            assert sets[fills]["fps"][0] == fps1(sets[fills]["batch"]), "an input buffer was overwritten before its consumption"
-        else:
-            sets[fills] = {"batch": in_a1s, "fps": (a1_stable, a2_out)}
-            a1_stable, in_a1s = at(a1_out, plan["consume"]), at(in_a, plan["consume"])
-            assert a1_stable == fps1(in_a1s), "an input buffer was overwritten between its FPS launch and its consumption"
-        for buf, pi in plan["load"]:
-            put(in_a, buf, pi)
-        # first-level FPS launch (finishes about a step later; modelled as reading its inputs now)
+    set_valid = [False, False]
+    read_pending = [False, False]           # set filled but not yet trained on
+    trained = []
+    t, busy = 0, True
+    while busy:
+        plan = schedule.tick_plan(t, J)
+        v0, v1 = plan["train"], plan["fill"]
+        assert v0 != v1
+        if set_valid[v0]:
+            st = sets[v0]
+            assert st["fps"] == ("fps", st["batch"]) and st["geo"] == ("geo", st["batch"], st["fps"])
+            trained.append(st["batch"])
+            read_pending[v0] = False
+        jc, l = plan["consume"]
+        assert not read_pending[v1], "a result set is refilled before its feature variant ran"
+        if lane_valid[jc][l]:
+            assert t - launched_at[jc] >= J, "a lane is consumed before its joint FPS launch can have finished"
+            assert joint_fps[jc][l] == ("fps", joint_in[jc][l]), "a lane was overwritten between launch and consumption"
+            sets[v1] = {"batch": joint_in[jc][l], "fps": joint_fps[jc][l]}
+        set_valid[v1], lane_valid[jc][l] = lane_valid[jc][l], False
         if plan["launch"] is not None:
-            if joint:
-                j = plan["launch"]
-                a1_out[j] = [full(b) for b in in_a[j]]
-                launched[j] = [n] * lanes
-            else:
-                a1_out[plan["launch"]] = fps1(in_a[plan["launch"]])
-                launched[plan["launch"]] = n
-        if not all_levels:
-            a2_out = fps2(a1_stable)                               # stream A2
-        sets[fills]["geo"] = geo(sets[fills]["batch"], sets[fills]["fps"])   # stream B, variant `fills`
-        # the feature half, variant `reads`
-        cur = sets[reads]
-        assert cur["fps"] == (fps1(cur["batch"]), fps2(fps1(cur["batch"]))), (n, cur)
-        assert cur["geo"] == geo(cur["batch"], cur["fps"]), (n, cur)
-        seen.append(cur["batch"])
-    seen = seen[4 * lanes + 4:]              # the initial contents of the buffers drain first
-    assert all(seen[i + 1] == (seen[i] + 1) % npool for i in range(len(seen) - 1)), seen
+            jl = plan["launch"]
+            assert jl != jc and not any(lane_valid[jl]), "a joint buffer is reloaded while lanes of it are still to be consumed"
+            got = 0
+            for k in range(J):
+                b = next(src, None)
+                if b is None:
+                    break
+                joint_in[jl][k] = b
+                got += 1
+            lane_valid[jl] = [k < got for k in range(J)]
+            if got:
+                joint_fps[jl] = [("fps", b) for b in joint_in[jl]]
+                launched_at[jl] = t
+        if set_valid[v1]:
+            sets[v1]["geo"] = ("geo", sets[v1]["batch"], sets[v1]["fps"])
+            read_pending[v1] = True
+        busy = set_valid[v1] or any(lane_valid[0]) or any(lane_valid[1])
+        t += 1
+        assert t < 4 * (nbatches + 4 * J), "the pipeline does not drain"
+    assert trained == list(range(nbatches))
+    assert schedule.period(J) == 2 * J and all(schedule.tick_plan(k, J) == schedule.tick_plan(k + 2 * J, J) for k in range(2 * J))
+
 
 
 def test_confusion_matrix_counts_and_rejects_out_of_range_labels():
