@@ -8,4 +8,8 @@ remaining keys of `cfg` as keyword arguments -- the entry point examples/segment
 from openpoints.utils.registry import Registry
 
 MODELS = Registry('models')
-build_model_from_cfg = MODELS.build
+
+
+def build_model_from_cfg(cfg, **kwargs):
+    """Build the model named by ``cfg.NAME`` (same parameter names as the reference: callers may pass ``cfg=``)."""
+    return MODELS.build(cfg, **kwargs)
