@@ -520,6 +520,6 @@ def test_main_AA_imports_and_call_sites_resolve_against_this_package():
               "openpoints.dataset.data_util:voxelize"):
         assert res.get(k) == "reference", (k, res.get(k))  # out of scope: resolved from the overlay
     assert res["sig:build_model_from_cfg"][0] == "cfg" and res["sig:build_criterion_from_cfg"][0] == "cfg"
-    assert res["sig:criterion"][:7] == ["self", "logits", "target", "stageACE_list", "num_classes", "ignore_index", "ambiguity_args"], res["sig:criterion"]
+    assert res["sig:criterion"][:7] == ["self", "logit", "target", "stageACE_list", "num_classes", "ignore_index", "ambiguity_args"], res["sig:criterion"]
     assert res["sig:model"][:2] == ["self", "data"], res["sig:model"]
     assert len(res["registered"]) == 5
