@@ -209,6 +209,53 @@ __global__ void nbr_fill_kernel(int m, int k, int nbr_stride, const int *__restr
     if (nb >= 0 && nb < m) rev_edge[rev_start[nb] + atomicAdd(cursor + nb, 1)] = i * k + j;
 }
 
+// ---- mutual edges of the loss stages' k-NN graph ----------------------------------------------------------------------------
+// mutual[i*k + s] = how many times anchor i stands in the list of its s-th neighbour x = nbr[i][s] (0 or 1 in a k-NN graph;
+// 91 % of the edges of the 24-NN graph of an S3DIS-like batch are mutual, measured) -- counted at the FIRST slot that holds x
+// when a degenerate list names x more than once, 0 at the others, so that a walk over N(i) meets every incoming edge once.
+// The loss backward needs, for every point n, the sum over the anchors i that list n; for a mutual edge n meets i while it
+// walks its OWN list, so only the non-mutual edges of the selected anchors (0 < a <= 1) need reverse lists: a tenth of the
+// integer atomics of nbr_degree / nbr_fill over all edges.  One thread per edge; x's list is one or two cache lines.
+__global__ void nbr_mutual_kernel(int m, int k, int nbr_stride, const int *__restrict__ nbr, const float *__restrict__ a,
+                                  unsigned char *__restrict__ mutual, int *__restrict__ deg)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)m * k) return;
+    const int i = (int)(t / k), s = (int)(t - (long)i * k);
+    const int *li = nbr + (size_t)i * nbr_stride;
+    const int x = li[s];
+    int count = 0;
+    if (x >= 0 && x < m) {
+        const int *lx = nbr + (size_t)x * nbr_stride;
+        for (int j = 0; j < k; ++j) count += lx[j] == i;
+    }
+    bool first = true;
+    for (int j = 0; j < s; ++j) first &= li[j] != x;
+    mutual[t] = (unsigned char)(first ? (count < 255 ? count : 255) : 0);
+    const float ai = a[i];
+    if (count == 0 && x >= 0 && x < m && 0.f < ai && ai <= 1.f) atomicAdd(deg + x, 1);
+}
+
+__global__ void nbr_fill_nonmutual_kernel(int m, int k, int nbr_stride, const int *__restrict__ nbr, const float *__restrict__ a,
+                                          const unsigned char *__restrict__ mutual, const int *__restrict__ rev_start,
+                                          int *__restrict__ cursor, int *__restrict__ rev_edge)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)m * k) return;
+    const int i = (int)(t / k), s = (int)(t - (long)i * k);
+    const float ai = a[i];
+    if (!(0.f < ai && ai <= 1.f)) return;
+    const int *li = nbr + (size_t)i * nbr_stride;
+    const int x = li[s];
+    if (x < 0 || x >= m) return;
+    // non-mutual = i is nowhere in x's list.  mutual[] holds that count at the first slot of x in i's list only
+    int j0 = s;
+    for (int j = 0; j < s; ++j)
+        if (li[j] == x) { j0 = j; break; }
+    if (mutual[(size_t)i * k + j0]) return;
+    rev_edge[rev_start[x] + atomicAdd(cursor + x, 1)] = (int)t;
+}
+
 constexpr int NBR_SORT_MAX = 96;  // longer lists (degenerate clouds) keep their fill order
 __global__ void nbr_order_kernel(int m, const int *__restrict__ rev_start, int *__restrict__ rev_edge)
 {
@@ -291,6 +338,32 @@ AMC_API int amc3d_contrast_csr(int m, int k, int nbr_stride, const int *nbr, con
                        (const int *)rev, cursor, rev + m + 1);
     hipLaunchKernelGGL(nbr_order_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, m, (const int *)rev, rev + m + 1);
     return launch_status("amc3d_contrast_csr");
+}
+
+// mutual (m*k) bytes and rev = [rev_start (m+1) | rev_edge (<= m*k)]: the positions i*k + s, ascending per row, of the
+// NON-mutual edges of the selected anchors (0 < a[i] <= 1) that point at the row.  Workspace as amc3d_contrast_csr.
+AMC_API int amc3d_contrast_mutual(int m, int k, int nbr_stride, const int *nbr, const float *a, unsigned char *mutual, int *rev,
+                                  void *workspace, size_t workspace_bytes, void *stream_)
+{
+    if (m <= 0) return 0;
+    if (k <= 0 || nbr_stride < k || !nbr || !a || !mutual || !rev || !workspace || (long)m * k >= (1L << 31) ||
+        workspace_bytes < amc3d_contrast_csr_workspace_bytes(m))
+        return bad_arg("amc3d_contrast_mutual: bad argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    char *w = (char *)workspace;
+    int *deg = (int *)w; w += csr_align((size_t)(m + 1) * 4);
+    int *cursor = (int *)w; w += csr_align((size_t)(m + 1) * 4);
+    size_t temp = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, temp, (const int *)nullptr, (int *)nullptr, m + 1);
+    if (int st = fill_i32(deg, 0, (size_t)(cursor - deg) + m + 1, stream)) return st;  // deg and cursor, one launch
+    const long slots = (long)m * k;
+    hipLaunchKernelGGL(nbr_mutual_kernel, dim3(div_up(slots, 256)), dim3(256), 0, stream, m, k, nbr_stride, nbr, a, mutual, deg);
+    const hipError_t e = hipcub::DeviceScan::ExclusiveSum(w, temp, (const int *)deg, rev, m + 1, stream);
+    if (e != hipSuccess) { set_error("amc3d_contrast_mutual: scan: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(nbr_fill_nonmutual_kernel, dim3(div_up(slots, 256)), dim3(256), 0, stream, m, k, nbr_stride, nbr, a,
+                       (const unsigned char *)mutual, (const int *)rev, cursor, rev + m + 1);
+    hipLaunchKernelGGL(nbr_order_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, m, (const int *)rev, rev + m + 1);
+    return launch_status("amc3d_contrast_mutual");
 }
 
 // the moments buffer of amc3d_group_moments (same layout) from the reverse lists: exact in-degree, dp sums in list order

@@ -42,15 +42,18 @@ def plan_stage(n, i, stageACE_list, target, nstride, num_classes, ignore_index, 
                                    ambiguity_args.ccbeta, ambiguity_args.vis, ambiguity_args.nu)
     # the anchors the loss keeps (0 < a <= 1, :250-252) as a compact list for the fused contrast kernels
     anchors = ops.select_anchors(a) if a.is_cuda and a.dtype == torch.float32 else None
-    # Opt-in (AMC3D_CONTRAST_CSR=1): the reverse lists of their edges, along which the loss backward gathers instead of
-    # scattering with float atomics -- bit-reproducible gradients.  Measured on PointNeXt-S B=8 x 24000: the backward
-    # drops from 0.71 to 0.42 ms, building the lists (integer atomics + scan + per-list ordering) costs 0.79 ms on the
-    # geometry stream, and the step gets 0.2 ms slower; so it is not the default.
-    rev = None
+    # Reverse structure for the loss backward, so that it GATHERS every gradient row instead of scattering rows with float
+    # atomics (0.71 ms per step at the chip's float-atomic rate in round 2).  Default (round 3): the mutual-edge form --
+    # ~90 % of the k-NN edges are mutual and need no list at all (ops.contrast_mutual: a mutual bit per edge + reverse lists
+    # of the remaining tenth).  AMC3D_CONTRAST_CSR=1: round 2's reverse lists of ALL edges (0.79 ms of integer atomics on
+    # the geometry stream); AMC3D_CONTRAST_ATOMIC=1: the float-atomic form.
+    rev = mutual = None
     if anchors is not None and os.environ.get("AMC3D_CONTRAST_CSR"):
         rev = ops.contrast_csr(neighbor_idx, anchors)
+    elif anchors is not None and not os.environ.get("AMC3D_CONTRAST_ATOMIC"):
+        mutual, rev = ops.contrast_mutual(neighbor_idx, a)
     return {'neighbor_idx': neighbor_idx, 'posmask': posmask, 'ambiguity': a, 'shares': shares, 'anchors': anchors,
-            'rev': rev}
+            'rev': rev, 'mutual': mutual}
 
 
 def _stage_plan(n, i, stageACE_list, target, nstride, num_classes, ignore_index, ambiguity_args, ftype):
@@ -161,7 +164,8 @@ class ContrastHead(nn.Module):
             # anchors with 0 < a <= 1 enter the loss (MarginContrast.py:250-257); selection, cosine
             # similarity, margin soft-NN loss and the mean are one forward and one backward kernel
             loss = ops.contrast_stage(features, neighbor_idx, posmask, ambiguity_soft, ambiguity_args.mu,
-                                      ambiguity_args.nu, ambiguity_args.temperature, g.get('anchors'), g.get('rev'))
+                                      ambiguity_args.nu, ambiguity_args.temperature, g.get('anchors'), g.get('rev'),
+                                      g.get('mutual'))
             return loss, output_ai, target_ai
         # other margin / decision-boundary / Method2 variants: composed from the torch-level pieces
         keep = torch.logical_and(0 < ambiguity_soft, ambiguity_soft <= 1)

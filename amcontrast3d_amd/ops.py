@@ -525,13 +525,34 @@ def contrast_csr(neighbor_idx, anchors):
     return rev
 
 
+def contrast_mutual(neighbor_idx, a):
+    """The mutual-edge structure of a loss stage's k-NN graph (csrc/csr.hip amc3d_contrast_mutual): neighbor_idx (m,k) int32
+    (may be idx[:, 1:]), a (m) the stage's ambiguities -> (mutual (m,k) uint8, rev int32 [rev_start (m+1) | rev_edge (m*k)]).
+    mutual[i,s] = 1 iff i is in the list of its s-th neighbour; rev lists, per row, the NON-mutual edges of the anchors with
+    0 < a <= 1 that point at it.  Coordinates and labels only: part of a stage's plan; ContrastStage's backward then
+    gathers every gradient row (no float atomics)."""
+    _need_gpu(neighbor_idx, a)
+    _need_dtype(torch.float32, a=a)
+    nptr, k, stride, keep = _nbr_view(neighbor_idx)
+    m = neighbor_idx.shape[0]
+    lib = _lib.load()
+    mutual = torch.empty(m, k, dtype=torch.uint8, device=a.device)
+    rev = torch.empty(m + 1 + m * k, dtype=torch.int32, device=a.device)
+    wbytes = int(lib.amc3d_contrast_csr_workspace_bytes(m))
+    work = torch.empty(wbytes, dtype=torch.uint8, device=a.device)
+    with torch.cuda.device(a.device), timing.span("contrast_mutual", m * k * 9 + m * 8, moved=m * k * (5 + 4 * k)):
+        _lib.check(lib.amc3d_contrast_mutual(m, k, stride, nptr, _ptr(a), _ptr(mutual), _ptr(rev), _ptr(work), wbytes,
+                                             _stream(a)), "contrast_mutual")
+    return mutual, rev
+
+
 class ContrastStage(Function):
     """Stage loss of ContrastHead.point_contrast_margin (MarginContrast.py:250-257): mean over the
     anchors with 0 < a <= 1 of the margin soft-NN loss on cosine similarities.  anchors: select_anchors(a) of
     the same a, or None (every anchor is then visited and tested)."""
 
     @staticmethod
-    def forward(ctx, features, neighbor_idx, posmask, a, mu, nu, temperature, anchors=None, rev=None):
+    def forward(ctx, features, neighbor_idx, posmask, a, mu, nu, temperature, anchors=None, rev=None, mutual=None):
         _need_gpu(features, neighbor_idx, posmask, a)
         f = features.contiguous()
         assert f.dtype == torch.float32 and posmask.dtype == torch.bool and posmask.is_contiguous()
@@ -554,18 +575,34 @@ class ContrastStage(Function):
         if rev is not None:
             _need_dtype(torch.int32, rev=rev)
             assert anchors is not None and rev.is_contiguous() and rev.numel() == m + 1 + m * k and rev.device == dev
-        ctx.save_for_backward(f, norm, keep, posmask, a, sim, mean_cnt, anchors, rev)
+        if mutual is not None:  # rev then holds the non-mutual edges only (contrast_mutual)
+            _need_dtype(torch.uint8, mutual=mutual)
+            assert rev is not None and mutual.is_contiguous() and mutual.shape == (m, k) and mutual.device == dev
+        ctx.save_for_backward(f, norm, keep, posmask, a, sim, mean_cnt, anchors, rev, mutual)
         ctx.args = (float(mu), float(nu), float(temperature), k, stride)
         return mean_cnt[0].clone()
 
     @staticmethod
     def backward(ctx, grad_out):
-        f, norm, nbr, posmask, a, sim, mean_cnt, anchors, rev = ctx.saved_tensors
+        f, norm, nbr, posmask, a, sim, mean_cnt, anchors, rev, mutual = ctx.saved_tensors
         mu, nu, temperature, k, stride = ctx.args
         m, C = f.shape
         g = grad_out.detach().to(torch.float32).reshape(1).contiguous()
         nptr = _ptr(nbr)  # data_ptr includes the offset of an idx[:, 1:] view: the first used column
         lib = _lib.load()
+        if mutual is not None and lib.amc3d_contrast_backward_csr_supported(C):
+            grad_f = torch.empty_like(f)  # every row is written
+            wb = int(lib.amc3d_contrast_backward_mutual_workspace_bytes(m))
+            work = torch.empty(wb, dtype=torch.uint8, device=f.device)
+            with torch.cuda.device(f.device), timing.span("contrast_backward", m * C * 8 + m * k * 10 + m * 8,
+                                                          moved=m * C * 4 * (2 + k) + m * k * 42 + m * 40):
+                _lib.check(lib.amc3d_contrast_backward_mutual(m, C, k, stride, _ptr(f), _ptr(norm), nptr, _ptr(posmask), _ptr(a),
+                                                              _ptr(mutual), _ptr(rev), mu, nu, temperature, _ptr(sim),
+                                                              _ptr(mean_cnt), _ptr(g), _ptr(work), wb, _ptr(grad_f), _stream(f)),
+                           "contrast_backward_mutual")
+            return (grad_f,) + (None,) * 9
+        if mutual is not None:
+            rev = None  # (a width the row kernels do not cover: the atomic form below; rev holds non-mutual edges only)
         if rev is not None and lib.amc3d_contrast_backward_csr_supported(C):
             grad_f = torch.empty_like(f)  # every row is written
             gco = torch.empty(m * k, dtype=torch.float32, device=f.device)
@@ -574,14 +611,14 @@ class ContrastStage(Function):
                                                            _ptr(a), _ptr(anchors), _ptr(rev), mu, nu, temperature,
                                                            _ptr(sim), _ptr(mean_cnt), _ptr(g), _ptr(gco), _ptr(grad_f),
                                                            _stream(f)), "contrast_backward_csr")
-            return grad_f, None, None, None, None, None, None, None, None
+            return (grad_f,) + (None,) * 9
         grad_f = torch.zeros_like(f)
         with torch.cuda.device(f.device), timing.span("contrast_backward", m * C * 8 + m * k * 9 + m * 8, moved=m * C * 4 * (1 + 2 * k) + m * k * 9):
             _lib.check(_lib.load().amc3d_contrast_backward(m, C, k, stride, _ptr(f), _ptr(norm), nptr, _ptr(posmask),
                                                            _ptr(a), _ptr(anchors) if anchors is not None else None,
                                                            mu, nu, temperature, _ptr(sim), _ptr(mean_cnt),
                                                            _ptr(g), _ptr(grad_f), _stream(f)), "contrast_backward")
-        return grad_f, None, None, None, None, None, None, None, None
+        return (grad_f,) + (None,) * 9
 
 
 contrast_stage = ContrastStage.apply

@@ -89,6 +89,8 @@ def operator_roofline(name, v, steps, traffic, rows, csv_name):
     ~ 20 flop/byte)."""
     nbytes, fl, tms, n = v["bytes"], v["flops"], v["total_ms"], max(v["launches"], 1)
     tr = traffic.get(name, {}).get("bytes_per_launch")
+    if tr is None and traffic.get(name, {}).get("bytes_per_step"):  # per step in the PMC table -> per operator launch
+        tr = traffic[name]["bytes_per_step"] / max(n / steps, 1e-9)
     out = {"kernel": name, "avg_launch_ms": round(tms / n, 4), "launches_per_step": round(n / steps, 2),
            "ms_per_step": round(tms / steps, 4), "algorithmic_bytes_per_launch": int(nbytes / n),
            "moved_bytes_per_launch": int(v.get("moved", nbytes) / n),

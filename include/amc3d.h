@@ -215,6 +215,25 @@ int amc3d_contrast_backward_csr(int m, int C, int k, int nbr_stride, const float
                                 float nu, float temperature, const float *sim, const float *mean_cnt,
                                 const float *grad_out, float *gco, float *grad_f, void *stream);
 
+/* The default since round 3: the gradient over the MUTUAL edges.  In the stages' k-NN graphs ~90 % of the edges are mutual
+ * (x in N(n) and n in N(x)); cosine and positive mask are symmetric in an edge's two ends, so row n, walking its own list
+ * once, computes both directions of every mutual edge from one fetch of f[x] and a 32-byte record of x; only the non-mutual
+ * edges of the selected anchors need reverse lists.  Every row of grad_f is WRITTEN once (no zero-initialisation), fixed
+ * summation order, no float atomics.
+ * amc3d_contrast_mutual: mutual (m*k) bytes, mutual[i*k+s] = 1 iff i is in the list of nbr[i][s]; rev = [rev_start (m+1) |
+ *   rev_edge (m*k)] int32: per row n the positions i*k+s, ascending, of the NON-mutual edges of the anchors with
+ *   0 < a[i] <= 1 that point at n.  Coordinates and labels only: part of the stage's plan.  Workspace:
+ *   amc3d_contrast_csr_workspace_bytes(m).
+ * amc3d_contrast_backward_mutual: workspace amc3d_contrast_backward_mutual_workspace_bytes(m) (the per-anchor records);
+ *   norm, sim, mean_cnt as amc3d_contrast_forward wrote them.  C in {16, 32, 64, 128, 256}. */
+int amc3d_contrast_mutual(int m, int k, int nbr_stride, const int *nbr, const float *a, unsigned char *mutual, int *rev,
+                          void *workspace, size_t workspace_bytes, void *stream);
+size_t amc3d_contrast_backward_mutual_workspace_bytes(int m);
+int amc3d_contrast_backward_mutual(int m, int C, int k, int nbr_stride, const float *f, const float *norm, const int *nbr,
+                                   const unsigned char *posmask, const float *a, const unsigned char *mutual, const int *rev,
+                                   float mu, float nu, float temperature, const float *sim, const float *mean_cnt,
+                                   const float *grad_out, void *workspace, size_t workspace_bytes, float *grad_f, void *stream);
+
 /* ---- grouped 1x1 convolution fused with its gather (fp32 MFMA) ------------------------------------
  * Replaces, for the first layer of a SetAbstraction / LocalAggregation MLP, the chain
  *   grouping_operation(features, idx) -> torch.cat([dp, fj], 1) -> nn.Conv2d 1x1 (bias-free)

@@ -89,7 +89,7 @@ def test_select_anchors(m, frac):
     assert torch.equal(sel[1:1 + want.numel()].long(), want)
 
 
-@pytest.mark.parametrize("listed", [True, False, "rev"])
+@pytest.mark.parametrize("listed", [True, False, "rev", "mutual"])
 @pytest.mark.parametrize("m,C,seed", [(3000, 32, 0), (1500, 64, 1), (800, 128, 2), (300, 256, 3), (200, 20, 4),
                                       (400, 16, 5), (100, 512, 6),
                                       # >= 16384 anchors: one wave per anchor forward, one lane group per anchor backward
@@ -104,6 +104,8 @@ def test_contrast_stage_other_neighbourhood_sizes(m, C, K):
     """k beyond one group of lanes (the backward walks the neighbours in chunks), and very small k"""
     _contrast_case(m, C, K, True, K)
     _contrast_case(m, C, K + 1, "rev", K)
+    if C in (32, 64, 128):
+        _contrast_case(m, C, K + 2, "mutual", K)
 
 
 def _contrast_case(m, C, seed, listed, K):
@@ -143,11 +145,66 @@ def _contrast_case(m, C, seed, listed, K):
         order = torch.argsort(tgt * (m * K) + pos)
         assert torch.equal(start, torch.searchsorted(tgt[order], torch.arange(m + 1)))
         assert torch.equal(edge[:pos.numel()], pos[order])
-    got = ops.contrast_stage(fg, idx_dev[:, 1:], posmask.to(DEV).contiguous(), a.to(DEV), mu, nu, T, anchors, rev)
+    mutual = None
+    if listed == "mutual":  # the default of the model's plan: a multiplicity per edge + reverse lists of the non-mutual edges
+        mutual, rev = ops.contrast_mutual(idx_dev[:, 1:], a.to(DEV))
+        mu_cpu, start, edge = mutual.cpu().long(), rev[:m + 1].cpu().long(), rev[m + 1:].cpu().long()
+        want_mut = torch.zeros(m, K - 1, dtype=torch.long)
+        nonmut = []
+        for i in range(m if m <= 1500 else 0):  # the structure against a plain enumeration (small cases)
+            row = nidx[i].long()
+            for sl in range(K - 1):
+                x = int(row[sl])
+                cnt = int((nidx[x].long() == i).sum())
+                if not bool((row[:sl] == x).any()):
+                    want_mut[i, sl] = cnt
+                if cnt == 0 and bool(keep[i]):
+                    nonmut.append((x, i * (K - 1) + sl))
+        if m <= 1500:
+            assert torch.equal(mu_cpu, want_mut)
+            nonmut.sort()
+            assert int(start[-1]) == len(nonmut) and edge[:len(nonmut)].tolist() == [p for _, p in nonmut]
+            assert torch.equal(start, torch.searchsorted(torch.tensor([x for x, _ in nonmut], dtype=torch.long), torch.arange(m + 1)))
+    got = ops.contrast_stage(fg, idx_dev[:, 1:], posmask.to(DEV).contiguous(), a.to(DEV), mu, nu, T, anchors, rev, mutual)
     assert abs(float(got) - float(want)) <= 1e-5 * max(1.0, abs(float(want)))
     (got * 0.9).backward()
     err = float((fg.grad.cpu() - fr.grad).norm() / fr.grad.norm())
     assert err <= 2e-5, err
+
+
+def test_contrast_backward_over_mutual_edges_on_a_real_knn_graph():
+    """The model's default since round 3: on the 24-NN graph of a synthetic batch (the flattened batch is one segment, as
+    the loss searches it) ~90 % of the edges are mutual; the gather over mutual edges + the reverse lists of the rest gives the
+    gradient of the float-atomic form, bit-reproducibly."""
+    from amcontrast3d_amd import ops, synthetic
+    nb = synthetic.make_batch(2, 6000, first_id=33)
+    p = torch.from_numpy(nb["pos"]).reshape(-1, 3).contiguous().to(DEV)
+    y = torch.from_numpy(nb["y"]).reshape(-1).to(DEV)
+    m = p.shape[0]
+    o = torch.tensor([m], dtype=torch.int32, device=DEV)
+    idx, _ = ops.knnquery(24, p, p, o, o)
+    nidx = idx[:, 1:]
+    posmask = ops.posmask_from_labels(y.int(), nidx)
+    g = torch.Generator().manual_seed(3)
+    a = torch.rand(m, generator=g).to(DEV)
+    a[torch.rand(m, generator=g).to(DEV) < 0.3] = 0.0
+    for C in (32, 64, 128, 256):
+        f = torch.randn(m, C, generator=g).to(DEV)
+        anchors = ops.select_anchors(a)
+        mutual, rev = ops.contrast_mutual(nidx, a)
+        share = float((mutual > 0).float().mean())
+        assert 0.8 < share < 1.0 and int(mutual.max()) == 1, share
+        grads = []
+        for kind in ("atomic", "mutual", "mutual"):
+            fg = f.clone().requires_grad_(True)
+            loss = ops.contrast_stage(fg, nidx, posmask, a, -1.0, 0.5, 0.3, anchors, rev if kind == "mutual" else None,
+                                      mutual if kind == "mutual" else None)
+            (loss * 0.9).backward()
+            grads.append(fg.grad.clone())
+        assert torch.equal(grads[1], grads[2]), "the gather form is bit-reproducible"
+        err = float((grads[1] - grads[0]).norm() / grads[0].norm())
+        assert err <= 2e-6, (C, err)
+    print(f"mutual share of the 24-NN edges: {share:.3f}; non-mutual edges listed: {int(rev[m])}")
 
 
 def test_contrast_stage_no_positive_anchor_is_constant():

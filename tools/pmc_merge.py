@@ -1,9 +1,11 @@
-"""Merge the FETCH_SIZE / WRITE_SIZE passes of scratch/pmc_round2.sh into one per-kernel table and the per-step total:
-python pmc_merge.py fetch.csv write.csv nsteps out.csv out.json
+"""Merge the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_passes.sh into one per-kernel table, the per-step total and the
+per-operator bytes (amcontrast3d_amd/roofline.py OPERATOR_KERNELS; only kernels that belong to ONE operator are attributed):
+python pmc_merge.py fetch.csv write.csv nsteps out.csv out.json [workload tag, e.g. S:192000]
 Units: rocprofv3 reports both counters in KB.  Correction (MI355X_MICROARCH.md, HBM): on gfx950 FETCH_SIZE tallies wide
 coalesced reads at half their bytes -> doubled; WRITE_SIZE is exact for 16-byte stores and float atomics."""
 import csv, json, sys
 fetch, write, nsteps, out_csv, out_json = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
+workload = sys.argv[6] if len(sys.argv) > 6 else None
 rows = {}
 for path, col in ((fetch, "fetch_kb"), (write, "write_kb")):
     for r in csv.DictReader(open(path)):
@@ -29,9 +31,26 @@ for b, k, d in table:
         if tag in k:
             fam[tag] = fam.get(tag, 0.0) + b
             break
-json.dump({"_step": {"bytes_per_step": tot, "amc_kernels_bytes_per_step": amc, "by_family_GB": {k: round(v / 1e9, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
-                     "note": "sum over every kernel of one eager train step of 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes, scratch/pmc_round2.sh)"}},
-          open(out_json, "w"), indent=1)
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from amcontrast3d_amd.roofline import OPERATOR_KERNELS
+owners = {}
+for op, pats in OPERATOR_KERNELS.items():
+    for pat in pats:
+        owners.setdefault(pat, []).append(op)
+ops = {}
+for b, k, d in table:
+    mine = {op for pat, os_ in owners.items() if pat in k and len(os_) == 1 for op in os_}
+    if len(mine) == 1:
+        op = mine.pop()
+        e = ops.setdefault(op, {"bytes_per_step": 0.0, "dispatches_per_step": 0.0})
+        e["bytes_per_step"] += b
+        e["dispatches_per_step"] += d["dispatches"] / nsteps
+out = {"_step": {"workload": workload, "bytes_per_step": tot, "amc_kernels_bytes_per_step": amc,
+                 "by_family_GB": {k: round(v / 1e9, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
+                 "note": "sum over every kernel of one eager train step of 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes, tools/pmc_passes.sh)"}}
+out.update(ops)
+json.dump(out, open(out_json, "w"), indent=1)
 print(f"HBM traffic per step: {tot / 1e9:.2f} GB (amc kernels {amc / 1e9:.2f} GB); top kernels:")
 for b, k, d in table[:14]: print(f"  {b / 1e6:8.1f} MB  x{d['dispatches'] / nsteps:5.1f}  {k[:100]}")
 print({k: round(v / 1e9, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])})
