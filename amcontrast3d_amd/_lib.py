@@ -47,7 +47,8 @@ SIGNATURES = {
     "amc3d_contrast_backward_csr_supported": (_i, [_i]),
     "amc3d_contrast_backward_csr": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp,
                                          _vp, _vp]),
-    "amc3d_contrast_mutual": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "amc3d_contrast_mutual_workspace_bytes": (_sz, [_i]),
+    "amc3d_contrast_mutual": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_contrast_backward_mutual_workspace_bytes": (_sz, [_i]),
     "amc3d_contrast_backward_mutual": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _sz,
                                             _vp, _vp]),

@@ -216,43 +216,107 @@ __global__ void nbr_fill_kernel(int m, int k, int nbr_stride, const int *__restr
 // The loss backward needs, for every point n, the sum over the anchors i that list n; for a mutual edge n meets i while it
 // walks its OWN list, so only the non-mutual edges of the selected anchors (0 < a <= 1) need reverse lists: a tenth of the
 // integer atomics of nbr_degree / nbr_fill over all edges.  One thread per edge; x's list is one or two cache lines.
-__global__ void nbr_mutual_kernel(int m, int k, int nbr_stride, const int *__restrict__ nbr, const float *__restrict__ a,
-                                  unsigned char *__restrict__ mutual, int *__restrict__ deg)
+// One wave per point i: lane s holds x_s = nbr[i][s]; the lists of two neighbours are read per step, lanes 0-31 the list of
+// x_t, lanes 32-63 that of x_{t+1} -- whole 92-byte rows per half-wave instead of k scattered 4-byte loads per edge thread --
+// and ALL steps' loads are issued before the first compare (the first version waited for each row in turn: 12 dependent
+// round trips per wave, 267 us for the 192000 points of the finest stage).  Counting is a ballot per step, no shuffles.
+// Bit 0x80 of mutual[] marks the edges the reverse lists take (non-mutual, anchor selected): the fill pass reads bytes only.
+__global__ __launch_bounds__(256) void nbr_mutual_kernel(int m, int k, int nbr_stride, const int *__restrict__ nbr,
+                                                         const float *__restrict__ a, unsigned char *__restrict__ mutual,
+                                                         int *__restrict__ deg)
+{
+    constexpr int STEPS = 32;  // k <= 64: two neighbours per step
+    const int lane = threadIdx.x & 63, half = lane >> 5, sub = lane & 31;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= m) return;
+    const float ai = a[i];
+    const bool selected = 0.f < ai && ai <= 1.f;
+    const int x = lane < k ? nbr[(size_t)i * nbr_stride + lane] : -1;
+    const bool valid = x >= 0 && x < m;
+    int v0[STEPS], v1[STEPS];  // entries sub and sub + 32 of the list of this half-wave's neighbour at every step
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        v0[st] = -1; v1[st] = -1;
+        if (2 * st < k) {  // wave-uniform
+            const int xt = __shfl(x, 2 * st + half, 64);
+            if (xt >= 0 && xt < m) {
+                if (sub < k) v0[st] = nbr[(size_t)xt * nbr_stride + sub];
+                if (sub + 32 < k) v1[st] = nbr[(size_t)xt * nbr_stride + sub + 32];
+            }
+        }
+    }
+    int count = 0;      // lane s: occurrences of i in the list of x_s
+    bool first = true;  // lane s: no earlier slot of this list names x_s (degenerate lists only)
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+        if (2 * st >= k) break;  // wave-uniform
+        const unsigned long long hit = __ballot(v0[st] == i) , hit2 = __ballot(v1[st] == i);
+        const int lo = __popc((unsigned)hit) + __popc((unsigned)hit2);
+        const int hi = __popc((unsigned)(hit >> 32)) + __popc((unsigned)(hit2 >> 32));
+        if (lane == 2 * st) count = lo;
+        if (lane == 2 * st + 1) count = hi;
+        const int xa = __shfl(x, 2 * st, 64), xb = __shfl(x, 2 * st + 1, 64);
+        first &= !(lane > 2 * st && xa == x) && !(lane > 2 * st + 1 && xb == x);
+    }
+    if (lane < k) {
+        const bool listed = valid && count == 0 && selected;
+        mutual[(size_t)i * k + lane] = (unsigned char)((first ? (count < 127 ? count : 127) : 0) | (listed ? 0x80 : 0));
+        if (listed) atomicAdd(deg + x, 1);
+    }
+}
+
+// The same bytes from the squared distances of the search that made the lists (amc3d_knnquery's dist2, same strides): in a
+// k-NN graph i is in the list of x exactly when d(i,x) is below x's largest kept distance -- ONE 4-byte gather per edge from a
+// compact, L2-resident array instead of x's whole list (the row-scan kernel above is bound by the rate of 128-byte lines out
+// of the Infinity Cache: 213 us for the 4.4 M edges of the finest stage).  dist2_ref(q, p) is bitwise symmetric in its
+// arguments, so both ends compare the same number.  Edges the comparison cannot decide -- equality with the bound (the
+// reference breaks such ties by scan order), zero distances (coincident points: column 0 of the search need not be the point
+// itself), unfilled slots of segments shorter than k (1e10) -- are decided as above, by scanning x's list.  dist2 may hold the
+// distances or their squares (the Python wrapper returns roots, pointops.py:55): any monotone image decides the same edges.
+__global__ void nbr_radius_kernel(int m, int k, int stride, const float *__restrict__ dist2, float *__restrict__ rk)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) rk[i] = dist2[(size_t)i * stride + k - 1];
+}
+
+__global__ __launch_bounds__(256) void nbr_mutual_dist_kernel(int m, int k, int nbr_stride, const int *__restrict__ nbr,
+                                                              const float *__restrict__ dist2, const float *__restrict__ rk,
+                                                              const float *__restrict__ a, unsigned char *__restrict__ mutual,
+                                                              int *__restrict__ deg)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)m * k) return;
     const int i = (int)(t / k), s = (int)(t - (long)i * k);
     const int *li = nbr + (size_t)i * nbr_stride;
     const int x = li[s];
+    const bool valid = x >= 0 && x < m;
+    const float d = dist2[(size_t)i * nbr_stride + s];
     int count = 0;
-    if (x >= 0 && x < m) {
-        const int *lx = nbr + (size_t)x * nbr_stride;
-        for (int j = 0; j < k; ++j) count += lx[j] == i;
-    }
     bool first = true;
-    for (int j = 0; j < s; ++j) first &= li[j] != x;
-    mutual[t] = (unsigned char)(first ? (count < 255 ? count : 255) : 0);
+    if (valid) {
+        const float r = rk[x];
+        if (d > 0.f && d < 9.0e4f && r < 9.0e4f && d != r) {  // (the placeholder of an unfilled slot is 1e10, or its root 1e5)
+            count = d < r ? 1 : 0;
+        } else {  // undecidable by distance: scan (rare)
+            const int *lx = nbr + (size_t)x * nbr_stride;
+            for (int j = 0; j < k; ++j) count += lx[j] == i;
+            for (int j = 0; j < s; ++j) first &= li[j] != x;
+        }
+    }
     const float ai = a[i];
-    if (count == 0 && x >= 0 && x < m && 0.f < ai && ai <= 1.f) atomicAdd(deg + x, 1);
+    const bool listed = valid && count == 0 && 0.f < ai && ai <= 1.f;
+    mutual[t] = (unsigned char)((first ? (count < 127 ? count : 127) : 0) | (listed ? 0x80 : 0));
+    if (listed) atomicAdd(deg + x, 1);
 }
 
-__global__ void nbr_fill_nonmutual_kernel(int m, int k, int nbr_stride, const int *__restrict__ nbr, const float *__restrict__ a,
+__global__ void nbr_fill_nonmutual_kernel(int m, int k, int nbr_stride, const int *__restrict__ nbr,
                                           const unsigned char *__restrict__ mutual, const int *__restrict__ rev_start,
                                           int *__restrict__ cursor, int *__restrict__ rev_edge)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long)m * k) return;
+    if (t >= (long)m * k || !(mutual[t] & 0x80)) return;
     const int i = (int)(t / k), s = (int)(t - (long)i * k);
-    const float ai = a[i];
-    if (!(0.f < ai && ai <= 1.f)) return;
-    const int *li = nbr + (size_t)i * nbr_stride;
-    const int x = li[s];
-    if (x < 0 || x >= m) return;
-    // non-mutual = i is nowhere in x's list.  mutual[] holds that count at the first slot of x in i's list only
-    int j0 = s;
-    for (int j = 0; j < s; ++j)
-        if (li[j] == x) { j0 = j; break; }
-    if (mutual[(size_t)i * k + j0]) return;
+    const int x = nbr[(size_t)i * nbr_stride + s];
     rev_edge[rev_start[x] + atomicAdd(cursor + x, 1)] = (int)t;
 }
 
@@ -342,13 +406,17 @@ AMC_API int amc3d_contrast_csr(int m, int k, int nbr_stride, const int *nbr, con
 
 // mutual (m*k) bytes and rev = [rev_start (m+1) | rev_edge (<= m*k)]: the positions i*k + s, ascending per row, of the
 // NON-mutual edges of the selected anchors (0 < a[i] <= 1) that point at the row.  Workspace as amc3d_contrast_csr.
-AMC_API int amc3d_contrast_mutual(int m, int k, int nbr_stride, const int *nbr, const float *a, unsigned char *mutual, int *rev,
-                                  void *workspace, size_t workspace_bytes, void *stream_)
+AMC_API size_t amc3d_contrast_mutual_workspace_bytes(int m) { return amc3d_contrast_csr_workspace_bytes(m) + csr_align((size_t)(m > 0 ? m : 0) * 4); }
+
+// dist2: NULL, or the squared distances of the search that produced nbr (same row stride, pointing at the same first column):
+// the fast path of nbr_mutual_dist_kernel.  Only for lists that ARE the k nearest of their row (amc3d_knnquery, self search).
+AMC_API int amc3d_contrast_mutual(int m, int k, int nbr_stride, const int *nbr, const float *dist2, const float *a,
+                                  unsigned char *mutual, int *rev, void *workspace, size_t workspace_bytes, void *stream_)
 {
     if (m <= 0) return 0;
-    if (k <= 0 || nbr_stride < k || !nbr || !a || !mutual || !rev || !workspace || (long)m * k >= (1L << 31) ||
-        workspace_bytes < amc3d_contrast_csr_workspace_bytes(m))
-        return bad_arg("amc3d_contrast_mutual: bad argument");
+    if (k <= 0 || k > 64 || nbr_stride < k || !nbr || !a || !mutual || !rev || !workspace || (long)m * k >= (1L << 31) ||
+        workspace_bytes < amc3d_contrast_mutual_workspace_bytes(m))
+        return bad_arg("amc3d_contrast_mutual: bad argument (k must be in 1..64)");
     hipStream_t stream = (hipStream_t)stream_;
     char *w = (char *)workspace;
     int *deg = (int *)w; w += csr_align((size_t)(m + 1) * 4);
@@ -357,10 +425,17 @@ AMC_API int amc3d_contrast_mutual(int m, int k, int nbr_stride, const int *nbr, 
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, temp, (const int *)nullptr, (int *)nullptr, m + 1);
     if (int st = fill_i32(deg, 0, (size_t)(cursor - deg) + m + 1, stream)) return st;  // deg and cursor, one launch
     const long slots = (long)m * k;
-    hipLaunchKernelGGL(nbr_mutual_kernel, dim3(div_up(slots, 256)), dim3(256), 0, stream, m, k, nbr_stride, nbr, a, mutual, deg);
+    if (dist2) {
+        float *rk = (float *)((char *)workspace + amc3d_contrast_csr_workspace_bytes(m));
+        hipLaunchKernelGGL(nbr_radius_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, m, k, nbr_stride, dist2, rk);
+        hipLaunchKernelGGL(nbr_mutual_dist_kernel, dim3(div_up(slots, 256)), dim3(256), 0, stream, m, k, nbr_stride, nbr, dist2,
+                           (const float *)rk, a, mutual, deg);
+    } else {
+        hipLaunchKernelGGL(nbr_mutual_kernel, dim3(div_up(m, 4)), dim3(256), 0, stream, m, k, nbr_stride, nbr, a, mutual, deg);
+    }
     const hipError_t e = hipcub::DeviceScan::ExclusiveSum(w, temp, (const int *)deg, rev, m + 1, stream);
     if (e != hipSuccess) { set_error("amc3d_contrast_mutual: scan: %s", hipGetErrorString(e)); return (int)e; }
-    hipLaunchKernelGGL(nbr_fill_nonmutual_kernel, dim3(div_up(slots, 256)), dim3(256), 0, stream, m, k, nbr_stride, nbr, a,
+    hipLaunchKernelGGL(nbr_fill_nonmutual_kernel, dim3(div_up(slots, 256)), dim3(256), 0, stream, m, k, nbr_stride, nbr,
                        (const unsigned char *)mutual, (const int *)rev, cursor, rev + m + 1);
     hipLaunchKernelGGL(nbr_order_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, m, (const int *)rev, rev + m + 1);
     return launch_status("amc3d_contrast_mutual");

@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256) void contrast_backward_mutual_kernel(
             if (t < k) {  // own list: the edge n -> x, and x -> n when it is mutual
                 x[u] = nbr[(size_t)n * nbr_stride + t];
                 pos[u] = posmask[(size_t)n * k + t] != 0;
-                inc[u] = (float)mutual[(size_t)n * k + t];
+                inc[u] = (float)(mutual[(size_t)n * k + t] & 0x7f);
                 own[u] = coef_n != 0.f;
                 if (!own[u] && inc[u] == 0.f) x[u] = -1;  // nothing flows along this edge
             } else if (t < total) {  // a non-mutual incoming edge x -> n

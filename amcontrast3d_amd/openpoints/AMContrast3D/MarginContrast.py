@@ -35,7 +35,7 @@ def plan_stage(n, i, stageACE_list, target, nstride, num_classes, ignore_index, 
     from amcontrast3d_amd import ops
     p, o = stageACE_list[n][i]['p_out'], stageACE_list[n][i]['offset']  # no embeddings needed here
     labels, _ = get_subscene_class(n, i, stageACE_list, target, nstride, num_classes, ignore_index)
-    neighbor_idx, _ = pointops.knnquery(ambiguity_args.nsample, p, p, o, o)
+    neighbor_idx, neighbor_d2 = pointops.knnquery(ambiguity_args.nsample, p, p, o, o)
     neighbor_idx = neighbor_idx[..., 1:]  # drop the self match: a strided view, no copy
     posmask = ops.posmask_from_labels(labels, neighbor_idx)
     a, shares = ambiguity_function(p, posmask, neighbor_idx.shape[1], neighbor_idx, ambiguity_args.cctype,
@@ -50,8 +50,11 @@ def plan_stage(n, i, stageACE_list, target, nstride, num_classes, ignore_index, 
     rev = mutual = None
     if anchors is not None and os.environ.get("AMC3D_CONTRAST_CSR"):
         rev = ops.contrast_csr(neighbor_idx, anchors)
-    elif anchors is not None and not os.environ.get("AMC3D_CONTRAST_ATOMIC"):
-        mutual, rev = ops.contrast_mutual(neighbor_idx, a)
+    elif anchors is not None and neighbor_idx.shape[1] <= 64 and not os.environ.get("AMC3D_CONTRAST_ATOMIC"):
+        # (one segment of more than k + 1 points: every list is full, membership follows from one distance comparison)
+        d2 = neighbor_d2[..., 1:] if (torch.is_tensor(neighbor_d2) and neighbor_d2.dtype == torch.float32 and o.numel() == 1
+                                      and neighbor_d2.shape[0] == neighbor_idx.shape[0] > neighbor_idx.shape[1] + 2) else None
+        mutual, rev = ops.contrast_mutual(neighbor_idx, a, d2)
     return {'neighbor_idx': neighbor_idx, 'posmask': posmask, 'ambiguity': a, 'shares': shares, 'anchors': anchors,
             'rev': rev, 'mutual': mutual}
 

@@ -525,23 +525,30 @@ def contrast_csr(neighbor_idx, anchors):
     return rev
 
 
-def contrast_mutual(neighbor_idx, a):
+def contrast_mutual(neighbor_idx, a, dist2=None):
     """The mutual-edge structure of a loss stage's k-NN graph (csrc/csr.hip amc3d_contrast_mutual): neighbor_idx (m,k) int32
     (may be idx[:, 1:]), a (m) the stage's ambiguities -> (mutual (m,k) uint8, rev int32 [rev_start (m+1) | rev_edge (m*k)]).
     mutual[i,s] = 1 iff i is in the list of its s-th neighbour; rev lists, per row, the NON-mutual edges of the anchors with
     0 < a <= 1 that point at it.  Coordinates and labels only: part of a stage's plan; ContrastStage's backward then
-    gathers every gradient row (no float atomics)."""
+    gathers every gradient row (no float atomics).  dist2: the squared distances knnquery returned with neighbor_idx (the
+    same view of them) when the lists are the self-search of the stage's cloud -- membership then follows from one distance
+    comparison per edge; None scans the neighbours' lists (any lists)."""
     _need_gpu(neighbor_idx, a)
     _need_dtype(torch.float32, a=a)
     nptr, k, stride, keep = _nbr_view(neighbor_idx)
     m = neighbor_idx.shape[0]
     lib = _lib.load()
+    dptr = None
+    if dist2 is not None:
+        _need_dtype(torch.float32, dist2=dist2)
+        assert dist2.shape == neighbor_idx.shape and dist2.stride() == neighbor_idx.stride() and dist2.device == a.device
+        dptr = _ptr(dist2)
     mutual = torch.empty(m, k, dtype=torch.uint8, device=a.device)
     rev = torch.empty(m + 1 + m * k, dtype=torch.int32, device=a.device)
-    wbytes = int(lib.amc3d_contrast_csr_workspace_bytes(m))
+    wbytes = int(lib.amc3d_contrast_mutual_workspace_bytes(m))
     work = torch.empty(wbytes, dtype=torch.uint8, device=a.device)
-    with torch.cuda.device(a.device), timing.span("contrast_mutual", m * k * 9 + m * 8, moved=m * k * (5 + 4 * k)):
-        _lib.check(lib.amc3d_contrast_mutual(m, k, stride, nptr, _ptr(a), _ptr(mutual), _ptr(rev), _ptr(work), wbytes,
+    with torch.cuda.device(a.device), timing.span("contrast_mutual", m * k * 9 + m * 8, moved=m * k * (13 if dist2 is not None else 5 + 4 * k)):
+        _lib.check(lib.amc3d_contrast_mutual(m, k, stride, nptr, dptr, _ptr(a), _ptr(mutual), _ptr(rev), _ptr(work), wbytes,
                                              _stream(a)), "contrast_mutual")
     return mutual, rev
 

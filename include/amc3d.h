@@ -220,14 +220,16 @@ int amc3d_contrast_backward_csr(int m, int C, int k, int nbr_stride, const float
  * once, computes both directions of every mutual edge from one fetch of f[x] and a 32-byte record of x; only the non-mutual
  * edges of the selected anchors need reverse lists.  Every row of grad_f is WRITTEN once (no zero-initialisation), fixed
  * summation order, no float atomics.
- * amc3d_contrast_mutual: mutual (m*k) bytes, mutual[i*k+s] = 1 iff i is in the list of nbr[i][s]; rev = [rev_start (m+1) |
+ * amc3d_contrast_mutual: mutual (m*k) bytes, mutual[i*k+s] = how often i is in the list of nbr[i][s] (0 / 1 in a k-NN graph;
+ *   counted at the first slot naming that neighbour); rev = [rev_start (m+1) |
  *   rev_edge (m*k)] int32: per row n the positions i*k+s, ascending, of the NON-mutual edges of the anchors with
- *   0 < a[i] <= 1 that point at n.  Coordinates and labels only: part of the stage's plan.  Workspace:
+ *   0 < a[i] <= 1 that point at n (those edges also carry bit 0x80 in mutual[]; the count is in the low 7 bits).  k <= 64.  Coordinates and labels only: part of the stage's plan.  Workspace:
  *   amc3d_contrast_csr_workspace_bytes(m).
  * amc3d_contrast_backward_mutual: workspace amc3d_contrast_backward_mutual_workspace_bytes(m) (the per-anchor records);
  *   norm, sim, mean_cnt as amc3d_contrast_forward wrote them.  C in {16, 32, 64, 128, 256}. */
-int amc3d_contrast_mutual(int m, int k, int nbr_stride, const int *nbr, const float *a, unsigned char *mutual, int *rev,
-                          void *workspace, size_t workspace_bytes, void *stream);
+size_t amc3d_contrast_mutual_workspace_bytes(int m);
+int amc3d_contrast_mutual(int m, int k, int nbr_stride, const int *nbr, const float *dist2, const float *a,
+                          unsigned char *mutual, int *rev, void *workspace, size_t workspace_bytes, void *stream);
 size_t amc3d_contrast_backward_mutual_workspace_bytes(int m);
 int amc3d_contrast_backward_mutual(int m, int C, int k, int nbr_stride, const float *f, const float *norm, const int *nbr,
                                    const unsigned char *posmask, const float *a, const unsigned char *mutual, const int *rev,
