@@ -63,6 +63,7 @@ SIGNATURES = {
     "amc3d_grouped_conv_forward": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_grouped_conv_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "amc3d_grouped_conv_backward": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "amc3d_confusion_update": (_i, [_i, _i, _l, _vp, _vp, _ll, _i, _vp, _vp, _vp]),
     "amc3d_cross_entropy_workspace_bytes": (_sz, [_i, _l]),
     "amc3d_cross_entropy_forward": (_i, [_i, _i, _l, _vp, _vp, _ll, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_cross_entropy_backward": (_i, [_i, _i, _l, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp]),

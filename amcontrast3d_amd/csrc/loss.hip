@@ -984,6 +984,55 @@ AMC_API int amc3d_contrast_backward_mutual(int m, int C, int k, int nbr_stride, 
     return launch_status("amc3d_contrast_backward_mutual");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Confusion matrix of the training predictions (main_AA.py:414-415: cm.update(logits.argmax(dim=1), target), every
+// iteration): arg-max over the class planes of channel-major logits (first maximum, as torch.argmax) and a v x v histogram,
+// v = C (+1 when an ignore label exists: points with target == ignore count in the extra row/column, utils/metrics.py).  One
+// launch: a histogram per workgroup in LDS, then one 64-bit atomic per non-empty bin -- the tensor form is an arg-max, ten
+// elementwise launches and 192000 int64 atomics onto 169 addresses.  invalid += points whose target is outside [0, v).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void confusion_kernel(int C, long N, int v, long long ignore, int has_ignore,
+                                                        const float *__restrict__ logits, const long long *__restrict__ target,
+                                                        long long *__restrict__ cm, long long *__restrict__ invalid)
+{
+    extern __shared__ int s_bins[];  // v * v + 1
+    for (int i = threadIdx.x; i <= v * v; i += 256) s_bins[i] = 0;
+    __syncthreads();
+    const int b = blockIdx.y;
+    for (long n = (long)blockIdx.x * 256 + threadIdx.x; n < N; n += (long)gridDim.x * 256) {
+        const float *lp = logits + (size_t)b * C * N + n;
+        float best = lp[0];
+        int arg = 0;
+        for (int c = 1; c < C; ++c) {
+            const float x = lp[(size_t)c * N];
+            if (x > best || (x != x && best == best)) { best = x; arg = c; }  // first maximum; a NaN wins, as in torch
+        }
+        long long t = target[(size_t)b * N + n];
+        int p = arg;
+        if (has_ignore && t == ignore) { t = v - 1; p = v - 1; }
+        if (t >= 0 && t < v) atomicAdd(&s_bins[(int)t * v + p], 1);
+        else atomicAdd(&s_bins[v * v], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < v * v; i += 256)
+        if (s_bins[i]) atomicAdd((unsigned long long *)(cm + i), (unsigned long long)s_bins[i]);
+    if (threadIdx.x == 0 && s_bins[v * v]) atomicAdd((unsigned long long *)invalid, (unsigned long long)s_bins[v * v]);
+}
+
+// cm (v*v) int64 += histogram of (target, argmax_c logits) over the B*N points; invalid (1) int64 += out-of-range targets.
+// v = C + has_ignore <= 64.
+AMC_API int amc3d_confusion_update(int B, int C, long N, const float *logits, const long long *target, long long ignore,
+                                   int has_ignore, long long *cm, long long *invalid, void *stream_)
+{
+    if (B <= 0 || N <= 0) return 0;
+    const int v = C + (has_ignore ? 1 : 0);
+    if (C <= 0 || v > 64 || !logits || !target || !cm || !invalid) return bad_arg("amc3d_confusion_update: bad argument (at most 64 classes)");
+    const int bx = (int)(div_up(N, 256) < 64 ? div_up(N, 256) : 64);
+    hipLaunchKernelGGL(confusion_kernel, dim3(bx, B), dim3(256), (size_t)(v * v + 1) * sizeof(int), (hipStream_t)stream_, C, N, v, ignore,
+                       has_ignore, logits, target, cm, invalid);
+    return launch_status("amc3d_confusion_update");
+}
+
 AMC_API size_t amc3d_cross_entropy_workspace_bytes(int B, long N)
 {
     return (size_t)(B > 0 ? B : 0) * (size_t)div_up(N > 0 ? N : 1, CE_THREADS) * 2 * sizeof(double);

@@ -59,6 +59,25 @@ class ConfusionMatrix:
         self.value = self.value + bins.view(v, v)[:self.num_classes, :self.num_classes]
         self.invalid = self.invalid + (~valid).sum()
 
+    @torch.no_grad()
+    def update_from_logits(self, logits, true):
+        """update(logits.argmax(dim=1), true) -- what the trainer does every iteration (main_AA.py:414-415) -- as ONE launch on
+        the GPU (ops.confusion_update: arg-max + histogram); anything else goes through update()"""
+        v = self.virtual_num_classes
+        if not (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 3 and true.dtype == torch.int64
+                and logits.shape[1] == self.num_classes and v <= 64 and true.shape == (logits.shape[0], logits.shape[2])):
+            return self.update(logits.argmax(dim=1), true)
+        from amcontrast3d_amd import ops
+        if not torch.is_tensor(self.value):
+            self._full = torch.zeros(v, v, dtype=torch.int64, device=logits.device)
+            self.invalid = torch.zeros(1, dtype=torch.int64, device=logits.device)
+            self.value = self._full[:self.num_classes, :self.num_classes]  # a view: the kernel adds into the full matrix
+        elif getattr(self, "_full", None) is None or self.value.data_ptr() != self._full.data_ptr():
+            return self.update(logits.argmax(dim=1), true)  # update() replaced the matrix in between: stay on that path
+        if not torch.is_tensor(self.invalid) or self.invalid.dim() == 0:
+            self.invalid = torch.zeros(1, dtype=torch.int64, device=logits.device) + self.invalid
+        ops.confusion_update(self._full, self.invalid, logits, true, self.ignore_index)
+
     def check(self):
         """raise if update() met a label / prediction outside the class range (reads one scalar back)"""
         n = int(self.invalid)
@@ -69,6 +88,7 @@ class ConfusionMatrix:
     def reset(self):
         self.value = 0
         self.invalid = 0
+        self._full = None
 
     # ---- per-class vectors --------------------------------------------------------------------
     @property

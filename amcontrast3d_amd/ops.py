@@ -1663,6 +1663,23 @@ def library_gemm_conv(x, weight):
     return LibraryGemmConv.apply(x, weight)
 
 
+def confusion_update(cm, invalid, logits, target, ignore_index=None):
+    """cm (v,v) int64 += histogram of (target, argmax_c logits) for logits (B,C,N) fp32 and target (B,N) int64 -- the
+    trainer's `cm.update(logits.argmax(dim=1), target)` (main_AA.py:414-415) as one launch; v = C (+1 with an ignore label:
+    such points count in the extra row / column, openpoints/utils/metrics.py).  invalid (1) int64 += out-of-range targets."""
+    _need_gpu(logits, target, cm, invalid)
+    _need_dtype(torch.float32, logits=logits)
+    _need_dtype(torch.int64, target=target, cm=cm, invalid=invalid)
+    logits, target = logits.contiguous(), target.contiguous()
+    B, C, N = logits.shape
+    v = C + (1 if ignore_index is not None else 0)
+    assert cm.is_contiguous() and cm.shape == (v, v) and target.shape == (B, N)
+    with torch.cuda.device(logits.device), timing.span("confusion_update", logits.numel() * 4 + target.numel() * 8):
+        _lib.check(_lib.load().amc3d_confusion_update(B, C, N, _ptr(logits), _ptr(target), int(ignore_index if ignore_index is not None else 0),
+                                                      int(ignore_index is not None), _ptr(cm), _ptr(invalid), _stream(logits)),
+                   "confusion_update")
+
+
 class CrossEntropyMean(Function):
     """nn.CrossEntropyLoss()(logits.transpose(1, 2).reshape(-1, C), target.flatten()) -- default arguments: mean
     over the targets != ignore_index -- on the channel-major logits (B, C, N) as the model returns them

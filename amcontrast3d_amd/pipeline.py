@@ -206,7 +206,9 @@ class GraphPipeline:
         # are background work with slack and slow the feature half more than they gain when they spread over the chip)
         ncu = torch.cuda.get_device_properties(self.dev).multi_processor_count
         if geometry_cus is None:
-            geometry_cus = 10 * ncu // 16 if self.N <= 24576 else 0
+            import os
+            sixteenths = int(os.environ.get("AMC3D_GEO_CUS_16THS", "10"))  # (sweeps)
+            geometry_cus = sixteenths * ncu // 16 if self.N <= 24576 else 0
         self.s_fps, self.s_geo = _dedicated_queues(self.dev, geometry_cus)
         self.geometry_cus = geometry_cus
         self.ev_lane = [torch.cuda.Event(), torch.cuda.Event()]
@@ -428,6 +430,9 @@ class GraphPipeline:
         """one tick: train the batch in input set v0 (if it holds one), prepare the next one's geometry, every J ticks
         load J new batches and launch their sampling.  -> (result dict or None, pipeline still holds batches)"""
         from . import schedule
+        import os
+        # diagnostic: leave parts out once every buffer holds results (they go stale; timing only, with one resident batch)
+        skip = os.environ.get("AMC3D_PIPE_SKIP", "") if self.tick > 6 * self.lanes else ""
         J, t = self.lanes, self.tick % (2 * self.lanes)
         self.tick += 1
         plan = schedule.tick_plan(t, J)
@@ -442,7 +447,8 @@ class GraphPipeline:
         with torch.cuda.stream(self.s_geo):
             self.s_geo.wait_event(self.ev_main)
             self.s_geo.wait_event(self.ev_lane[jc])
-            self.g_side[t].replay()
+            if "side" not in skip:
+                self.g_side[t].replay()
             self._set_valid[v1], self._lane_valid[jc][l] = self._lane_valid[jc][l], False
             launch = False
             if jl is not None:  # J new batches into the buffer whose lanes were all consumed J ticks ago
@@ -461,10 +467,12 @@ class GraphPipeline:
         if launch:
             with torch.cuda.stream(self.s_fps):
                 self.s_fps.wait_event(self.ev_rot)
-                self.g_fps[jl].replay()
+                if "fps" not in skip:
+                    self.g_fps[jl].replay()
                 self.ev_lane[jl].record(self.s_fps)
         with torch.cuda.stream(self.s_geo):
-            self.g_geo[v1].replay()
+            if "geo" not in skip:
+                self.g_geo[v1].replay()
             self.ev_geo.record(self.s_geo)
         return out, self._set_valid[v1] or any(self._lane_valid[0]) or any(self._lane_valid[1])
 

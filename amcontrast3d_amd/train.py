@@ -152,8 +152,11 @@ def _run_epoch(model, train_loader, criterion, optimizer, scheduler, scaler, epo
             for out in pipe.run(same_shape(itertools.chain([first], batches))):
                 if not cfg.sched_on_epoch:
                     scheduler.step(epoch)
-                cm.update(out["logits"].argmax(dim=1), out["target"])
-                loss_sum += torch.stack([out["loss"].detach()] + [v.detach() for v in out["parts"]]).double()
+                cm.update_from_logits(out["logits"], out["target"])
+                if extras:
+                    loss_sum.add_(torch.stack([out["loss"].detach()] + [v.detach() for v in out["parts"]]))
+                else:
+                    loss_sum.add_(out["loss"].detach().reshape(1))  # one launch (the fp32 -> fp64 promotion happens in it)
                 n_batches += 1
         cur.wait_stream(main)
         batches = iter(odd)
@@ -186,7 +189,7 @@ def _run_epoch(model, train_loader, criterion, optimizer, scheduler, scaler, epo
             optimizer.zero_grad()
             if not cfg.sched_on_epoch:
                 scheduler.step(epoch)
-        cm.update(logits.argmax(dim=1), target)
+        cm.update_from_logits(logits, target)
         loss_sum += torch.stack([loss.detach()] + [v.detach() for v in parts]).double()
         n_batches += 1
     miou, macc, oa, ious, accs = cm.all_metrics()

@@ -367,7 +367,7 @@ def main():
             scfg = EasyConfig()
             scfg.update({"sched": "cosine", "epochs": 100, "min_lr": 1e-5, "warmup_epochs": 0, "lr": 0.01})
             sched = build_scheduler_from_cfg(scfg, opt)
-            nb = max(100, 5 * args.steps)  # an epoch long enough that filling the pipeline (one joint FPS launch + one geometry pass, ~14 ms) is noise
+            nb = max(200, 5 * args.steps)  # an S3DIS-sized epoch (~200 iterations): filling the pipeline once (one joint FPS launch + one geometry pass, ~14 ms) is then 1 % of it
             for rep in range(2):  # the first epoch builds (and caches) the loop's own pipeline
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()

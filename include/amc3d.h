@@ -255,6 +255,13 @@ int amc3d_grouped_conv_backward(int b, int cin, int cout, int n, int npoints, in
                                 const float *dp, const int *idx, const float *weight, const float *dy,
                                 float *df_pm, float *dweight, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Confusion matrix of the training predictions (examples/segmentation/main_AA.py:414-415, utils/metrics.py:50-75:
+ * cm.update(logits.argmax(dim=1), target) every iteration): cm (v*v) int64 += histogram of (target, arg-max over the class
+ * planes of logits (B,C,N); first maximum as torch.argmax), v = C + has_ignore <= 64 (points whose target == ignore count in
+ * the extra row and column); invalid (1) int64 += points whose target lies outside [0, v).  One launch. */
+int amc3d_confusion_update(int B, int C, long N, const float *logits, const long long *target, long long ignore,
+                           int has_ignore, long long *cm, long long *invalid, void *stream);
+
 /* ---- cross entropy over channel-major logits -----------------------------------------------------
  * nn.CrossEntropyLoss() with its defaults (mean over targets != ignore_index) as CrossEntropyAce applies it
  * (openpoints/loss/build.py:328,338-340), without the (B*N, C) transposed copy of the logits.

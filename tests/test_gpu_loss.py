@@ -244,3 +244,32 @@ def test_cross_entropy_matches_torch(B, C, N, ignored):
     (got * 0.7).backward()
     (want * 0.7).backward()
     assert float((lg.grad - lr.grad).abs().max()) <= 1e-6 * max(1.0, float(lr.grad.abs().max()) * 10)
+
+
+@pytest.mark.parametrize("B,C,N,ignore", [(8, 13, 24000, None), (2, 20, 5000, -100), (1, 13, 77, None), (3, 5, 1000, 255)])
+def test_confusion_matrix_from_logits_is_update_of_the_argmax(B, C, N, ignore):
+    """ConfusionMatrix.update_from_logits (one launch: csrc/loss.hip confusion_kernel) == update(logits.argmax(dim=1), target),
+    the call the trainer makes every iteration (main_AA.py:414-415), including ignored labels, equal logits (first maximum)
+    and an out-of-range label."""
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from openpoints.utils import ConfusionMatrix
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    logits = torch.randn(B, C, N, generator=g)
+    logits[:, :, ::7] = logits[:, :1, ::7]          # all classes equal: the first wins
+    logits[:, 2, 1::11] = logits[:, 4 % C, 1::11]   # two-way ties
+    target = torch.randint(0, C, (B, N), generator=g)
+    if ignore is not None:
+        target[torch.rand(B, N, generator=g) < 0.2] = ignore
+    logits, target = logits.to(DEV), target.to(DEV)
+    a, b = ConfusionMatrix(C, ignore), ConfusionMatrix(C, ignore)
+    for _ in range(2):
+        a.update(logits.argmax(dim=1), target)
+        b.update_from_logits(logits, target)
+    assert torch.equal(a.value, b.value) and int(a.invalid) == int(b.invalid) == 0
+    for x, y in zip(a.all_metrics(), b.all_metrics()):
+        assert torch.equal(torch.as_tensor(x), torch.as_tensor(y))
+    target[0, 3] = C + 5  # outside the class range: counted, not binned
+    a.update(logits.argmax(dim=1), target)
+    b.update_from_logits(logits, target)
+    assert torch.equal(a.value, b.value) and int(a.invalid) == int(b.invalid) == 1
