@@ -305,6 +305,7 @@ class GraphPipeline:
     # -- capture ------------------------------------------------------------------------------------------------------
     def _build(self, example):
         from .graphs import SegmentedGraph, quiesce
+        import os
         import torch.distributed as tdist
         J, B = self.lanes, self.B
         ex = {k: example[k] for k in self.keys}
@@ -331,6 +332,7 @@ class GraphPipeline:
         for _ in range(3):
             eager_step()
         torch.cuda.synchronize()
+        has_grad = [p.grad is not None for p in self.params]
         dist_on = tdist.is_available() and tdist.is_initialized()
         if dist_on:
             quiesce()  # c10d's watchdog must not poll an event of a stream that is capturing
@@ -351,23 +353,41 @@ class GraphPipeline:
             def check(t):
                 assert t.untyped_storage().data_ptr() not in other, "the geometry plan aliases another batch's buffers"
             geometry._walk(r, check)
-        # feature variants.  The second must deliver its gradients in the FIRST variant's .grad tensors (the update graph
-        # reads those): captured with .grad still set, autograd would accumulate into them, so it runs with .grad = None
-        # and ends with one multi-tensor copy into the first variant's buffers
+        # One rank, nothing between backward and update (no gradient all-reduce, no SyncBatchNorm cuts): the update is the tail
+        # of both feature graphs -- one graph launch per step instead of two (the launch of the update graph and the gap in front
+        # of it were ~0.1 ms of the 0.25 ms the main stream idled per step)
+        fused = type(self.opt).__name__ == "FusedAdamW"
+        self.update_in_feature_graph = (self.flatg is None and not self.sync_bn and not os.environ.get("AMC3D_SEPARATE_UPDATE")
+                                        and (fused or all(g.get("capturable", False) for g in self.opt.param_groups)))
+        # feature variants.  Both deliver their gradients in ONE set of static .grad tensors (what the update reads, captured or
+        # not): backward runs with .grad = None -- captured with .grad set, autograd would ACCUMULATE into it, last step's
+        # gradient plus this one's -- and ends with one multi-tensor copy into the static tensors (3 MB for PointNeXt-S)
+        static = None
+        if self.flatg is None:
+            static = [torch.zeros_like(p) if h else None for p, h in zip(self.params, has_grad)]  # (who gets one: the warm-up steps)
+            for p, g0 in zip(self.params, static):
+                p.grad = g0
+            if fused:
+                self.opt.prepare()  # the tensor table of the update, built outside the capture
         self.g_feat = []
         for v in range(2):
             data = dict(self.set_in[v])
             data["_geometry"] = geometry.join(self.set_fps[v], self.rest[v])
-            keep = [p.grad for p in self.params] if v else None
 
-            def body(data=data, v=v, keep=keep):
-                if keep is not None and self.flatg is None:
+            def body(data=data, v=v):
+                if static is not None:
                     for p in self.params:
                         p.grad = None
                 self._fwd_bwd(data, self.out[v])
-                if keep is not None and self.flatg is None:
-                    pairs = [(g0, p.grad) for g0, p in zip(keep, self.params) if g0 is not None and p.grad is not None]
+                if static is not None:
+                    assert all((g0 is None) == (p.grad is None) for g0, p in zip(static, self.params)), \
+                        "a parameter's gradient appeared / vanished between the warm-up and the capture"
+                    pairs = [(g0, p.grad) for g0, p in zip(static, self.params) if g0 is not None]
                     torch._foreach_copy_([a for a, _ in pairs], [b for _, b in pairs])
+                    for p, g0 in zip(self.params, static):
+                        p.grad = g0
+                if self.update_in_feature_graph:
+                    self._update()
             if self.sync_bn:  # the statistics all-reduces are not captured: a chain of graphs with eager collectives between
                 g = SegmentedGraph(mode).capture(body, stream=self.main)
             else:
@@ -376,16 +396,13 @@ class GraphPipeline:
                 with torch.cuda.graph(g, stream=self.main, capture_error_mode=mode, **kw):
                     body()
             self.g_feat.append(g)
-            if keep is not None and self.flatg is None:
-                assert all((g0 is None) == (p.grad is None) for g0, p in zip(keep, self.params)), "variants disagree on which parameters get gradients"
-                for p, g0 in zip(self.params, keep):
-                    p.grad = g0
         # the update: captured where the optimizer allows it
         self.g_update = None
-        fused = type(self.opt).__name__ == "FusedAdamW"
-        if fused or all(g.get("capturable", False) for g in self.opt.param_groups):
+        if self.update_in_feature_graph:
+            pass
+        elif fused or all(g.get("capturable", False) for g in self.opt.param_groups):
             if fused:
-                self.opt.prepare()  # the .grad tensors are the feature graph's now: rebuild the tensor table before capture
+                self.opt.prepare()
             self.g_update = G()
             with torch.cuda.graph(self.g_update, stream=self.main, capture_error_mode=mode):
                 self._update()
@@ -413,15 +430,19 @@ class GraphPipeline:
         return 2 * self.lanes
 
     def _critical_path(self, v0):
-        self.g_feat[v0].replay()
-        if self.flatg is not None:
-            self.flatg.allreduce()
-        if self.g_update is not None:
+        captured = self.g_update is not None or self.update_in_feature_graph
+        if captured:
             lr = tuple(g["lr"] for g in self.opt.param_groups)
             if lr != self._lr:  # a scheduler stepped: the captured update reads its learning rates from device memory
                 if hasattr(self.opt, "sync_hyperparameters"):
                     self.opt.sync_hyperparameters()
                 self._lr = lr
+        self.g_feat[v0].replay()
+        if self.update_in_feature_graph:
+            return
+        if self.flatg is not None:
+            self.flatg.allreduce()
+        if self.g_update is not None:
             self.g_update.replay()
         else:
             self._update()
@@ -507,7 +528,8 @@ class GraphPipeline:
             torch.cuda.synchronize()
             return round((time.perf_counter() - t) / reps * 1e3, 3)
         return {"features_ms": alone(self.g_feat[0].replay, self.main),
-                "update_ms": alone(self.g_update.replay if self.g_update is not None else self._update, self.main),
+                "update_ms": (0.0 if self.update_in_feature_graph else
+                              alone(self.g_update.replay if self.g_update is not None else self._update, self.main)),
                 "fps_all_levels_joint_launch_ms": alone(self.g_fps[0].replay, self.s_fps),
                 "neighbourhood_geometry_ms": alone(self.g_geo[0].replay, self.s_geo),
                 "hand_down_ms": alone(self.g_side[0].replay, self.s_geo)}
@@ -530,7 +552,8 @@ class GraphPipeline:
                 st.synchronize()
             if self.flatg is not None:
                 self.flatg.allreduce()
-            (self.g_update.replay if self.g_update is not None else self._update)()
+            if not self.update_in_feature_graph:
+                (self.g_update.replay if self.g_update is not None else self._update)()
             self.main.synchronize()
         return round((time.perf_counter() - t) / reps * 1e3, 3)
 
@@ -540,7 +563,8 @@ class GraphPipeline:
         return {"launch": "hipGraph replay", "batches_per_joint_fps_launch": J, "look_ahead_batches": [J + 1, 2 * J],
                 "geometry_queue_cus": self.geometry_cus or "all", "feature_graph_segments": seg,
                 "collectives_per_step": getattr(self.g_feat[0], "collectives", 0) + (1 if self.flatg is not None else 0),
-                "update": "captured" if self.g_update is not None else "eager",
+                "update": ("captured in the feature graph" if self.update_in_feature_graph else
+                           "captured" if self.g_update is not None else "eager"),
                 "pipeline": (f"3 queues: sampling (all FPS levels of {J} future batches as one launch every {J} steps) | neighbourhood + "
                              "loss geometry of the next batch (CU-masked) | features of this batch; geometry handed over without "
                              "copies (two captured variants each)")}

@@ -144,7 +144,7 @@ def test_a_schedulers_learning_rate_reaches_the_captured_update():
     model, crit, aa, opt = _setup(0.01)
     src = _batches(6, first=40)
     pipe, main = _pipeline(model, crit, aa, opt, src[0], 2)
-    assert pipe.g_update is not None, "FusedAdamW's step is captured"
+    assert pipe.g_update is not None or pipe.update_in_feature_graph, "FusedAdamW's step is captured"
     lrs = [0.01, 0.01, 0.0, 0.0, 0.0, 0.0]   # lr -> 0 after the second step: later steps may only apply weight decay * 0 = nothing
     snaps = []
     with torch.cuda.stream(main):
@@ -168,6 +168,6 @@ def test_endless_feed_and_describe():
         losses = [float(next(run)["loss"]) for _ in range(9)]
     assert all(torch.isfinite(torch.tensor(losses)))
     d = pipe.describe()
-    assert d["launch"].startswith("hipGraph") and d["batches_per_joint_fps_launch"] == 2 and d["update"] == "captured"
+    assert d["launch"].startswith("hipGraph") and d["batches_per_joint_fps_launch"] == 2 and d["update"].startswith("captured")
     parts = pipe.parts_alone(reps=2)
     assert parts["features_ms"] > 0 and pipe.serial_ms(reps=2) > 0
