@@ -126,7 +126,7 @@ def precompute_refine(model, plan):
     for i in range(-1, -len(stages) - 1, -1):
         xyz = stages[4 + i]["p_out"]
         o = _segment_offset(xyz.shape[0], xyz.device)
-        idx, _ = ops.knnquery(k, xyz, xyz, o, o)
+        idx, _ = ops.knnquery_squared(k, xyz, xyz, o, o)  # (the distances are not used: no root taken)
         out[i] = idx[..., 1:].contiguous()
     return out
 

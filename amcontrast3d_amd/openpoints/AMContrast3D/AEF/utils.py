@@ -41,7 +41,8 @@ def get_subscene_class(stage_n, stage_i, stage_list, target, nstride, num_classe
     kr = int(torch.prod(nstride[:stage_i]))
     src = stage_list['up'][0]
     dst = stage_list[stage_n][stage_i]
-    neighbor_idx, _ = pointops.knnquery(kr, src['p_out'], dst['p_out'], src['offset'], dst['offset'])
+    knn = ops.knnquery_squared if labels0.is_cuda else pointops.knnquery  # (the distances are not used: no root taken)
+    neighbor_idx, _ = knn(kr, src['p_out'], dst['p_out'], src['offset'], dst['offset'])
     return ops.vote_labels(labels0, neighbor_idx, num_classes), num_classes
 
 

@@ -35,7 +35,8 @@ def plan_stage(n, i, stageACE_list, target, nstride, num_classes, ignore_index, 
     from amcontrast3d_amd import ops
     p, o = stageACE_list[n][i]['p_out'], stageACE_list[n][i]['offset']  # no embeddings needed here
     labels, _ = get_subscene_class(n, i, stageACE_list, target, nstride, num_classes, ignore_index)
-    neighbor_idx, neighbor_d2 = pointops.knnquery(ambiguity_args.nsample, p, p, o, o)
+    knn = ops.knnquery_squared if p.is_cuda else pointops.knnquery  # (distances: any monotone image serves contrast_mutual)
+    neighbor_idx, neighbor_d2 = knn(ambiguity_args.nsample, p, p, o, o)
     neighbor_idx = neighbor_idx[..., 1:]  # drop the self match: a strided view, no copy
     posmask = ops.posmask_from_labels(labels, neighbor_idx)
     a, shares = ambiguity_function(p, posmask, neighbor_idx.shape[1], neighbor_idx, ambiguity_args.cctype,

@@ -424,6 +424,8 @@ class KNNQuery(Function):
                                           _ptr(new_offset), _ptr(idx), _ptr(dist2), _ptr(work), work.numel(),
                                           int(reuse), _stream(xyz)), "knnquery")
         ctx.mark_non_differentiable(idx)
+        if _knn_squared:  # knnquery_squared(): the plan code wants no root (one elementwise launch per search on the geometry queue)
+            return idx, dist2
         return idx, torch.sqrt(dist2)
 
     @staticmethod
@@ -432,6 +434,18 @@ class KNNQuery(Function):
 
 
 knnquery = KNNQuery.apply
+_knn_squared = False
+
+
+def knnquery_squared(nsample, xyz, new_xyz, offset, new_offset):
+    """knnquery that leaves the distances SQUARED, as the kernel (and the reference's knnquery_cuda) produces them: the
+    reference's wrapper takes the root in a separate elementwise op (pointops.py:55), which the loss's plan never looks at"""
+    global _knn_squared
+    prev, _knn_squared = _knn_squared, True
+    try:
+        return KNNQuery.apply(nsample, xyz, new_xyz, offset, new_offset)
+    finally:
+        _knn_squared = prev
 
 
 # ----------------------------------------------------------------------------------------------

@@ -11,6 +11,7 @@ rounding luck, not correctness.  Intermediate decoder features are compared at 1
 range."""
 
 GRAD_RTOL = 3e-2
+GRAD_RTOL_ROUTED = 2e-3  # (measured 4.8e-4) with the max-pool routing of the two runs made equal (test_gradients_with_the_max_pools_routed_alike)
 
 
 def assert_close_range(got, ref, what):
@@ -117,6 +118,41 @@ def test_product_matches_oracle_on_fresh_batch():
     for k, p in model.named_parameters():
         ref = want["grads"][k]
         assert float((p.grad.cpu() - ref).norm()) <= GRAD_RTOL * float(ref.norm()) + 1e-6, k
+
+
+def test_gradients_with_the_max_pools_routed_alike():
+    """The same batch with the one discontinuity that dominates GRAD_RTOL taken out: the oracle's max-pools gather at the
+    arg-max the product used (ops.pool_log -> model_ref.PoolRouting), so a near-tie between two neighbours routes the gradient
+    alike in both runs.  What is left is fp32 rounding through 17 batch-statistics BatchNorms and ReLU masks at pre-activations
+    within rounding of zero: the bound drops from 3e-2 to GRAD_RTOL_ROUTED per parameter (measured: see the print)."""
+    from amcontrast3d_amd import ops, synthetic
+    from oracle import model_ref
+    dev = torch.device("cuda:0")
+    cfg = configs.model_cfg("S", dropout=0)
+    model, criterion = build(cfg, dev)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    nb = synthetic.make_batch(3, 3000, first_id=900)
+    cpu = {k: torch.from_numpy(v) for k, v in nb.items()}
+    gpu = {k: v.to(dev) for k, v in cpu.items()}
+    aa = configs.ambiguity_args("s3dis")
+    log = {}
+    ops.pool_log(log)
+    try:
+        logits, stage = model(gpu)
+        loss = criterion(logits, gpu["y"], stage, 13, None, easy(aa))
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.pool_log(None)
+    want = model_ref.train_step(sd, cfg, cpu, cpu["y"], 13, None, aa, pool=model_ref.PoolRouting({i: a.cpu() for i, a in log.items()}))
+    gmax = max(float(g.norm()) for g in want["grads"].values())
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        ref = want["grads"][k]
+        rel = float((p.grad.cpu() - ref).norm()) / max(float(ref.norm()), 1e-3 * gmax)
+        worst = max(worst, (k, rel), key=lambda kv: kv[1])
+    print(f"routed gradients: worst relative distance {worst[1]:.2e} ({worst[0]})")
+    assert worst[1] <= GRAD_RTOL_ROUTED, worst
 
 
 def test_stage_list_structure():
