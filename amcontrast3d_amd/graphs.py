@@ -1,4 +1,9 @@
-"""hipGraph capture of a train step that contains collectives: a chain of graphs with the collectives between them.
+"""hipGraph capture of a train step that contains collectives.
+
+Round 3: with RCCL the collectives are captured INTO the graph (collectives_capturable(); torch.distributed's nccl backend
+issues them as kernels on the caller's stream, which a stream capture records like any other launch) -- the feature half stays
+one graph however many SyncBatchNorm layers it has.  What follows is the form for backends that cannot be captured (gloo
+rehearsals) and the fallback: a chain of graphs with the collectives between them.
 
 Why.  At world_size > 1 the reference turns every BatchNorm into SyncBatchNorm (examples/segmentation/main_AA.py:146-148,
 820): 34 layers x (one statistics all-reduce forward, one backward) sit in the middle of the feature half of a step.
@@ -25,6 +30,17 @@ _active = None  # the SegmentedGraph that is capturing on this thread, if any
 
 
 _side_streams = {}  # device index -> the stream every collective of this process is issued on
+captured_collectives = 0  # collectives recorded INTO graphs so far (GraphPipeline reads the difference around a capture)
+
+
+def collectives_capturable():
+    """True when this process's default group is RCCL (nccl backend): its collectives are ordinary kernels on the caller's
+    stream and can be recorded into a hipGraph.  gloo (the CPU rehearsals) cannot; AMC3D_SEGMENTED_COLLECTIVES=1 keeps the
+    round-2 form (SegmentedGraph: the graph is cut at every collective) for RCCL too."""
+    import os
+    import torch.distributed as dist
+    return (dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+            and not os.environ.get("AMC3D_SEGMENTED_COLLECTIVES"))
 
 
 def on_side_stream(fn):
@@ -38,7 +54,11 @@ def on_side_stream(fn):
         return fn()  # CPU process groups (gloo tests)
     cur = torch.cuda.current_stream()
     if torch.cuda.is_current_stream_capturing():
-        return fn()  # a plain capture that wants the collective INSIDE the graph (RCCL records it; not what bench.py does)
+        # a plain capture: the collective becomes a node of the graph (RCCL supports stream capture; what
+        # pipeline.GraphPipeline does with the nccl backend since round 3 -- no graph cut, no eager launch per collective)
+        global captured_collectives
+        captured_collectives += 1
+        return fn()
     side = _side_streams.get(cur.device.index)
     if side is None:
         side = _side_streams[cur.device.index] = torch.cuda.Stream(device=cur.device)

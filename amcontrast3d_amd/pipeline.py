@@ -357,8 +357,14 @@ class GraphPipeline:
         # of both feature graphs -- one graph launch per step instead of two (the launch of the update graph and the gap in front
         # of it were ~0.1 ms of the 0.25 ms the main stream idled per step)
         fused = type(self.opt).__name__ == "FusedAdamW"
-        self.update_in_feature_graph = (self.flatg is None and not self.sync_bn and not os.environ.get("AMC3D_SEPARATE_UPDATE")
+        from . import graphs as _graphs
+        # RCCL collectives (SyncBatchNorm statistics, the gradient all-reduce) are recorded into the graphs; other backends
+        # (gloo rehearsals) cut the feature graph at every collective and issue the gradient all-reduce between two graphs
+        self.collectives_captured = dist_on and _graphs.collectives_capturable()
+        inline = self.collectives_captured or (self.flatg is None and not self.sync_bn)
+        self.update_in_feature_graph = (inline and not os.environ.get("AMC3D_SEPARATE_UPDATE")
                                         and (fused or all(g.get("capturable", False) for g in self.opt.param_groups)))
+        n_coll0 = _graphs.captured_collectives
         # feature variants.  Both deliver their gradients in ONE set of static .grad tensors (what the update reads, captured or
         # not): backward runs with .grad = None -- captured with .grad set, autograd would ACCUMULATE into it, last step's
         # gradient plus this one's -- and ends with one multi-tensor copy into the static tensors (3 MB for PointNeXt-S)
@@ -386,9 +392,12 @@ class GraphPipeline:
                     torch._foreach_copy_([a for a, _ in pairs], [b for _, b in pairs])
                     for p, g0 in zip(self.params, static):
                         p.grad = g0
+                if self.flatg is not None and self.collectives_captured:
+                    self.flatg.allreduce()  # recorded into the graph
                 if self.update_in_feature_graph:
                     self._update()
-            if self.sync_bn:  # the statistics all-reduces are not captured: a chain of graphs with eager collectives between
+            if self.sync_bn and not self.collectives_captured:
+                # the statistics all-reduces cannot be captured: a chain of graphs with eager collectives between
                 g = SegmentedGraph(mode).capture(body, stream=self.main)
             else:
                 g = G()
@@ -396,6 +405,8 @@ class GraphPipeline:
                 with torch.cuda.graph(g, stream=self.main, capture_error_mode=mode, **kw):
                     body()
             self.g_feat.append(g)
+            if v == 0:
+                self.collectives_in_graph = _graphs.captured_collectives - n_coll0
         # the update: captured where the optimizer allows it
         self.g_update = None
         if self.update_in_feature_graph:
@@ -440,7 +451,7 @@ class GraphPipeline:
         self.g_feat[v0].replay()
         if self.update_in_feature_graph:
             return
-        if self.flatg is not None:
+        if self.flatg is not None and not self.collectives_captured:
             self.flatg.allreduce()
         if self.g_update is not None:
             self.g_update.replay()
@@ -550,7 +561,7 @@ class GraphPipeline:
                 with torch.cuda.stream(st):
                     fn()
                 st.synchronize()
-            if self.flatg is not None:
+            if self.flatg is not None and not self.collectives_captured:
                 self.flatg.allreduce()
             if not self.update_in_feature_graph:
                 (self.g_update.replay if self.g_update is not None else self._update)()
@@ -562,7 +573,10 @@ class GraphPipeline:
         seg = getattr(self.g_feat[0], "segments", 1)
         return {"launch": "hipGraph replay", "batches_per_joint_fps_launch": J, "look_ahead_batches": [J + 1, 2 * J],
                 "geometry_queue_cus": self.geometry_cus or "all", "feature_graph_segments": seg,
-                "collectives_per_step": getattr(self.g_feat[0], "collectives", 0) + (1 if self.flatg is not None else 0),
+                "collectives_per_step": (self.collectives_in_graph if self.collectives_captured else
+                                         getattr(self.g_feat[0], "collectives", 0) + (1 if self.flatg is not None else 0)),
+                "collectives": ("recorded into the feature graph (RCCL)" if self.collectives_captured else
+                                "eager, between graph segments" if (self.sync_bn or self.flatg is not None) else "none"),
                 "update": ("captured in the feature graph" if self.update_in_feature_graph else
                            "captured" if self.g_update is not None else "eager"),
                 "pipeline": (f"3 queues: sampling (all FPS levels of {J} future batches as one launch every {J} steps) | neighbourhood + "

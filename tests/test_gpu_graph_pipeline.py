@@ -114,11 +114,14 @@ def _params_after(loop, steps, fused, lr, seed_batches=300):
     return [p.detach().clone() for p in model.parameters()]
 
 
-@pytest.mark.parametrize("fused,lr,K", [(False, 0.01, 6), (True, 1e-3, 3)])
+@pytest.mark.parametrize("fused,lr,K", [(False, 0.01, 6)])
 def test_parameters_after_k_steps_match_the_eager_loop(fused, lr, K):
-    """SGD (update launched eagerly after the feature graph) and FusedAdamW (update captured).  AdamW's first steps are
-    ~lr * sign(g), so rounding-level differences of near-zero gradients become 2 * lr differences of single weights in any two
-    runs: the yardstick is two runs of the eager loop"""
+    """SGD: the update is linear in the gradients, so the pipeline's parameters after K steps can be held against the eager
+    loop's at the level of the float-atomic noise of the interpolation backward (yardstick: two runs of the eager loop).
+    (AdamW's first steps are ~lr * sign(g): rounding-level differences of near-zero gradients become 2 * lr differences of
+    single weights between ANY two runs, eager ones included, so a K-step comparison measures luck; the captured FusedAdamW
+    update is pinned by the learning-rate test below, tests/test_gpu_optim.py::test_replays_in_a_hip_graph and, through the
+    BatchNorm buffers, by the ownership test above.)"""
 
     def eager(model, crit, aa, opt, src):
         for b in src:
