@@ -326,8 +326,22 @@ def main():
         feed = itertools.cycle(pool)
         step = lambda: eager_step(dict(next(feed)))  # noqa: E731
     else:
-        pipe = GraphPipeline(model, step_loss, criterion.contrast_head, opt, pool[0], 13, None, aargs, lanes=args.fps_lanes,
-                             max_grad_norm=10, flat_grads=flatg, sync_bn=sync_bn, keep_state=False, amp_dtype=amp, verbose=rank == 0)
+        def make_pipeline():
+            return GraphPipeline(model, step_loss, criterion.contrast_head, opt, pool[0], 13, None, aargs, lanes=args.fps_lanes,
+                                 max_grad_norm=10, flat_grads=flatg, sync_bn=sync_bn, keep_state=False, amp_dtype=amp,
+                                 verbose=rank == 0)
+        try:
+            pipe = make_pipeline()
+        except Exception as e:  # noqa: BLE001
+            # RCCL collectives recorded into the graphs (round 3) were rehearsed with a one-rank group only: should the capture be
+            # refused on a real node (it fails alike on every rank), fall back to round 2's form -- graphs cut at the collectives
+            if world == 1 and not sync_bn or os.environ.get("AMC3D_SEGMENTED_COLLECTIVES"):
+                raise
+            print(f"bench.py: capturing the collectives failed ({type(e).__name__}: {str(e)[:200]}); retrying with graph segments",
+                  file=sys.stderr)
+            os.environ["AMC3D_SEGMENTED_COLLECTIVES"] = "1"
+            torch.cuda.synchronize()
+            pipe = make_pipeline()
         runner = pipe.run(itertools.cycle(pool))
         step = lambda: next(runner)["loss"]  # noqa: E731
     for _ in range(args.warmup):
