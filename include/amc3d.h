@@ -581,6 +581,20 @@ int amc3d_adamw_chunk(void);
 int amc3d_adamw_step(const void *table, const int *block_map, int nblocks, double beta1, double beta2, float eps,
                      float max_grad_norm, double *partial, float *total_norm, void *stream);
 
+/* ---- training-time augmentation of a batch of cropped clouds (the loader's transform chain, cfgs/s3dis/default.yaml:33-43:
+ * ChromaticAutoContrast, PointCloudScaling, PointCloudXYZAlign, PointCloudRotation, PointCloudJitter, ChromaticDropGPU,
+ * ChromaticNormalize -- openpoints/transforms/point_transform_cpu.py:192-209, point_transformer_gpu.py:70-89,135-164,216-229,
+ * 267-311,373-409 -- which the reference applies per cloud in loader workers).  Two launches for the whole batch.  The random
+ * draws are the caller's: params (b,24) floats per cloud = {contrast 0/1, blend, scale[3], rot[9] row-major (pos' = pos @ rot^T),
+ * drop 0/1, 9 unused}, noise (b,n,3) standard-normal draws.  pos (b,n,3), color (b,n,3) (0..255, or 0..1: colours are divided by
+ * 255 when their maximum exceeds 1, as ChromaticNormalize does) -> pos_out (b,n,3), x_out (b,n,3) = (colour - mean) / std,
+ * heights (b,n) = the UNtransformed gravity coordinate (dataset/s3dis/s3dis.py:141-142). */
+size_t amc3d_augment_workspace_bytes(int b);
+int amc3d_augment_clouds(int b, int n, int gravity_dim, float jitter_sigma, float jitter_clip, const float *pos,
+                         const float *color, const float *noise, const float *params, const float *color_mean,
+                         const float *color_std, float *pos_out, float *x_out, float *heights, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

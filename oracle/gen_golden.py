@@ -374,6 +374,63 @@ def run_input_case(name="input_room", n_base=12000, copies=3, voxel=0.04, voxel_
     print(name, "raw points", len(coord), "voxels", len(count), "max per voxel", int(count.max()), "crop", len(crop_idx))
 
 
+def run_augment_case(name="augment_s3dis", n=3000):
+    """The training transform chain of cfgs/s3dis/default.yaml:33-43, run with the reference's OWN classes
+    (transforms/point_transform_cpu.py:8-19,192-209, transforms/point_transformer_gpu.py:70-89,135-164,216-229,267-311,373-409)
+    on one cropped cloud, exactly as S3DIS.__getitem__ calls it (dataset/s3dis/s3dis.py:136-143, including `heights`, which
+    reads the numpy array handed to the transforms -- untouched by them: PointsToTensor copies before torch.from_numpy).  Every random number the classes draw is logged by wrapping the generator functions they call; stored are
+    the inputs, the draws and the outputs.  Two cases: auto-contrast and colour drop taken / not taken."""
+    import collections
+    import collections.abc
+    if not hasattr(collections, "Iterable"):
+        collections.Iterable = collections.abc.Iterable  # removed from `collections` in Python 3.10; the reference's image had 3.7
+    from openpoints.transforms import point_transform_cpu as T_cpu, point_transformer_gpu as T_gpu
+    room = synthetic.make_batch(1, n, first_id=811)
+    coord0 = (room["pos"][0] - room["pos"][0].min(0)).astype(np.float32)
+    feat0 = (room["x"][0, :3].T * 255.0).astype(np.float32)
+    out = {"coord": coord0, "feat": feat0}
+    kw = dict(color_drop=0.2, gravity_dim=2, scale=[0.9, 1.1], angle=[0, 0, 1], jitter_sigma=0.005, jitter_clip=0.02)
+    for tag, p_contrast, p_drop, seed in (("a", 1.0, 1.0, 5), ("b", 0.0, 0.0, 6)):
+        log = []
+        orig = (torch.rand, torch.randn_like, np.random.rand, np.random.uniform)
+        torch.rand = lambda *a, **k: (lambda t: (log.append(("torch.rand", t.clone().numpy())), t)[1])(orig[0](*a, **k))
+        torch.randn_like = lambda *a, **k: (lambda t: (log.append(("torch.randn_like", t.clone().numpy())), t)[1])(orig[1](*a, **k))
+        np.random.rand = lambda *a: (lambda v: (log.append(("np.rand", np.array(v))), v)[1])(orig[2](*a))
+        np.random.uniform = lambda *a, **k: (lambda v: (log.append(("np.uniform", np.array(v))), v)[1])(orig[3](*a, **k))
+        try:
+            np.random.seed(seed)
+            torch.manual_seed(seed)
+            chain = [T_cpu.ChromaticAutoContrast(p=p_contrast), T_cpu.PointsToTensor(), T_gpu.PointCloudScaling(**kw),
+                     T_gpu.PointCloudXYZAlign(**kw), T_gpu.PointCloudRotation(**kw), T_gpu.PointCloudJitter(**kw),
+                     T_gpu.ChromaticDropGPU(color_drop=p_drop), T_gpu.ChromaticNormalize()]
+            coord, feat = coord0.copy(), feat0.copy()
+            data = {"pos": coord, "x": feat}
+            for t in chain:
+                data = t(data)
+            heights = torch.from_numpy(coord[:, 2:3].astype(np.float32))  # s3dis.py:141-142
+        finally:
+            torch.rand, torch.randn_like, np.random.rand, np.random.uniform = orig
+        kinds = [k for k, _ in log]
+        # the order the classes draw in: [contrast u, (blend)], scale (3), theta x / y / z, noise (n,3), drop u
+        i = 0
+        out[f"{tag}/contrast_u"] = log[i][1]; i += 1
+        if p_contrast >= 1.0:
+            out[f"{tag}/blend"] = log[i][1]; i += 1
+        assert kinds[i] == "torch.rand" and log[i][1].shape == (3,)
+        out[f"{tag}/scale_u"] = log[i][1]; i += 1
+        assert kinds[i:i + 3] == ["np.uniform"] * 3
+        out[f"{tag}/theta"] = np.array([log[i][1], log[i + 1][1], log[i + 2][1]], dtype=np.float64); i += 3
+        assert kinds[i] == "torch.randn_like"
+        out[f"{tag}/noise"] = log[i][1]; i += 1
+        out[f"{tag}/drop_u"] = log[i][1]; i += 1
+        assert i == len(log), kinds
+        out[f"{tag}/p_contrast"], out[f"{tag}/p_drop"] = np.float64(p_contrast), np.float64(p_drop)
+        out[f"{tag}/pos"], out[f"{tag}/x"], out[f"{tag}/heights"] = data["pos"].numpy(), data["x"].numpy(), heights.numpy()
+        print(name, tag, "draws", kinds, "pos range", float(data["pos"].min()), float(data["pos"].max()))
+    out["meta"] = json.dumps(kw)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
 def run_mm_cases():
     # AMContrast3D++ with a narrow S-shaped backbone and stored weights: APM towers, masked refinement (DualMasks,
     # threshold lowered so that a good share of the points is refined at seed-0 init), three-term loss
@@ -393,6 +450,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "input":
         run_input_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "augment":
+        run_augment_case()
+        sys.exit(0)
     run_state_keys()
     run_ops_case()
     G = ["encoder.encoder.0.0.convs.0.0.weight", "encoder.encoder.1.0.convs.0.0.weight",
@@ -410,3 +470,4 @@ if __name__ == "__main__":
     run_mm_cases()
     run_eval_case()
     run_input_case()
+    run_augment_case()
