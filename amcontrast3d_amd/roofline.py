@@ -70,6 +70,28 @@ def load_profiles(variant="S"):
     return traffic, rows, name
 
 
+def family_traffic(op, kernels, steps):
+    """PMC bytes per step of every kernel `op` launches (profiles/round3_hbm_pmc.csv) against the algorithmic bytes per step of
+    every operator that shares one of those kernels (a pointwise conv's forward and backward run the same GEMM kernels, so
+    counters cannot be split between them): -> {'operators', 'traffic_GB_per_step', 'algorithmic_GB_per_step', 'ratio'} or None"""
+    pats = OPERATOR_KERNELS.get(op)
+    try:
+        with open(os.path.join(_profiles_dir(), "round3_hbm_pmc.csv")) as fh:
+            pmc = list(csv.DictReader(fh))
+    except OSError:
+        return None
+    if not pats or not pmc:
+        return None
+    family = sorted(o for o, ps in OPERATOR_KERNELS.items() if set(ps) & set(pats) and o in kernels)
+    allp = sorted({p for o in family for p in OPERATOR_KERNELS[o]})
+    mb = sum(float(r["HBM_MB_per_step_corrected"]) for r in pmc if any(p in r["kernel"] for p in allp))
+    alg = sum(kernels[o]["bytes"] for o in family) / steps
+    if not mb or not alg:
+        return None
+    return {"operators": family, "traffic_GB_per_step": round(mb / 1e3, 3), "algorithmic_GB_per_step": round(alg / 1e9, 3),
+            "ratio": round(mb * 1e6 / alg, 2), "file": "profiles/round3_hbm_pmc.csv"}
+
+
 def rocprof_of(op, rows, csv_name):
     """the committed rocprofv3 rows of the kernels operator `op` launches: us per step and per-kernel averages"""
     pats = OPERATOR_KERNELS.get(op)
@@ -115,6 +137,8 @@ def report(kernels, steps, ms_per_step, points_per_step, variant, mm, overlapped
     if crit:
         name, v = max(crit.items(), key=lambda kv: kv[1]["total_ms"])
         out["roofline"] = operator_roofline(name, v, steps, traffic, rows, csv_name)
+        if out["roofline"]["traffic"] is None:  # its kernels are shared with other operators: the family's counters instead
+            out["roofline"]["traffic_family"] = family_traffic(name, kernels, steps)
         out["roofline"]["note"] = ("largest live HIP-event time among the operators of the feature half (the stream that bounds the "
                                    "overlapped step); achieved = SURVEY 8(d) algorithmic bytes or FLOPs / that time")
     hbm = {k: v for k, v in crit.items() if v["flops"] == 0 or v["flops"] / max(v["bytes"], 1) < 19.7}
