@@ -39,8 +39,9 @@ for op, pats in OPERATOR_KERNELS.items():
     for pat in pats:
         owners.setdefault(pat, []).append(op)
 ops = {}
+exclusive = {op for op, pats in OPERATOR_KERNELS.items() if all(len(owners[p]) == 1 for p in pats)}  # no kernel shared with another operator
 for b, k, d in table:
-    mine = {op for pat, os_ in owners.items() if pat in k and len(os_) == 1 for op in os_}
+    mine = {op for pat, os_ in owners.items() if pat in k and len(os_) == 1 for op in os_ if op in exclusive}
     if len(mine) == 1:
         op = mine.pop()
         e = ops.setdefault(op, {"bytes_per_step": 0.0, "dispatches_per_step": 0.0})
