@@ -150,3 +150,18 @@ for name, flags in (("disable-timing (torch's)", 0x2), ("+ release to device", 0
         print("raw HIP events, %-26s %.3f ms" % (name, timeit(raw_pair(flags))))
     except AssertionError:
         print("raw HIP events, %-26s refused" % name)
+
+
+# the host polls the other queue's event before it launches the next graph: the training stream then never carries a wait on
+# an event that is incomplete at enqueue time (ROCclr drops waits on complete events)
+def host_polled():
+    while not ev_b.query():
+        pass
+    ev_a.record(main)
+    g.replay()
+    with torch.cuda.stream(pipe.s_geo):
+        pipe.s_geo.wait_event(ev_a)
+        ev_b.record(pipe.s_geo)
+
+
+print("host polls ev_b, no stream wait         %.3f ms" % timeit(host_polled))
