@@ -164,10 +164,13 @@ class GraphPipeline:
                          is latency-bound, more clouds per launch cost nothing); two J-batch buffers used in turn
         geometry queue   hand-down copies, then the neighbourhood + loss geometry (ball queries, relative positions,
                          reverse edge lists, 3-NN, the loss's k-NN / votes / masks / ambiguities / anchor lists) of the
-                         batch that trains NEXT tick; CU-masked; two captured variants filling two result sets in turn
+                         batch that trains NEXT tick; CU-masked; three captured variants filling three result sets in turn
         main stream      features of the current batch: forward + loss + backward (+ gradient all-reduce) + clip + optimizer
-                         step; two captured variants, variant v reading the very input set and result set the geometry
-                         variant v worked on one tick earlier -- nothing is copied on the main stream between two steps
+                         step; three captured variants, variant v reading the very input set and result set the geometry
+                         variant v worked on one tick earlier -- nothing is copied on the main stream between two steps, and
+                         it records no event that another queue waits for (a set is refilled two ticks after it was read,
+                         which the host checks; with two sets the geometry queue had to wait for the training stream's event,
+                         0.21 ms per step on the training stream: tools/bubble_probe.py)
 
     Every batch goes through exactly the computation of the eager loop, once; the pipeline decides WHEN its coordinate-only
     half runs (1 .. 2J ticks ahead).  Batches come out in the order they went in.
@@ -212,12 +215,18 @@ class GraphPipeline:
         self.s_fps, self.s_geo = _dedicated_queues(self.dev, geometry_cus)
         self.geometry_cus = geometry_cus
         self.ev_lane = [torch.cuda.Event(), torch.cuda.Event()]
-        self.ev_geo, self.ev_main, self.ev_rot = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        self.ev_geo, self.ev_rot = torch.cuda.Event(), torch.cuda.Event()
+        # "tick t's feature graph has finished": recorded on the training stream, only ever queried by the HOST.  The geometry
+        # queue refills a set two ticks after it was read (three sets in turn), so that this check can be the host's: an event
+        # of the training stream that ANOTHER QUEUE waits for costs the training stream 0.21 ms per step (tools/bubble_probe.py)
+        from . import schedule
+        self.ev_done = [torch.cuda.Event() for _ in range(schedule.SETS)]
+        self._done_recorded = [False] * schedule.SETS
         self._build(example)
         if snapshot is not None:
             self._restore(snapshot)
         self.tick = 0
-        self._set_valid = [False, False]
+        self._set_valid = [False] * schedule.SETS
         self._lane_valid = [[False] * J, [False] * J]
         self._lr = tuple(g["lr"] for g in optimizer.param_groups)
 
@@ -315,10 +324,12 @@ class GraphPipeline:
         self.fps_J = [self._fps_all(self.in_J[j]) for j in range(2)]
         self.in_lane = [[{k: lane(v, l) for k, v in self.in_J[j].items()} for l in range(J)] for j in range(2)]
         self.fps_lane = [[geometry._walk(self.fps_J[j], lambda t, l=l: lane(t, l)) for l in range(J)] for j in range(2)]
-        # two input sets (batch + its FPS picks) shared by geometry variant v and, one tick later, feature variant v
-        self.set_in = [{k: v.clone() for k, v in ex.items()} for _ in range(2)]
-        self.set_fps = [geometry.clone(self.fps_lane[0][0]) for _ in range(2)]
-        self.out = [{}, {}]
+        # three input sets (batch + its FPS picks) shared by geometry variant v and, one tick later, feature variant v
+        from . import schedule
+        S = schedule.SETS
+        self.set_in = [{k: v.clone() for k, v in ex.items()} for _ in range(S)]
+        self.set_fps = [geometry.clone(self.fps_lane[0][0]) for _ in range(S)]
+        self.out = [{} for _ in range(S)]
         data0 = dict(self.set_in[0])
 
         def eager_step():  # everything once, in line: allocator warm-up, lazy initialisations, optimizer state
@@ -342,13 +353,14 @@ class GraphPipeline:
         self.mode = mode
         G = torch.cuda.CUDAGraph
         # geometry variants: their own output tensors are the two result sets
-        self.g_geo, self.rest = [G(), G()], []
-        for v in range(2):
+        self.g_geo, self.rest = [G() for _ in range(S)], []
+        for v in range(S):
             with torch.cuda.graph(self.g_geo[v], stream=self.s_geo, capture_error_mode=mode):
                 self.rest.append(geometry.split(self._rest(self.set_in[v], self.set_fps[v]))[1])
         for v, r in enumerate(self.rest):  # a result set may only alias the inputs of its own variant
             other = set()
-            geometry._walk([self.set_fps[1 - v], self.set_in[1 - v], self.in_J, self.fps_J], lambda t: other.add(t.untyped_storage().data_ptr()))
+            geometry._walk([[self.set_fps[u], self.set_in[u]] for u in range(S) if u != v] + [self.in_J, self.fps_J],
+                           lambda t: other.add(t.untyped_storage().data_ptr()))
 
             def check(t):
                 assert t.untyped_storage().data_ptr() not in other, "the geometry plan aliases another batch's buffers"
@@ -376,7 +388,7 @@ class GraphPipeline:
             if fused:
                 self.opt.prepare()  # the tensor table of the update, built outside the capture
         self.g_feat = []
-        for v in range(2):
+        for v in range(S):
             data = dict(self.set_in[v])
             data["_geometry"] = geometry.join(self.set_fps[v], self.rest[v])
 
@@ -419,7 +431,6 @@ class GraphPipeline:
                 self._update()
         # hand-down on the geometry queue, one graph per tick of the period 2J: lane (buffer jc, lane l) -> input set v1
         self.g_side = []
-        from . import schedule
         for t in range(schedule.period(J)):
             plan = schedule.tick_plan(t, J)
             (jc, l), v1 = plan["consume"], plan["fill"]
@@ -465,19 +476,23 @@ class GraphPipeline:
         import os
         # diagnostic: leave parts out once every buffer holds results (they go stale; timing only, with one resident batch)
         skip = os.environ.get("AMC3D_PIPE_SKIP", "") if self.tick > 6 * self.lanes else ""
-        J, t = self.lanes, self.tick % (2 * self.lanes)
+        J, t = self.lanes, self.tick % schedule.period(self.lanes)
         self.tick += 1
         plan = schedule.tick_plan(t, J)
         v0, v1, (jc, l), jl = plan["train"], plan["fill"], plan["consume"], plan["launch"]
         out = None
         # the main stream goes first: the side launches below take the host 0.3-0.5 ms
         self.main.wait_event(self.ev_geo)   # result set v0 is complete
-        self.ev_main.record(self.main)      # ... and everything earlier on the main stream has read set v1
         if self._set_valid[v0]:
             self._critical_path(v0)
             out = dict(self.out[v0], target=self.set_in[v0]["y"], data=self.set_in[v0])
+            self.ev_done[v0].record(self.main)
+            self._done_recorded[v0] = True
+        # set v1 is refilled now; the feature graph that read it last ran two ticks ago: the host makes sure it has finished
+        # (it has, unless the host is more than two steps ahead of the GPU) -- no device-side wait for the training stream
+        if self._done_recorded[v1]:
+            self.ev_done[v1].synchronize()
         with torch.cuda.stream(self.s_geo):
-            self.s_geo.wait_event(self.ev_main)
             self.s_geo.wait_event(self.ev_lane[jc])
             if "side" not in skip:
                 self.g_side[t].replay()
@@ -515,8 +530,9 @@ class GraphPipeline:
         iterable makes an endless generator (bench.py)."""
         it = iter(batches)
         # start at a launch tick with empty buffers
+        from . import schedule
         self.tick = 0
-        self._set_valid = [False, False]
+        self._set_valid = [False] * schedule.SETS
         self._lane_valid = [[False] * self.lanes, [False] * self.lanes]
         busy = True
         while busy:
@@ -555,9 +571,9 @@ class GraphPipeline:
             if r == 0:
                 torch.cuda.synchronize()
                 t = time.perf_counter()
-            for fn, st in ((self.g_side[r % (2 * J)].replay, self.s_geo),
+            for fn, st in ((self.g_side[r % len(self.g_side)].replay, self.s_geo),
                            (self.g_fps[(r // J) % 2].replay if r % J == 0 else (lambda: None), self.s_fps),
-                           (self.g_geo[r % 2].replay, self.s_geo), (self.g_feat[r % 2].replay, self.main)):
+                           (self.g_geo[r % len(self.g_geo)].replay, self.s_geo), (self.g_feat[r % len(self.g_feat)].replay, self.main)):
                 with torch.cuda.stream(st):
                     fn()
                 st.synchronize()
@@ -581,4 +597,4 @@ class GraphPipeline:
                            "captured" if self.g_update is not None else "eager"),
                 "pipeline": (f"3 queues: sampling (all FPS levels of {J} future batches as one launch every {J} steps) | neighbourhood + "
                              "loss geometry of the next batch (CU-masked) | features of this batch; geometry handed over without "
-                             "copies (two captured variants each)")}
+                             "copies (three captured variants each; the training stream carries no event another queue waits for)")}

@@ -364,9 +364,10 @@ def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, nbatc
     joint_fps = [[None] * J, [None] * J]    # ("fps", id) once launched
     launched_at = [None, None]
     lane_valid = [[False] * J, [False] * J]
-    sets = [None, None]
-    set_valid = [False, False]
-    read_pending = [False, False]           # set filled but not yet trained on
+    sets = [None] * schedule.SETS
+    set_valid = [False] * schedule.SETS
+    read_pending = [False] * schedule.SETS  # set filled but not yet trained on
+    last_read = [-10] * schedule.SETS       # tick at which a set was last trained on
     trained = []
     t, busy = 0, True
     while busy:
@@ -378,8 +379,10 @@ def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, nbatc
             assert st["fps"] == ("fps", st["batch"]) and st["geo"] == ("geo", st["batch"], st["fps"])
             trained.append(st["batch"])
             read_pending[v0] = False
+            last_read[v0] = t
         jc, l = plan["consume"]
         assert not read_pending[v1], "a result set is refilled before its feature variant ran"
+        assert t - last_read[v1] >= 2, "a set is refilled less than two ticks after it was read (the host only checks tick t - 2)"
         if lane_valid[jc][l]:
             assert t - launched_at[jc] >= J, "a lane is consumed before its joint FPS launch can have finished"
             assert joint_fps[jc][l] == ("fps", joint_in[jc][l]), "a lane was overwritten between launch and consumption"
@@ -406,7 +409,8 @@ def test_pipeline_hand_down_keeps_every_batch_with_its_own_geometry(lanes, nbatc
         t += 1
         assert t < 4 * (nbatches + 4 * J), "the pipeline does not drain"
     assert trained == list(range(nbatches))
-    assert schedule.period(J) == 2 * J and all(schedule.tick_plan(k, J) == schedule.tick_plan(k + 2 * J, J) for k in range(2 * J))
+    P = schedule.period(J)
+    assert P % (2 * J) == 0 and P % schedule.SETS == 0 and all(schedule.tick_plan(k, J) == schedule.tick_plan(k + P, J) for k in range(P))
 
 
 

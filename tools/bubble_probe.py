@@ -165,3 +165,33 @@ def host_polled():
 
 
 print("host polls ev_b, no stream wait         %.3f ms" % timeit(host_polled))
+
+
+# one direction only: the training stream waits for the other queue's event, the other queue waits for nothing of the training
+# stream (what a third result set + a host-side check of an old training-stream event would leave)
+def one_way():
+    main.wait_event(ev_b)
+    g.replay()
+    with torch.cuda.stream(pipe.s_geo):
+        pipe.g_side[0].replay()
+        ev_b.record(pipe.s_geo)
+
+
+print("one way: main waits, the other queue never waits for main %.3f ms" % timeit(one_way))
+ev_old = [torch.cuda.Event() for _ in range(3)]
+cnt = [0]
+
+
+def one_way_host_check():
+    i = cnt[0]
+    cnt[0] += 1
+    ev_old[(i + 1) % 3].synchronize()  # the replay of two iterations ago has finished (host-side: no device dependency)
+    main.wait_event(ev_b)
+    g.replay()
+    ev_old[i % 3].record(main)
+    with torch.cuda.stream(pipe.s_geo):
+        pipe.g_side[0].replay()
+        ev_b.record(pipe.s_geo)
+
+
+print("  + host-side check of the replay two iterations back      %.3f ms" % timeit(one_way_host_check))
