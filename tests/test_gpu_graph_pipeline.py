@@ -114,7 +114,7 @@ def _params_after(loop, steps, fused, lr, seed_batches=300):
     return [p.detach().clone() for p in model.parameters()]
 
 
-@pytest.mark.parametrize("fused,lr,K", [(False, 0.01, 6)])
+@pytest.mark.parametrize("fused,lr,K", [(False, 1e-3, 3)])  # three steps: each of the three captured variants delivers one gradient
 def test_parameters_after_k_steps_match_the_eager_loop(fused, lr, K):
     """SGD: the update is linear in the gradients, so the pipeline's parameters after K steps can be held against the eager
     loop's at the level of the float-atomic noise of the interpolation backward (yardstick: two runs of the eager loop).
@@ -140,7 +140,9 @@ def test_parameters_after_k_steps_match_the_eager_loop(fused, lr, K):
     noise = max(float((x - y).abs().max()) / max(float(x.abs().max()), 1e-2) for x, y in zip(a, a2))
     worst = max(float((x - y).abs().max()) / max(float(x.abs().max()), 1e-2) for x, y in zip(a, b))
     print(f"parameters after {K} {'AdamW' if fused else 'SGD'} steps: pipeline vs eager {worst:.2e} (relative to each tensor's range); eager vs eager {noise:.2e}")
-    assert worst <= max(4 * noise, 1e-5), (worst, noise)
+    # (a gradient that did not reach the update -- a variant's copy into the static tensors missing -- shows as ~1e-2 here;
+    # at lr = 0.01 over 6 steps two EAGER runs already differ by 7 %: training amplifies the atomics' rounding noise)
+    assert worst <= max(4 * noise, 1e-3), (worst, noise)
 
 
 def test_a_schedulers_learning_rate_reaches_the_captured_update():
