@@ -131,6 +131,30 @@ __global__ __launch_bounds__(256) void row_norm_kernel(int m, int C, const float
     if (lane == 0) norm[i] = fmaxf(sqrtf(s), 1e-8f);
 }
 
+// the same norm and the UNIT rows h_i = f_i / max(||f_i||, eps) (C == 4 * LPR, LPR lanes per row, 16-byte pieces).  The
+// contrast kernels below gather h instead of f: the four IEEE divisions per lane and fetched row -- 40 of the ~85 VALU
+// instructions a round of rows cost; the kernels were VALU-bound, not gather-bound: with every gather redirected to the
+// anchor's own row they took the same time -- are done once per row here, and no neighbour norm is fetched.
+template <int LPR>
+__global__ __launch_bounds__(256) void row_unit_kernel(int m, const float *__restrict__ f, float *__restrict__ norm,
+                                                       float *__restrict__ unit)
+{
+    const int q = threadIdx.x & (LPR - 1);
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
+    if (i >= m) return;  // (whole LPR-lane groups leave together: the shuffles below stay inside a group)
+    float4 v = reinterpret_cast<const float4 *>(f)[i * LPR + q];
+    float s = v.x * v.x;
+    s += v.y * v.y;
+    s += v.z * v.z;
+    s += v.w * v.w;
+#pragma unroll
+    for (int d = LPR / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    const float n = fmaxf(sqrtf(s), 1e-8f);
+    v.x = __fdiv_rn(v.x, n); v.y = __fdiv_rn(v.y, n); v.z = __fdiv_rn(v.z, n); v.w = __fdiv_rn(v.w, n);
+    reinterpret_cast<float4 *>(unit)[i * LPR + q] = v;
+    if (q == 0) norm[i] = n;
+}
+
 // ---------------------------------------------------------------------------------------------
 // The anchors that enter the loss, 0 < a <= 1 (MarginContrast.py:250-252), as a compact ascending list:
 // sel[0] = count, sel[1..count] = anchor ids, sel[m+1..] = per-256-block counts (scratch).  The list depends on
@@ -170,72 +194,70 @@ __global__ __launch_bounds__(256) void select_write_kernel(int m, const float *_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Contrast forward, one wave per anchor (C == 4 * LPR): LPR lanes read one embedding row as 16-byte pieces, so
-// every wave instruction fetches 64/LPR whole rows (full 64-byte sectors, where a lane-per-neighbour stream
-// takes 16 bytes of each sector per instruction), with four such rounds in flight before the first is used.
-// Same per-element arithmetic as contrast_forward_kernel below; the channel sum is a tree over the LPR lanes.
+// Contrast forward, one wave per anchor (C == 4 * LPR) over the UNIT rows: LPR lanes read one row as 16-byte pieces, so
+// every wave instruction fetches R = 64/LPR whole rows (full 64-byte sectors), U = 4 such rounds in flight.  The cosine
+// of a slot is four products and a tree over the row's LPR lanes (every lane of the row then holds it); the exponential of
+// slot (round t, row r) is evaluated ONCE, by lane q = t of row r, not by all LPR lanes of the row in every round.
+// Same per-element arithmetic as contrast_forward_kernel below (u_c / n_i * (v_c / n_x), channel order of the tree).
 // sel == nullptr: every anchor is visited and tested.
 // ---------------------------------------------------------------------------------------------
 template <int LPR>
-__global__ __launch_bounds__(256) void contrast_forward_rows_kernel(
-    int m, int k, int nbr_stride, const float *__restrict__ f, const float *__restrict__ norm,
-    const int *__restrict__ nbr, const unsigned char *__restrict__ posmask, const float *__restrict__ a,
-    const int *__restrict__ sel, float mu, float nu, float temperature, float *__restrict__ sim,
-    float *__restrict__ loss_pt)
+__global__ __launch_bounds__(256) void contrast_forward_unit_kernel(
+    int m, int k, int nbr_stride, const float *__restrict__ unit, const int *__restrict__ nbr,
+    const unsigned char *__restrict__ posmask, const float *__restrict__ a, const int *__restrict__ sel, float mu, float nu,
+    float temperature, float *__restrict__ sim, float *__restrict__ loss_pt)
 {
     constexpr int R = 64 / LPR;  // rows per round
-    constexpr int U = 4;         // rounds in flight
+    constexpr int U = 4;         // rounds in flight (LPR >= U: lane q < U of a row owns the row's slot of round q)
     const int lane = threadIdx.x & 63, q = lane & (LPR - 1), r = lane / LPR;
+    const int cnt = sel ? sel[0] : m;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= (sel ? sel[0] : m)) return;
+    if (w >= cnt) return;
     const int i = sel ? sel[1 + w] : w;
     const float ai = a[i];
     if (!(0.f < ai && ai <= 1.f)) {
         if (lane == 0) loss_pt[i] = 0.f;
         return;
     }
-    const float ni = norm[i];
     const float margin = __fadd_rn(__fmul_rn(mu, ai), nu);
-    const float4 *f4 = reinterpret_cast<const float4 *>(f);
-    float4 u = f4[(size_t)i * LPR + q];
-    u.x = __fdiv_rn(u.x, ni); u.y = __fdiv_rn(u.y, ni); u.z = __fdiv_rn(u.z, ni); u.w = __fdiv_rn(u.w, ni);
+    const float4 *h4 = reinterpret_cast<const float4 *>(unit);
+    const float4 u = h4[(size_t)i * LPR + q];
     float psum = 0.f, tsum = 0.f;
     for (int j0 = 0; j0 < k; j0 += U * R) {
         int nb[U];
-        bool pos[U];
-        float nj[U];
         float4 v[U];
 #pragma unroll
         for (int t = 0; t < U; ++t) {
             const int j = j0 + t * R + r;
             nb[t] = j < k ? nbr[(size_t)i * nbr_stride + j] : -1;
-            pos[t] = j < k ? posmask[(size_t)i * k + j] != 0 : false;
         }
+        const int jq = j0 + q * R + r;  // the slot this lane evaluates
+        const bool mine = q < U && jq < k;
+        const bool pos = mine ? posmask[(size_t)i * k + jq] != 0 : false;
+#pragma unroll
+        for (int t = 0; t < U; ++t) v[t] = nb[t] >= 0 ? h4[(size_t)nb[t] * LPR + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float s = 0.f;
 #pragma unroll
         for (int t = 0; t < U; ++t) {
-            nj[t] = nb[t] >= 0 ? norm[nb[t]] : 1.f;
-            v[t] = nb[t] >= 0 ? f4[(size_t)nb[t] * LPR + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float acc = u.x * v[t].x;
+            acc += u.y * v[t].y;
+            acc += u.z * v[t].z;
+            acc += u.w * v[t].w;
+#pragma unroll
+            for (int d = LPR / 2; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+            s = q == t ? acc : s;
         }
-#pragma unroll
-        for (int t = 0; t < U; ++t) {
-            float acc = u.x * __fdiv_rn(v[t].x, nj[t]);
-            acc += u.y * __fdiv_rn(v[t].y, nj[t]);
-            acc += u.z * __fdiv_rn(v[t].z, nj[t]);
-            acc += u.w * __fdiv_rn(v[t].w, nj[t]);
-#pragma unroll
-            for (int s = LPR / 2; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
-            if (nb[t] >= 0) {
-                if (q == 0) sim[(size_t)i * k + j0 + t * R + r] = acc;
-                const float e = expf(__fdiv_rn(pos[t] ? __fsub_rn(acc, margin) : acc, temperature));
-                psum += pos[t] ? e : 0.f;
-                tsum += e;
-            }
+        if (mine) {
+            sim[(size_t)i * k + jq] = s;
+            const float e = expf(__fdiv_rn(pos ? __fsub_rn(s, margin) : s, temperature));
+            psum += pos ? e : 0.f;
+            tsum += e;
         }
     }
 #pragma unroll
-    for (int s = LPR; s < 64; s <<= 1) {  // every lane of a row slot holds the slot's sums: fold the slots
-        psum += __shfl_xor(psum, s, 64);
-        tsum += __shfl_xor(tsum, s, 64);
+    for (int d = 1; d < 64; d <<= 1) {
+        psum += __shfl_xor(psum, d, 64);
+        tsum += __shfl_xor(tsum, d, 64);
     }
     if (lane == 0) loss_pt[i] = -logf(__fadd_rn(__fdiv_rn(psum, tsum), 1e-12f));
 }
@@ -633,83 +655,90 @@ __global__ __launch_bounds__(256) void contrast_record_kernel(
     }
 }
 
+// (unit rows, see row_unit_kernel: hx = f_x / n_x is fetched, not recomputed; lane q < U of a row decodes and evaluates the
+// row's slot of round q -- index, mask, mutual count, the record of x, the two exponentials -- once, and hands x down to /
+// the finished coefficient back to the row's lanes by shuffles)
 template <int LPR>
 __global__ __launch_bounds__(256) void contrast_backward_mutual_kernel(
-    int m, int k, int nbr_stride, const float *__restrict__ f, const int *__restrict__ nbr,
+    int m, int k, int nbr_stride, const float *__restrict__ unit, const int *__restrict__ nbr,
     const unsigned char *__restrict__ posmask, const unsigned char *__restrict__ mutual, const int *__restrict__ rev,
     const ContrastRecord *__restrict__ rec, float temperature, float *__restrict__ grad_f)
 {
     constexpr int R = 64 / LPR;  // rows per round
     constexpr int U = 4;         // rounds in flight
-    const int lane = threadIdx.x & 63, q = lane & (LPR - 1), r = lane / LPR;
+    const int lane = threadIdx.x & 63, q = lane & (LPR - 1), r = lane / LPR, row0 = lane & ~(LPR - 1);
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= m) return;
-    const float4 *f4 = reinterpret_cast<const float4 *>(f);
+    const float4 *h4 = reinterpret_cast<const float4 *>(unit);
     const float4 *rec4 = reinterpret_cast<const float4 *>(rec);
     const float4 rn0 = rec4[(size_t)n * 2];       // norm, coef, tsum, psum
     const float margin_n = rec[n].margin;
     const float nn = rn0.x, coef_n = rn0.y, tsum_n = rn0.z, psum_n = rn0.w;
-    float4 fn = f4[(size_t)n * LPR + q];
-    fn.x = __fdiv_rn(fn.x, nn); fn.y = __fdiv_rn(fn.y, nn); fn.z = __fdiv_rn(fn.z, nn); fn.w = __fdiv_rn(fn.w, nn);
+    const float4 fn = h4[(size_t)n * LPR + q];
     const int e0 = rev[n], deg = rev[n + 1] - e0;
     const int *rev_edge = rev + m + 1;
     const int total = k + deg;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int t0 = 0; t0 < total; t0 += U * R) {
+        // the slot this lane decodes and evaluates: round q, row r
+        const int tq = t0 + q * R + r;
+        int myx = -1;
+        bool pos = false, own = false;
+        float inc = 0.f;  // incoming edges x -> n met at this slot (their number: 0 or 1 in a k-NN graph)
+        if (q < U) {
+            if (tq < k) {  // own list: the edge n -> x, and x -> n when it is mutual
+                myx = nbr[(size_t)n * nbr_stride + tq];
+                pos = posmask[(size_t)n * k + tq] != 0;
+                inc = (float)(mutual[(size_t)n * k + tq] & 0x7f);
+                own = coef_n != 0.f;
+                if (!own && inc == 0.f) myx = -1;  // nothing flows along this edge
+            } else if (tq < total) {  // a non-mutual incoming edge x -> n
+                const int p = rev_edge[e0 + tq - k];
+                myx = p / k;
+                pos = posmask[p] != 0;
+                inc = 1.f;
+            }
+        }
         int x[U];
-        bool pos[U], own[U];
-        float inc[U];  // incoming edges x -> n met at this slot (their number: 0 or 1 in a k-NN graph)
-        float4 rx[U], v[U];
-        float mx[U];
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = __shfl(myx, row0 | u, 64);
+        const float4 rx = myx >= 0 ? rec4[(size_t)myx * 2] : make_float4(1.f, 0.f, 1.f, 0.f);
+        const float mx = myx >= 0 ? rec[myx].margin : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = x[u] >= 0 ? h4[(size_t)x[u] * LPR + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float s[U], smine = 0.f;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int t = t0 + u * R + r;
-            x[u] = -1; pos[u] = false; own[u] = false; inc[u] = 0.f;
-            if (t < k) {  // own list: the edge n -> x, and x -> n when it is mutual
-                x[u] = nbr[(size_t)n * nbr_stride + t];
-                pos[u] = posmask[(size_t)n * k + t] != 0;
-                inc[u] = (float)(mutual[(size_t)n * k + t] & 0x7f);
-                own[u] = coef_n != 0.f;
-                if (!own[u] && inc[u] == 0.f) x[u] = -1;  // nothing flows along this edge
-            } else if (t < total) {  // a non-mutual incoming edge x -> n
-                const int p = rev_edge[e0 + t - k];
-                x[u] = p / k;
-                pos[u] = posmask[p] != 0;
-                inc[u] = 1.f;
-            }
+            float t = fn.x * v[u].x;   // the forward's expression and order (contrast_forward_unit_kernel)
+            t += fn.y * v[u].y;
+            t += fn.z * v[u].z;
+            t += fn.w * v[u].w;
+#pragma unroll
+            for (int d = LPR / 2; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+            s[u] = t;
+            smine = q == u ? t : smine;
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool ok = x[u] >= 0;
-            rx[u] = ok ? rec4[(size_t)x[u] * 2] : make_float4(1.f, 0.f, 1.f, 0.f);
-            mx[u] = ok ? rec[x[u]].margin : 0.f;
-            v[u] = ok ? f4[(size_t)x[u] * LPR + q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float nx = rx[u].x;
-            const float hx = __fdiv_rn(v[u].x, nx), hy = __fdiv_rn(v[u].y, nx), hz = __fdiv_rn(v[u].z, nx), hw = __fdiv_rn(v[u].w, nx);
-            float s = fn.x * hx;   // the forward's expression and order (contrast_forward_rows_kernel)
-            s += fn.y * hy;
-            s += fn.z * hz;
-            s += fn.w * hw;
-#pragma unroll
-            for (int d = LPR / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-            if (x[u] < 0) continue;
+        float gn = 0.f;
+        if (myx >= 0) {
             float g = 0.f;
-            if (own[u]) {
-                const float e = expf(__fdiv_rn(pos[u] ? __fsub_rn(s, margin_n) : s, temperature));
-                g += coef_n * e * ((pos[u] ? tsum_n : 0.f) - psum_n);
+            if (own) {
+                const float e = expf(__fdiv_rn(pos ? __fsub_rn(smine, margin_n) : smine, temperature));
+                g += coef_n * e * ((pos ? tsum_n : 0.f) - psum_n);
             }
-            if (inc[u] != 0.f && rx[u].y != 0.f) {
-                const float e = expf(__fdiv_rn(pos[u] ? __fsub_rn(s, mx[u]) : s, temperature));
-                g += inc[u] * (rx[u].y * e * ((pos[u] ? rx[u].z : 0.f) - rx[u].w));
+            if (inc != 0.f && rx.y != 0.f) {
+                const float e = expf(__fdiv_rn(pos ? __fsub_rn(smine, mx) : smine, temperature));
+                g += inc * (rx.y * e * ((pos ? rx.z : 0.f) - rx.w));
             }
-            const float gn = g / nn;
-            acc.x += gn * (hx - s * fn.x);
-            acc.y += gn * (hy - s * fn.y);
-            acc.z += gn * (hz - s * fn.z);
-            acc.w += gn * (hw - s * fn.w);
+            gn = g / nn;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float gu = __shfl(gn, row0 | u, 64);
+            acc.x += gu * (v[u].x - s[u] * fn.x);
+            acc.y += gu * (v[u].y - s[u] * fn.y);
+            acc.z += gu * (v[u].z - s[u] * fn.z);
+            acc.w += gu * (v[u].w - s[u] * fn.w);
         }
     }
 #pragma unroll
@@ -874,26 +903,30 @@ AMC_API int amc3d_select_anchors(int m, const float *a, int *sel, size_t sel_int
 
 AMC_API int amc3d_contrast_forward(int m, int C, int k, int nbr_stride, const float *f, const int *nbr,
                                    const unsigned char *posmask, const float *a, const int *sel, float mu, float nu,
-                                   float temperature, float *norm, float *sim, float *loss_pt, float *mean_cnt,
-                                   void *stream_)
+                                   float temperature, float *norm, float *unit, float *sim, float *loss_pt,
+                                   float *mean_cnt, void *stream_)
 {
     if (m <= 0) return 0;
     if (C <= 0 || k <= 0 || nbr_stride < k || !f || !nbr || !posmask || !a || !norm || !sim || !loss_pt || !mean_cnt)
         return bad_arg("amc3d_contrast_forward: bad argument");
     hipStream_t stream = (hipStream_t)stream_;
-    hipLaunchKernelGGL(row_norm_kernel, dim3(div_up(m, 4)), dim3(256), 0, stream, m, C, f, norm);
-#define AMC_FWD(LPR)                                                                                                 \
-    hipLaunchKernelGGL((contrast_forward_rows_kernel<LPR>), dim3(div_up(m, 4)), dim3(256), 0, stream, m, k, nbr_stride, \
-                       f, norm, nbr, posmask, a, sel, mu, nu, temperature, sim, loss_pt)
-    const bool al16 = (((uintptr_t)f) & 15) == 0;
-    if (al16 && C == 16) AMC_FWD(4);
-    else if (al16 && C == 32) AMC_FWD(8);
-    else if (al16 && C == 64) AMC_FWD(16);
-    else if (al16 && C == 128) AMC_FWD(32);
-    else if (al16 && C == 256) AMC_FWD(64);
-    else
+    const bool rows = unit && ((((uintptr_t)f) | ((uintptr_t)unit)) & 15) == 0 && amc3d_contrast_backward_csr_supported(C);
+#define AMC_FWD(LPR)                                                                                                       \
+    do {                                                                                                                   \
+        hipLaunchKernelGGL((row_unit_kernel<LPR>), dim3(div_up((long)m * LPR, 256)), dim3(256), 0, stream, m, f, norm, unit); \
+        hipLaunchKernelGGL((contrast_forward_unit_kernel<LPR>), dim3(div_up(m, 4)), dim3(256), 0, stream, m, k, nbr_stride, \
+                           (const float *)unit, nbr, posmask, a, sel, mu, nu, temperature, sim, loss_pt);                  \
+    } while (0)
+    if (rows && C == 16) AMC_FWD(4);
+    else if (rows && C == 32) AMC_FWD(8);
+    else if (rows && C == 64) AMC_FWD(16);
+    else if (rows && C == 128) AMC_FWD(32);
+    else if (rows && C == 256) AMC_FWD(64);
+    else {
+        hipLaunchKernelGGL(row_norm_kernel, dim3(div_up(m, 4)), dim3(256), 0, stream, m, C, f, norm);
         hipLaunchKernelGGL(contrast_forward_kernel, dim3(div_up((long)m * 32, 256)), dim3(256), 0, stream, m, C, k,
                            nbr_stride, f, norm, nbr, posmask, a, sel, mu, nu, temperature, sim, loss_pt);
+    }
 #undef AMC_FWD
     // anchors the list skips never write loss_pt; masked_mean_kernel reads the selected ones only
     hipLaunchKernelGGL(masked_mean_kernel, dim3(1), dim3(1024), 0, stream, m, loss_pt, a, mean_cnt);
@@ -955,25 +988,25 @@ AMC_API int amc3d_contrast_backward_csr(int m, int C, int k, int nbr_stride, con
 AMC_API size_t amc3d_contrast_backward_mutual_workspace_bytes(int m) { return (size_t)(m > 0 ? m : 0) * sizeof(ContrastRecord) + 64; }
 
 // grad_f (m,C): every row written once (no zero-initialisation, no atomics).  mutual / rev from amc3d_contrast_mutual on the
-// same neighbour lists and ambiguities; sim, norm, mean_cnt as amc3d_contrast_forward left them.
-AMC_API int amc3d_contrast_backward_mutual(int m, int C, int k, int nbr_stride, const float *f, const float *norm,
+// same neighbour lists and ambiguities; unit (the rows f_i / norm_i), sim, norm, mean_cnt as amc3d_contrast_forward left them.
+AMC_API int amc3d_contrast_backward_mutual(int m, int C, int k, int nbr_stride, const float *unit, const float *norm,
                                            const int *nbr, const unsigned char *posmask, const float *a,
                                            const unsigned char *mutual, const int *rev, float mu, float nu, float temperature,
                                            const float *sim, const float *mean_cnt, const float *grad_out, void *workspace,
                                            size_t workspace_bytes, float *grad_f, void *stream_)
 {
     if (m <= 0) return 0;
-    if (!amc3d_contrast_backward_csr_supported(C) || k <= 0 || nbr_stride < k || !f || !norm || !nbr || !posmask || !a || !mutual ||
+    if (!amc3d_contrast_backward_csr_supported(C) || k <= 0 || nbr_stride < k || !unit || !norm || !nbr || !posmask || !a || !mutual ||
         !rev || !sim || !mean_cnt || !grad_out || !grad_f || !workspace ||
         workspace_bytes < amc3d_contrast_backward_mutual_workspace_bytes(m) ||
-        (((uintptr_t)f | (uintptr_t)grad_f | (uintptr_t)workspace) & 15))
+        (((uintptr_t)unit | (uintptr_t)grad_f | (uintptr_t)workspace) & 15))
         return bad_arg("amc3d_contrast_backward_mutual: bad argument (C must be 16, 32, 64, 128 or 256; 16-byte aligned rows)");
     hipStream_t stream = (hipStream_t)stream_;
     ContrastRecord *rec = (ContrastRecord *)workspace;
     hipLaunchKernelGGL(contrast_record_kernel, dim3(div_up((long)m * 32, 256)), dim3(256), 0, stream, m, k, norm, posmask, a, mu, nu,
                        temperature, sim, mean_cnt, grad_out, rec);
 #define AMC_BWD(LPR)                                                                                                    \
-    hipLaunchKernelGGL((contrast_backward_mutual_kernel<LPR>), dim3(div_up(m, 4)), dim3(256), 0, stream, m, k, nbr_stride, f, \
+    hipLaunchKernelGGL((contrast_backward_mutual_kernel<LPR>), dim3(div_up(m, 4)), dim3(256), 0, stream, m, k, nbr_stride, unit, \
                        nbr, posmask, mutual, rev, (const ContrastRecord *)rec, temperature, grad_f)
     if (C == 16) AMC_BWD(4);
     else if (C == 32) AMC_BWD(8);

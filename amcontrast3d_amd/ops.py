@@ -584,14 +584,18 @@ class ContrastStage(Function):
         m, C = f.shape
         dev = f.device
         norm = torch.empty(m, dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        # the unit rows f_i / |f_i| the row-gather kernels read (forward, and the mutual-edge backward instead of f)
+        unit = torch.empty_like(f) if lib.amc3d_contrast_backward_csr_supported(C) else None
         sim = torch.empty(m, k, dtype=torch.float32, device=dev)
         loss_pt = torch.empty(m, dtype=torch.float32, device=dev)
         mean_cnt = torch.empty(2, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), timing.span("contrast_forward", m * C * 4 + m * k * 9 + m * 12, moved=m * C * 4 * (1 + k) + m * k * 9 + m * 12):
-            _lib.check(_lib.load().amc3d_contrast_forward(m, C, k, stride, _ptr(f), nptr, _ptr(posmask), _ptr(a),
-                                                          _ptr(anchors) if anchors is not None else None,
-                                                          float(mu), float(nu), float(temperature), _ptr(norm),
-                                                          _ptr(sim), _ptr(loss_pt), _ptr(mean_cnt), _stream(f)),
+        with torch.cuda.device(dev), timing.span("contrast_forward", m * C * 4 + m * k * 9 + m * 12, moved=m * C * 4 * (3 + k) + m * k * 9 + m * 12):
+            _lib.check(lib.amc3d_contrast_forward(m, C, k, stride, _ptr(f), nptr, _ptr(posmask), _ptr(a),
+                                                  _ptr(anchors) if anchors is not None else None,
+                                                  float(mu), float(nu), float(temperature), _ptr(norm),
+                                                  _ptr(unit) if unit is not None else None,
+                                                  _ptr(sim), _ptr(loss_pt), _ptr(mean_cnt), _stream(f)),
                        "contrast_forward")
         if rev is not None:
             _need_dtype(torch.int32, rev=rev)
@@ -599,25 +603,25 @@ class ContrastStage(Function):
         if mutual is not None:  # rev then holds the non-mutual edges only (contrast_mutual)
             _need_dtype(torch.uint8, mutual=mutual)
             assert rev is not None and mutual.is_contiguous() and mutual.shape == (m, k) and mutual.device == dev
-        ctx.save_for_backward(f, norm, keep, posmask, a, sim, mean_cnt, anchors, rev, mutual)
+        ctx.save_for_backward(f, norm, keep, posmask, a, sim, mean_cnt, anchors, rev, mutual, unit)
         ctx.args = (float(mu), float(nu), float(temperature), k, stride)
         return mean_cnt[0].clone()
 
     @staticmethod
     def backward(ctx, grad_out):
-        f, norm, nbr, posmask, a, sim, mean_cnt, anchors, rev, mutual = ctx.saved_tensors
+        f, norm, nbr, posmask, a, sim, mean_cnt, anchors, rev, mutual, unit = ctx.saved_tensors
         mu, nu, temperature, k, stride = ctx.args
         m, C = f.shape
         g = grad_out.detach().to(torch.float32).reshape(1).contiguous()
         nptr = _ptr(nbr)  # data_ptr includes the offset of an idx[:, 1:] view: the first used column
         lib = _lib.load()
-        if mutual is not None and lib.amc3d_contrast_backward_csr_supported(C):
+        if mutual is not None and unit is not None:
             grad_f = torch.empty_like(f)  # every row is written
             wb = int(lib.amc3d_contrast_backward_mutual_workspace_bytes(m))
             work = torch.empty(wb, dtype=torch.uint8, device=f.device)
             with torch.cuda.device(f.device), timing.span("contrast_backward", m * C * 8 + m * k * 10 + m * 8,
                                                           moved=m * C * 4 * (2 + k) + m * k * 42 + m * 40):
-                _lib.check(lib.amc3d_contrast_backward_mutual(m, C, k, stride, _ptr(f), _ptr(norm), nptr, _ptr(posmask), _ptr(a),
+                _lib.check(lib.amc3d_contrast_backward_mutual(m, C, k, stride, _ptr(unit), _ptr(norm), nptr, _ptr(posmask), _ptr(a),
                                                               _ptr(mutual), _ptr(rev), mu, nu, temperature, _ptr(sim),
                                                               _ptr(mean_cnt), _ptr(g), _ptr(work), wb, _ptr(grad_f), _stream(f)),
                            "contrast_backward_mutual")

@@ -189,10 +189,14 @@ int amc3d_select_anchors(int m, const float *a, int *sel, size_t sel_ints, void 
  * s = cosine similarity of the (m,C) embeddings f.  Outputs: norm (m) clamped row norms, sim (m,k),
  * loss_pt (m), mean_cnt[2] = {stage loss, number of anchors}; all kept for the backward.
  * sel: the list of amc3d_select_anchors for this a (sim / loss_pt are then written for the listed anchors
- * only), or NULL to visit and test every anchor. */
+ * only), or NULL to visit and test every anchor.
+ * unit (m,C) or NULL: receives the unit rows f_i / norm_i; with it (and C in {16, 32, 64, 128, 256}, 16-byte aligned rows) the
+ * row-gather kernels run on those rows -- no division per fetched neighbour element -- and amc3d_contrast_backward_mutual
+ * takes the same buffer; NULL: the generic kernel on f and norm. */
 int amc3d_contrast_forward(int m, int C, int k, int nbr_stride, const float *f, const int *nbr,
                            const unsigned char *posmask, const float *a, const int *sel, float mu, float nu,
-                           float temperature, float *norm, float *sim, float *loss_pt, float *mean_cnt, void *stream);
+                           float temperature, float *norm, float *unit, float *sim, float *loss_pt, float *mean_cnt,
+                           void *stream);
 
 /* grad_f (m,C) += grad_out[0] * d(stage loss)/d f; the caller zero-initialises grad_f.
  * grad_out is a DEVICE scalar (no host sync).  C <= 512.  sel as in the forward. */
@@ -226,12 +230,12 @@ int amc3d_contrast_backward_csr(int m, int C, int k, int nbr_stride, const float
  *   0 < a[i] <= 1 that point at n (those edges also carry bit 0x80 in mutual[]; the count is in the low 7 bits).  k <= 64.  Coordinates and labels only: part of the stage's plan.  Workspace:
  *   amc3d_contrast_csr_workspace_bytes(m).
  * amc3d_contrast_backward_mutual: workspace amc3d_contrast_backward_mutual_workspace_bytes(m) (the per-anchor records);
- *   norm, sim, mean_cnt as amc3d_contrast_forward wrote them.  C in {16, 32, 64, 128, 256}. */
+ *   unit, norm, sim, mean_cnt as amc3d_contrast_forward wrote them.  C in {16, 32, 64, 128, 256}. */
 size_t amc3d_contrast_mutual_workspace_bytes(int m);
 int amc3d_contrast_mutual(int m, int k, int nbr_stride, const int *nbr, const float *dist2, const float *a,
                           unsigned char *mutual, int *rev, void *workspace, size_t workspace_bytes, void *stream);
 size_t amc3d_contrast_backward_mutual_workspace_bytes(int m);
-int amc3d_contrast_backward_mutual(int m, int C, int k, int nbr_stride, const float *f, const float *norm, const int *nbr,
+int amc3d_contrast_backward_mutual(int m, int C, int k, int nbr_stride, const float *unit, const float *norm, const int *nbr,
                                    const unsigned char *posmask, const float *a, const unsigned char *mutual, const int *rev,
                                    float mu, float nu, float temperature, const float *sim, const float *mean_cnt,
                                    const float *grad_out, void *workspace, size_t workspace_bytes, float *grad_f, void *stream);

@@ -20,7 +20,7 @@ for i, (g, C) in enumerate(zip(plan["loss"], (32, 64, 128, 256))):
     f = torch.randn(m, C, device=dev, requires_grad=True)
     sel = int(g["anchors"][0])
     def fwd():
-        return ops.contrast_stage(f, g["neighbor_idx"], g["posmask"], g["ambiguity"], aa.mu, aa.nu, aa.temperature, g["anchors"])
+        return ops.contrast_stage(f, g["neighbor_idx"], g["posmask"], g["ambiguity"], aa.mu, aa.nu, aa.temperature, g["anchors"], g.get("rev"), g.get("mutual"))
     for _ in range(3):
         fwd().backward()
     torch.cuda.synchronize()
