@@ -57,6 +57,7 @@ SIGNATURES = {
     "amc3d_select_anchors_ints": (_sz, [_i]),
     "amc3d_select_anchors": (_i, [_i, _vp, _vp, _sz, _vp]),
     "amc3d_contrast_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_contrast_forward_cm": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_contrast_backward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_grouped_conv_supported": (_i, [_i, _i]),
     "amc3d_transpose_cn": (_i, [_i, _i, _i, _vp, _vp, _vp]),

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(CSR_BS) void csr_collapse_kernel(int C, int n, long
         const float *d0 = dp + b * 3 * P, *d1 = d0 + P, *d2 = d1 + P;
         const float *xrow = dx1_pm + b * P * C + c;
         const int s = rev_start[g], e = rev_start[g + 1];
-        float q = 0.f;
+        float q = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, q4 = 0.f;  // this point's sums in fp32 (a list has ~8 edges), fp64 across points
         for (int j0 = s; j0 < e; j0 += 8) {  // eight edges at a time: their loads are independent, one latency for all
             int p[8];
             float e0[8], e1[8], e2[8], d[8];
@@ -166,10 +166,10 @@ __global__ __launch_bounds__(CSR_BS) void csr_collapse_kernel(int C, int n, long
                 float dv = d[u];
                 if (j0 + u >= e || (relu && !(__fadd_rn(__fmul_rn(xh, ga), be) > 0.f))) dv = 0.f;
                 q += dv;
-                const double dd = dv;
-                a0 += dd; a1 += dd * (double)xh; a2 += dd * (double)e0[u]; a3 += dd * (double)e1[u]; a4 += dd * (double)e2[u];
+                q1 = __fmaf_rn(dv, xh, q1); q2 = __fmaf_rn(dv, e0[u], q2); q3 = __fmaf_rn(dv, e1[u], q3); q4 = __fmaf_rn(dv, e2[u], q4);
             }
         }
+        a0 += (double)q; a1 += (double)q1; a2 += (double)q2; a3 += (double)q3; a4 += (double)q4;
         Q[g * C + c] = q;
     }
     red[grp][cl][0] = a0; red[grp][cl][1] = a1; red[grp][cl][2] = a2; red[grp][cl][3] = a3; red[grp][cl][4] = a4;

@@ -155,6 +155,41 @@ __global__ __launch_bounds__(256) void row_unit_kernel(int m, const float *__res
     if (q == 0) norm[i] = n;
 }
 
+// the same from CHANNEL-major embeddings f_cm (B, C, n), as the decoder leaves them (pointnext_AA.py:518-519 makes the
+// point-major copy the loss reads with flatten(transpose)): a 64-point tile goes through LDS, the row-major f is never
+// written.  Same arithmetic and summation order as row_unit_kernel.
+template <int LPR, int TP>  // TP points per tile (16 at the wide, short stages: a cloud of 375 points is 24 tiles, not 6)
+__global__ __launch_bounds__(256) void row_unit_cm_kernel(int n, const float *__restrict__ f_cm, float *__restrict__ norm,
+                                                          float *__restrict__ unit)
+{
+    constexpr int C = 4 * LPR, TS = TP + 1;
+    extern __shared__ float s_tile[];  // [C][TP + 1]
+    const int b = blockIdx.y, n0 = blockIdx.x * TP;
+    for (int e = threadIdx.x; e < C * TP; e += 256) {
+        const int ch = e / TP, pt = e - ch * TP;
+        s_tile[ch * TS + pt] = n0 + pt < n ? f_cm[((size_t)b * C + ch) * n + n0 + pt] : 0.f;
+    }
+    __syncthreads();
+    const int q = threadIdx.x & (LPR - 1);
+    for (int pl = threadIdx.x / LPR; pl < TP; pl += 256 / LPR) {  // (the same trip count for every thread)
+        float4 v = make_float4(s_tile[(4 * q) * TS + pl], s_tile[(4 * q + 1) * TS + pl], s_tile[(4 * q + 2) * TS + pl],
+                               s_tile[(4 * q + 3) * TS + pl]);
+        float s = v.x * v.x;
+        s += v.y * v.y;
+        s += v.z * v.z;
+        s += v.w * v.w;
+#pragma unroll
+        for (int d = LPR / 2; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        const float nv = fmaxf(sqrtf(s), 1e-8f);
+        v.x = __fdiv_rn(v.x, nv); v.y = __fdiv_rn(v.y, nv); v.z = __fdiv_rn(v.z, nv); v.w = __fdiv_rn(v.w, nv);
+        if (n0 + pl < n) {
+            const size_t i = (size_t)b * n + n0 + pl;
+            reinterpret_cast<float4 *>(unit)[i * LPR + q] = v;
+            if (q == 0) norm[i] = nv;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The anchors that enter the loss, 0 < a <= 1 (MarginContrast.py:250-252), as a compact ascending list:
 // sel[0] = count, sel[1..count] = anchor ids, sel[m+1..] = per-256-block counts (scratch).  The list depends on
@@ -901,19 +936,23 @@ AMC_API int amc3d_select_anchors(int m, const float *a, int *sel, size_t sel_int
     return launch_status("amc3d_select_anchors");
 }
 
-AMC_API int amc3d_contrast_forward(int m, int C, int k, int nbr_stride, const float *f, const int *nbr,
+// cm_b > 0: f is channel-major (cm_b, C, m / cm_b) and only the unit-row kernels apply
+static int contrast_forward_launch(int cm_b, int m, int C, int k, int nbr_stride, const float *f, const int *nbr,
                                    const unsigned char *posmask, const float *a, const int *sel, float mu, float nu,
-                                   float temperature, float *norm, float *unit, float *sim, float *loss_pt,
-                                   float *mean_cnt, void *stream_)
+                                   float temperature, float *norm, float *unit, float *sim, float *loss_pt, float *mean_cnt,
+                                   hipStream_t stream)
 {
-    if (m <= 0) return 0;
-    if (C <= 0 || k <= 0 || nbr_stride < k || !f || !nbr || !posmask || !a || !norm || !sim || !loss_pt || !mean_cnt)
-        return bad_arg("amc3d_contrast_forward: bad argument");
-    hipStream_t stream = (hipStream_t)stream_;
     const bool rows = unit && ((((uintptr_t)f) | ((uintptr_t)unit)) & 15) == 0 && amc3d_contrast_backward_csr_supported(C);
+    if (cm_b > 0 && !rows) return bad_arg("amc3d_contrast_forward_cm: C must be 16, 32, 64, 128 or 256; unit required, 16-byte aligned");
 #define AMC_FWD(LPR)                                                                                                       \
     do {                                                                                                                   \
-        hipLaunchKernelGGL((row_unit_kernel<LPR>), dim3(div_up((long)m * LPR, 256)), dim3(256), 0, stream, m, f, norm, unit); \
+        if (cm_b > 0) {                                                                                                    \
+            constexpr int TP = LPR >= 32 ? 16 : 64;                                                                        \
+            const size_t lds = (size_t)4 * LPR * (TP + 1) * sizeof(float);                                                 \
+            hipLaunchKernelGGL((row_unit_cm_kernel<LPR, TP>), dim3(div_up(m / cm_b, TP), cm_b), dim3(256), lds, stream,    \
+                               m / cm_b, f, norm, unit);                                                                   \
+        } else                                                                                                             \
+            hipLaunchKernelGGL((row_unit_kernel<LPR>), dim3(div_up((long)m * LPR, 256)), dim3(256), 0, stream, m, f, norm, unit); \
         hipLaunchKernelGGL((contrast_forward_unit_kernel<LPR>), dim3(div_up(m, 4)), dim3(256), 0, stream, m, k, nbr_stride, \
                            (const float *)unit, nbr, posmask, a, sel, mu, nu, temperature, sim, loss_pt);                  \
     } while (0)
@@ -931,6 +970,33 @@ AMC_API int amc3d_contrast_forward(int m, int C, int k, int nbr_stride, const fl
     // anchors the list skips never write loss_pt; masked_mean_kernel reads the selected ones only
     hipLaunchKernelGGL(masked_mean_kernel, dim3(1), dim3(1024), 0, stream, m, loss_pt, a, mean_cnt);
     return launch_status("amc3d_contrast_forward");
+}
+
+AMC_API int amc3d_contrast_forward(int m, int C, int k, int nbr_stride, const float *f, const int *nbr,
+                                   const unsigned char *posmask, const float *a, const int *sel, float mu, float nu,
+                                   float temperature, float *norm, float *unit, float *sim, float *loss_pt,
+                                   float *mean_cnt, void *stream_)
+{
+    if (m <= 0) return 0;
+    if (C <= 0 || k <= 0 || nbr_stride < k || !f || !nbr || !posmask || !a || !norm || !sim || !loss_pt || !mean_cnt)
+        return bad_arg("amc3d_contrast_forward: bad argument");
+    return contrast_forward_launch(0, m, C, k, nbr_stride, f, nbr, posmask, a, sel, mu, nu, temperature, norm, unit, sim, loss_pt,
+                                   mean_cnt, (hipStream_t)stream_);
+}
+
+// the same on channel-major embeddings f_cm (b, C, n), m = b * n anchors in cloud-major order (the decoder's layout: no
+// point-major copy of f is made; unit receives the point-major unit rows the backward reads)
+AMC_API int amc3d_contrast_forward_cm(int b, int C, int n, int k, int nbr_stride, const float *f_cm, const int *nbr,
+                                      const unsigned char *posmask, const float *a, const int *sel, float mu, float nu,
+                                      float temperature, float *norm, float *unit, float *sim, float *loss_pt,
+                                      float *mean_cnt, void *stream_)
+{
+    if (b <= 0 || n <= 0) return 0;
+    if ((long)b * n > 0x7fffffffL || C <= 0 || k <= 0 || nbr_stride < k || !f_cm || !nbr || !posmask || !a || !norm || !unit || !sim ||
+        !loss_pt || !mean_cnt)
+        return bad_arg("amc3d_contrast_forward_cm: bad argument");
+    return contrast_forward_launch(b, b * n, C, k, nbr_stride, f_cm, nbr, posmask, a, sel, mu, nu, temperature, norm, unit, sim,
+                                   loss_pt, mean_cnt, (hipStream_t)stream_);
 }
 
 AMC_API int amc3d_contrast_backward(int m, int C, int k, int nbr_stride, const float *f, const float *norm,

@@ -155,15 +155,23 @@ class ContrastHead(nn.Module):
         g = _stage_plan(n, i, stageACE_list, target, self.nstride, num_classes, ignore_index, ambiguity_args,
                         self.ftype)
         neighbor_idx, posmask, ambiguity_soft = g['neighbor_idx'], g['posmask'], g['ambiguity']
+        target_ai = ambiguity_soft
+        output_ai = stageACE_list['ambiguity'][i].flatten() if 'ambiguity' in stageACE_list.keys() else None
+        fused = (ambiguity_args.margin == 'adaptive' and ambiguity_args.db == '-m'
+                 and ambiguity_args.supervisedCL == 'Method1' and ambiguity_args.temperature is not None)
+        # the decoder's channel-major embedding, where the stage entry still holds it: the fused stage reads it as it is and
+        # the (B*n, C) copy of pointnext_AA.py:518-519 is not made
+        stage = stageACE_list[n][i]
+        f_cm = stage.channel_major() if fused and hasattr(stage, 'channel_major') else None
+        if (f_cm is not None and not os.environ.get("AMC3D_LOSS_ROWS")
+                and ops.contrast_stage_supported_cm(f_cm, g.get('anchors'), g.get('rev'), g.get('mutual'))):
+            loss = ops.contrast_stage_cm(f_cm, neighbor_idx, posmask, ambiguity_soft, ambiguity_args.mu, ambiguity_args.nu,
+                                         ambiguity_args.temperature, g['anchors'], g['rev'], g['mutual'])
+            return loss, output_ai, target_ai
         features = fetch_pxo(n, i, stageACE_list, self.ftype)[1]
         if features.dtype != torch.float32:  # embeddings produced under autocast (use_amp): the loss is evaluated in fp32
             features = features.float()
         k = neighbor_idx.shape[1]
-        target_ai = ambiguity_soft
-        output_ai = stageACE_list['ambiguity'][i].flatten() if 'ambiguity' in stageACE_list.keys() else None
-
-        fused = (ambiguity_args.margin == 'adaptive' and ambiguity_args.db == '-m'
-                 and ambiguity_args.supervisedCL == 'Method1' and ambiguity_args.temperature is not None)
         if fused:
             # anchors with 0 < a <= 1 enter the loss (MarginContrast.py:250-257); selection, cosine
             # similarity, margin soft-NN loss and the mean are one forward and one backward kernel

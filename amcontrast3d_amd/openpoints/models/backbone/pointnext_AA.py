@@ -34,6 +34,14 @@ from .pointnext_blocks import (_BLOCKS, FeaturePropogation, InvResMLP, LocalAggr
 _OFFSETS = {}
 
 
+def _set_embedding(stage, f):
+    """stage['f_out'] = rows of the channel-major embedding f (B, C, n); deferred where the stage entry can defer it"""
+    if isinstance(stage, _Stage):
+        stage.set_features(f)
+    else:
+        stage['f_out'] = point_major_rows(f)
+
+
 class _Stage(dict):
     """One entry of stageACE_list['down'] / ['up']: {'p_out', 'f_out', 'offset'} (pointnext_AA.py:458-462).  The
     encoder's 'f_out' -- a transposed copy of its features -- is overwritten by the decoder before anything reads it
@@ -48,6 +56,15 @@ class _Stage(dict):
             from amcontrast3d_amd.ops import point_major_rows
             dict.__setitem__(self, 'f_out', point_major_rows(self._features))
         self._features = None
+
+    def set_features(self, features):
+        """the decoder's embedding of this resolution, channel-major (B, C, n): 'f_out' -- its (B*n, C) rows,
+        pointnext_AA.py:518-519 -- is made when somebody reads it; the fused loss stage takes channel_major() instead"""
+        dict.pop(self, 'f_out', None)
+        self._features = features
+
+    def channel_major(self):
+        return self._features
 
     def __getitem__(self, key):
         if key == 'f_out':
@@ -278,7 +295,7 @@ class PointNextDecoder_AMContrast3D(nn.Module):
             f[i - 1] = self.decoder[i][1:](
                 [p[i], self.decoder[i][0]([p[i - 1], f[i - 1]], [p[i], f[i]], geom=geometry['decoder'][i])])[1]
             # decoder embedding of this resolution, (B*n, C) rows, for the contrastive loss
-            stageACE_list['up'][i]['f_out'] = point_major_rows(f[i - 1])
+            _set_embedding(stageACE_list['up'][i], f[i - 1])
         return f[-len(self.decoder) - 1].squeeze(-1), stageACE_list
 
     def forward(self, p, f, stageACE_list):

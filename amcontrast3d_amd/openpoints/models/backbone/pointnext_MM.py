@@ -15,7 +15,7 @@ import torch
 from amcontrast3d_amd.ops import point_major_rows
 
 from ..build import MODELS
-from .pointnext_AA import PointNextDecoder_AMContrast3D, PointNextEncoder_AMContrast3D
+from .pointnext_AA import PointNextDecoder_AMContrast3D, PointNextEncoder_AMContrast3D, _set_embedding
 from openpoints.AMContrast3D.MarginContrast import AmbiguityHead
 from openpoints.AMContrast3D.MaskedRefine import RefinementMethod
 
@@ -56,7 +56,7 @@ class PointNextDecoder_M_AMContrast3D(PointNextDecoder_AMContrast3D):
             f[i - 1] = self.decoder[i][1:](
                 [p[i], self.decoder[i][0]([p[i - 1], f[i - 1]], [p[i], f[i]], geom=geometry['decoder'][i])])[1]
             # the contrastive embedding is taken BEFORE the refinement (pointnext_MM.py:541-544)
-            stage_list['up'][i]['f_out'] = point_major_rows(f[i - 1])
+            _set_embedding(stage_list['up'][i], f[i - 1])
             a = a_list[i].unsqueeze(0).view(B, 1, -1)
             refine = RefinementMethod(stage_list, p[i - 1], f[i - 1], a, i, B, nsample_k, fusion, threshold_max,
                                       threshold, gamma)

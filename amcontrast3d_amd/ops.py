@@ -649,6 +649,70 @@ class ContrastStage(Function):
 contrast_stage = ContrastStage.apply
 
 
+class ContrastStageChannelMajor(Function):
+    """contrast_stage on the decoder's channel-major embeddings f_cm (B, C, n) -- what the reference flattens into (B*n, C) rows
+    first (pointnext_AA.py:518-519).  The point-major copy of f is never made: the forward writes the unit rows f_i / |f_i|
+    through an LDS tile, the mutual-edge backward reads only those; its gradient rows go back through one tiled transpose.
+    Needs the mutual-edge plan (anchors, rev, mutual) and C in {16, 32, 64, 128, 256}: contrast_stage_supported_cm()."""
+
+    @staticmethod
+    def forward(ctx, f_cm, neighbor_idx, posmask, a, mu, nu, temperature, anchors, rev, mutual):
+        _need_gpu(f_cm, neighbor_idx, posmask, a, anchors, rev, mutual)
+        _need_dtype(torch.float32, f_cm=f_cm)
+        _need_dtype(torch.int32, anchors=anchors, rev=rev)
+        _need_dtype(torch.uint8, mutual=mutual)
+        f_cm = f_cm.contiguous()
+        B, C, n = f_cm.shape
+        m = B * n
+        nptr, k, stride, keep = _nbr_view(neighbor_idx)
+        assert posmask.dtype == torch.bool and posmask.is_contiguous() and neighbor_idx.shape[0] == m
+        assert anchors.is_contiguous() and anchors.numel() >= m + 1 and rev.is_contiguous() and rev.numel() == m + 1 + m * k
+        assert mutual.is_contiguous() and mutual.shape == (m, k)
+        dev = f_cm.device
+        norm = torch.empty(m, dtype=torch.float32, device=dev)
+        unit = torch.empty(m, C, dtype=torch.float32, device=dev)
+        sim = torch.empty(m, k, dtype=torch.float32, device=dev)
+        loss_pt = torch.empty(m, dtype=torch.float32, device=dev)
+        mean_cnt = torch.empty(2, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev), timing.span("contrast_forward", m * C * 4 + m * k * 9 + m * 12, moved=m * C * 4 * (2 + k) + m * k * 9 + m * 12):
+            _lib.check(_lib.load().amc3d_contrast_forward_cm(B, C, n, k, stride, _ptr(f_cm), nptr, _ptr(posmask), _ptr(a), _ptr(anchors),
+                                                             float(mu), float(nu), float(temperature), _ptr(norm), _ptr(unit),
+                                                             _ptr(sim), _ptr(loss_pt), _ptr(mean_cnt), _stream(f_cm)),
+                       "contrast_forward_cm")
+        ctx.save_for_backward(norm, keep, posmask, a, sim, mean_cnt, rev, mutual, unit)
+        ctx.args = (float(mu), float(nu), float(temperature), k, stride, B, C, n)
+        return mean_cnt[0].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        norm, nbr, posmask, a, sim, mean_cnt, rev, mutual, unit = ctx.saved_tensors
+        mu, nu, temperature, k, stride, B, C, n = ctx.args
+        m = B * n
+        g = grad_out.detach().to(torch.float32).reshape(1).contiguous()
+        lib = _lib.load()
+        grad_rows = torch.empty_like(unit)  # every row is written
+        grad_cm = torch.empty(B, C, n, dtype=torch.float32, device=unit.device)
+        wb = int(lib.amc3d_contrast_backward_mutual_workspace_bytes(m))
+        work = torch.empty(wb, dtype=torch.uint8, device=unit.device)
+        with torch.cuda.device(unit.device), timing.span("contrast_backward", m * C * 8 + m * k * 10 + m * 8,
+                                                         moved=m * C * 4 * (4 + k) + m * k * 42 + m * 40):
+            _lib.check(lib.amc3d_contrast_backward_mutual(m, C, k, stride, _ptr(unit), _ptr(norm), _ptr(nbr), _ptr(posmask), _ptr(a),
+                                                          _ptr(mutual), _ptr(rev), mu, nu, temperature, _ptr(sim),
+                                                          _ptr(mean_cnt), _ptr(g), _ptr(work), wb, _ptr(grad_rows), _stream(unit)),
+                       "contrast_backward_mutual")
+            # (B, n, C) -> (B, C, n)
+            _lib.check(lib.amc3d_transpose_cn(B, n, C, _ptr(grad_rows), _ptr(grad_cm), _stream(unit)), "transpose_cn")
+        return (grad_cm,) + (None,) * 9
+
+
+def contrast_stage_supported_cm(f_cm, anchors, rev, mutual):
+    return (torch.is_tensor(f_cm) and f_cm.is_cuda and f_cm.dtype == torch.float32 and f_cm.dim() == 3 and anchors is not None
+            and rev is not None and mutual is not None and bool(_lib.load().amc3d_contrast_backward_csr_supported(int(f_cm.shape[1]))))
+
+
+contrast_stage_cm = ContrastStageChannelMajor.apply
+
+
 # ----------------------------------------------------------------------------------------------
 # training-mode BatchNorm fused with ReLU / neighbourhood max-pool (csrc/bn.hip)
 # ----------------------------------------------------------------------------------------------

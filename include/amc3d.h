@@ -198,6 +198,14 @@ int amc3d_contrast_forward(int m, int C, int k, int nbr_stride, const float *f, 
                            float temperature, float *norm, float *unit, float *sim, float *loss_pt, float *mean_cnt,
                            void *stream);
 
+/* The same on CHANNEL-major embeddings f_cm (b, C, n) -- the decoder's layout; pointnext_AA.py:518-519 makes the point-major
+ * copy with flatten(transpose) -- m = b * n anchors in cloud-major order.  C in {16, 32, 64, 128, 256}; unit (b*n, C) is required
+ * and receives the point-major unit rows (what amc3d_contrast_backward_mutual reads); no point-major copy of f is made. */
+int amc3d_contrast_forward_cm(int b, int C, int n, int k, int nbr_stride, const float *f_cm, const int *nbr,
+                              const unsigned char *posmask, const float *a, const int *sel, float mu, float nu,
+                              float temperature, float *norm, float *unit, float *sim, float *loss_pt, float *mean_cnt,
+                              void *stream);
+
 /* grad_f (m,C) += grad_out[0] * d(stage loss)/d f; the caller zero-initialises grad_f.
  * grad_out is a DEVICE scalar (no host sync).  C <= 512.  sel as in the forward. */
 int amc3d_contrast_backward(int m, int C, int k, int nbr_stride, const float *f, const float *norm,

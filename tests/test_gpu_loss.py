@@ -209,6 +209,39 @@ def test_contrast_backward_over_mutual_edges_on_a_real_knn_graph():
     print(f"mutual share of the 24-NN edges: {share:.3f}; non-mutual edges listed: {int(rev[m])}")
 
 
+@pytest.mark.parametrize("B,n", [(2, 6000), (3, 1000), (1, 77)])
+def test_contrast_stage_on_channel_major_embeddings(B, n):
+    """ops.contrast_stage_cm reads the decoder's (B, C, n) tensor as it is; loss and gradient are bit for bit those of
+    contrast_stage on flatten(f.transpose(1, 2)) (pointnext_AA.py:518-519) with the mutual-edge plan: same unit rows, same
+    kernels after them, the gradient rows through one tiled transpose.  n = 77, 1000: tiles that end inside a cloud."""
+    from amcontrast3d_amd import ops, synthetic
+    nb = synthetic.make_batch(B, n, first_id=5)
+    p = torch.from_numpy(nb["pos"]).reshape(-1, 3).contiguous().to(DEV)
+    y = torch.from_numpy(nb["y"]).reshape(-1).to(DEV)
+    m = p.shape[0]
+    o = torch.tensor([m], dtype=torch.int32, device=DEV)
+    idx, d2 = ops.knnquery(24, p, p, o, o)
+    nidx = idx[:, 1:]
+    posmask = ops.posmask_from_labels(y.int(), nidx)
+    g = torch.Generator().manual_seed(B * n)
+    a = torch.rand(m, generator=g).to(DEV)
+    a[torch.rand(m, generator=g).to(DEV) < 0.3] = 0.0
+    anchors = ops.select_anchors(a)
+    mutual, rev = ops.contrast_mutual(nidx, a)
+    for C in (16, 32, 64, 128, 256):
+        f_cm = torch.randn(B, C, n, generator=g).to(DEV)
+        assert ops.contrast_stage_supported_cm(f_cm, anchors, rev, mutual)
+        fa = f_cm.clone().requires_grad_(True)
+        la = ops.contrast_stage_cm(fa, nidx, posmask, a, -1.0, 0.5, 0.3, anchors, rev, mutual)
+        (la * 0.7).backward()
+        fb = f_cm.clone().requires_grad_(True)
+        lb = ops.contrast_stage(torch.flatten(fb.transpose(1, 2), 0, 1).contiguous(), nidx, posmask, a, -1.0, 0.5, 0.3, anchors, rev, mutual)
+        (lb * 0.7).backward()
+        assert torch.equal(la, lb), (C, float(la), float(lb))
+        assert torch.equal(fa.grad, fb.grad), (C, float((fa.grad - fb.grad).abs().max()))
+    assert not ops.contrast_stage_supported_cm(torch.randn(B, 20, n, device=DEV), anchors, rev, mutual)  # width without row kernels
+
+
 def test_contrast_stage_no_positive_anchor_is_constant():
     """n+ = 0 -> a = 1: the anchor contributes -log(1e-12) and no gradient."""
     from amcontrast3d_amd import ops
