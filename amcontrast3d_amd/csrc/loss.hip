@@ -236,6 +236,13 @@ __global__ __launch_bounds__(256) void select_write_kernel(int m, const float *_
 // Same per-element arithmetic as contrast_forward_kernel below (u_c / n_i * (v_c / n_x), channel order of the tree).
 // sel == nullptr: every anchor is visited and tested.
 // ---------------------------------------------------------------------------------------------
+// four channels of the cosine of two unit rows: one multiply and three fused multiply-adds, the same in the forward and in
+// the backward that recomputes it
+__device__ __forceinline__ float unit_dot4(const float4 &a, const float4 &b)
+{
+    return __fmaf_rn(a.w, b.w, __fmaf_rn(a.z, b.z, __fmaf_rn(a.y, b.y, __fmul_rn(a.x, b.x))));
+}
+
 template <int LPR>
 __global__ __launch_bounds__(256) void contrast_forward_unit_kernel(
     int m, int k, int nbr_stride, const float *__restrict__ unit, const int *__restrict__ nbr,
@@ -270,14 +277,11 @@ __global__ __launch_bounds__(256) void contrast_forward_unit_kernel(
         const bool mine = q < U && jq < k;
         const bool pos = mine ? posmask[(size_t)i * k + jq] != 0 : false;
 #pragma unroll
-        for (int t = 0; t < U; ++t) v[t] = nb[t] >= 0 ? h4[(size_t)nb[t] * LPR + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < U; ++t) v[t] = nb[t] >= 0 ? h4[(unsigned)nb[t] * (unsigned)LPR + (unsigned)q] : make_float4(0.f, 0.f, 0.f, 0.f);
         float s = 0.f;
 #pragma unroll
         for (int t = 0; t < U; ++t) {
-            float acc = u.x * v[t].x;
-            acc += u.y * v[t].y;
-            acc += u.z * v[t].z;
-            acc += u.w * v[t].w;
+            float acc = unit_dot4(u, v[t]);
 #pragma unroll
             for (int d = LPR / 2; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
             s = q == t ? acc : s;
@@ -741,14 +745,11 @@ __global__ __launch_bounds__(256) void contrast_backward_mutual_kernel(
         const float4 rx = myx >= 0 ? rec4[(size_t)myx * 2] : make_float4(1.f, 0.f, 1.f, 0.f);
         const float mx = myx >= 0 ? rec[myx].margin : 0.f;
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = x[u] >= 0 ? h4[(size_t)x[u] * LPR + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < U; ++u) v[u] = x[u] >= 0 ? h4[(unsigned)x[u] * (unsigned)LPR + (unsigned)q] : make_float4(0.f, 0.f, 0.f, 0.f);
         float s[U], smine = 0.f;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            float t = fn.x * v[u].x;   // the forward's expression and order (contrast_forward_unit_kernel)
-            t += fn.y * v[u].y;
-            t += fn.z * v[u].z;
-            t += fn.w * v[u].w;
+            float t = unit_dot4(fn, v[u]);   // the forward's expression and order (contrast_forward_unit_kernel)
 #pragma unroll
             for (int d = LPR / 2; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
             s[u] = t;
@@ -770,10 +771,10 @@ __global__ __launch_bounds__(256) void contrast_backward_mutual_kernel(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const float gu = __shfl(gn, row0 | u, 64);
-            acc.x += gu * (v[u].x - s[u] * fn.x);
-            acc.y += gu * (v[u].y - s[u] * fn.y);
-            acc.z += gu * (v[u].z - s[u] * fn.z);
-            acc.w += gu * (v[u].w - s[u] * fn.w);
+            acc.x = __fmaf_rn(gu, __fmaf_rn(-s[u], fn.x, v[u].x), acc.x);
+            acc.y = __fmaf_rn(gu, __fmaf_rn(-s[u], fn.y, v[u].y), acc.y);
+            acc.z = __fmaf_rn(gu, __fmaf_rn(-s[u], fn.z, v[u].z), acc.z);
+            acc.w = __fmaf_rn(gu, __fmaf_rn(-s[u], fn.w, v[u].w), acc.w);
         }
     }
 #pragma unroll
@@ -942,7 +943,9 @@ static int contrast_forward_launch(int cm_b, int m, int C, int k, int nbr_stride
                                    float temperature, float *norm, float *unit, float *sim, float *loss_pt, float *mean_cnt,
                                    hipStream_t stream)
 {
-    const bool rows = unit && ((((uintptr_t)f) | ((uintptr_t)unit)) & 15) == 0 && amc3d_contrast_backward_csr_supported(C);
+    // (the row kernels index 16-byte pieces with 32 bits: m * C / 4 < 2^32)
+    const bool rows = unit && ((((uintptr_t)f) | ((uintptr_t)unit)) & 15) == 0 && amc3d_contrast_backward_csr_supported(C) &&
+                      (long)m * C < (1L << 34);
     if (cm_b > 0 && !rows) return bad_arg("amc3d_contrast_forward_cm: C must be 16, 32, 64, 128 or 256; unit required, 16-byte aligned");
 #define AMC_FWD(LPR)                                                                                                       \
     do {                                                                                                                   \
@@ -1064,7 +1067,7 @@ AMC_API int amc3d_contrast_backward_mutual(int m, int C, int k, int nbr_stride, 
     if (m <= 0) return 0;
     if (!amc3d_contrast_backward_csr_supported(C) || k <= 0 || nbr_stride < k || !unit || !norm || !nbr || !posmask || !a || !mutual ||
         !rev || !sim || !mean_cnt || !grad_out || !grad_f || !workspace ||
-        workspace_bytes < amc3d_contrast_backward_mutual_workspace_bytes(m) ||
+        workspace_bytes < amc3d_contrast_backward_mutual_workspace_bytes(m) || (long)m * C >= (1L << 34) ||
         (((uintptr_t)unit | (uintptr_t)grad_f | (uintptr_t)workspace) & 15))
         return bad_arg("amc3d_contrast_backward_mutual: bad argument (C must be 16, 32, 64, 128 or 256; 16-byte aligned rows)");
     hipStream_t stream = (hipStream_t)stream_;

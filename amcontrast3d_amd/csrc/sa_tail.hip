@@ -106,26 +106,60 @@ __global__ __launch_bounds__(256) void sat_kernel(SatArgs a)
             for (int it = 0; it < NIT; ++it) accw[ct][it] = sat_f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     }
 
+    // C1 <= 32: the raw y1 of the NEXT tile is fetched into four float4 registers while this tile is multiplied
+    // (two to four workgroups share a CU: too few to hide 2-3 us of load latency per tile behind each other's MFMA work)
+    const bool PRE = C1 <= 32;  // (workgroup-uniform)
+    float4 pre[4];
+    auto fetch = [&](int tile_) {
+        const long q0 = (long)tile_ * SAT_TP;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = threadIdx.x + j * 256;
+            const int k = i / (SAT_TP / 4), c4 = i - k * (SAT_TP / 4);
+            const long p = q0 + c4 * 4;
+            pre[j] = (k < C1 && tile_ < ntiles && p < P) ? *reinterpret_cast<const float4 *>(a.y1 + ((size_t)b * C1 + k) * P + p)
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (PRE) fetch(blockIdx.x * SAT_TILES);
+
     for (int tt = 0; tt < SAT_TILES; ++tt) {
         const int tile = blockIdx.x * SAT_TILES + tt;
         if (tile >= ntiles) break;  // workgroup-uniform
         const long p0 = (long)tile * SAT_TP;
         __syncthreads();  // previous tile consumed (and ws / bn1 written, first time round)
         // ---- stage x1 = relu(bn1(y1)): 16-byte loads along the positions --------------------------------------
-        // (a register prefetch of the next tile was tried: its 16-32 VGPRs cost more occupancy than the overlap
-        // returns; several workgroups per CU hide the load latency instead)
-        for (int i = threadIdx.x; i < C1 * (SAT_TP / 4); i += 256) {
-            const int k = i / (SAT_TP / 4), c4 = i - k * (SAT_TP / 4);
-            const long p = p0 + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < P) {  // P is a multiple of 32: the four elements are in range together
-                v = *reinterpret_cast<const float4 *>(a.y1 + ((size_t)b * C1 + k) * P + p);
-                const float mu = bn1[k], is = bn1[C1 + k], g = bn1[2 * C1 + k], bt = bn1[3 * C1 + k];
-                v.x = fmaxf(sat_bn(v.x, mu, is, g, bt), 0.f); v.y = fmaxf(sat_bn(v.y, mu, is, g, bt), 0.f);
-                v.z = fmaxf(sat_bn(v.z, mu, is, g, bt), 0.f); v.w = fmaxf(sat_bn(v.w, mu, is, g, bt), 0.f);
+        if (PRE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = threadIdx.x + j * 256;
+                const int k = i / (SAT_TP / 4), c4 = i - k * (SAT_TP / 4);
+                if (k < C1) {
+                    float4 v = pre[j];
+                    if (p0 + c4 * 4 < P) {  // P is a multiple of 32: the four elements are in range together
+                        const float mu = bn1[k], is = bn1[C1 + k], g = bn1[2 * C1 + k], bt = bn1[3 * C1 + k];
+                        v.x = fmaxf(sat_bn(v.x, mu, is, g, bt), 0.f); v.y = fmaxf(sat_bn(v.y, mu, is, g, bt), 0.f);
+                        v.z = fmaxf(sat_bn(v.z, mu, is, g, bt), 0.f); v.w = fmaxf(sat_bn(v.w, mu, is, g, bt), 0.f);
+                    }
+                    float *d = xs + k * SAT_XS + c4 * 4;
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                }
             }
-            float *d = xs + k * SAT_XS + c4 * 4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            if (tt + 1 < SAT_TILES) fetch(tile + 1);  // in flight during the products below
+        } else {
+            for (int i = threadIdx.x; i < C1 * (SAT_TP / 4); i += 256) {
+                const int k = i / (SAT_TP / 4), c4 = i - k * (SAT_TP / 4);
+                const long p = p0 + c4 * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p < P) {  // P is a multiple of 32: the four elements are in range together
+                    v = *reinterpret_cast<const float4 *>(a.y1 + ((size_t)b * C1 + k) * P + p);
+                    const float mu = bn1[k], is = bn1[C1 + k], g = bn1[2 * C1 + k], bt = bn1[3 * C1 + k];
+                    v.x = fmaxf(sat_bn(v.x, mu, is, g, bt), 0.f); v.y = fmaxf(sat_bn(v.y, mu, is, g, bt), 0.f);
+                    v.z = fmaxf(sat_bn(v.z, mu, is, g, bt), 0.f); v.w = fmaxf(sat_bn(v.w, mu, is, g, bt), 0.f);
+                }
+                float *d = xs + k * SAT_XS + c4 * 4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
         }
         __syncthreads();
         // ---- z[position][channel] = x1^T . W2^T: A[i = position][k] = x1, B[k][j = channel] = W2[channel][k] ---------
