@@ -32,7 +32,8 @@ GEOMETRY_OPS = ("furthest_point_sampling", "ball_query", "three_nn", "knnquery",
 OPERATOR_KERNELS = {
     "contrast_backward": ("contrast_backward_kernel", "contrast_backward_mutual_kernel", "contrast_record_kernel"),
     "contrast_backward_csr": ("contrast_backward_rows_kernel", "contrast_coef_kernel"),
-    "contrast_forward": ("contrast_forward_rows_kernel", "contrast_forward_kernel", "row_norm_kernel", "masked_mean_kernel"),
+    "contrast_forward": ("contrast_forward_unit_kernel", "contrast_forward_kernel", "row_norm_kernel", "row_unit_kernel",
+                         "row_unit_cm_kernel", "masked_mean_kernel"),
     "pointwise_conv_forward": ("pw_gemm_kernel", "gm_gemm_kernel", "gb_gemm_kernel", "gm_split_reduce"),
     "pointwise_conv_backward": ("pw_gemm_kernel", "pw_wgrad_kernel", "gw_wgrad_kernel", "gm_gemm_kernel", "gcc_reduce", "gb_gemm_kernel"),
     "sa_tail_forward": ("sat_kernel", "sat_finalize"), "sa_tail_backward": ("sat_kernel", "sat_bwd"),

@@ -8,6 +8,7 @@ LINES_SHOWN=3 bash tools/prof_steady.sh ${TAG}S
 LINES_SHOWN=3 bash tools/prof_steady.sh ${TAG}L --variant L
 LINES_SHOWN=3 bash tools/prof_steady.sh ${TAG}XLMM --variant XL --mm --batch 2 --points 64000 --steps 24 --warmup 24
 bash tools/pmc_passes.sh ${TAG}S | tail -4
+bash tools/pmc_valu.sh ${TAG}S | head -12
 timeout -k 10 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 tail -1 gpurun_out/${TAG}_bench.json | cut -c1-200
 ( echo -n '{"config": "S-MM 8x24000", "line": '; timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 8 --lean --mm 2>/dev/null | tail -1; echo '}'
