@@ -109,7 +109,8 @@ SIGNATURES = {
     "amc3d_group_csr": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_group_moments_csr": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_grouped_conv_bn_csr_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "amc3d_grouped_conv_bn_backward_csr": (_i, [_i] * 6 + [_vp, _i] + [_vp] * 15 + [_i, _vp, _vp, _vp, _sz, _vp]),
+    "amc3d_grouped_conv_bn_backward_csr": (_i, [_i] * 6 + [_vp, _i] + [_vp] * 16 + [_i, _vp, _vp, _vp, _sz, _vp]),
+    "amc3d_group_csr_dp": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "amc3d_sa_tail_supported": (_i, [_i, _i, _i]),
     "amc3d_sa_tail_pays": (_i, [_i, _i]),
     "amc3d_sa_tail_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -129,7 +129,8 @@ __global__ __launch_bounds__(CSR_BS) void csr_collapse_kernel(int C, int n, long
                                                            const float *__restrict__ w_dp, const float *__restrict__ mean,
                                                            const float *__restrict__ invstd, const float *__restrict__ gamma,
                                                            const float *__restrict__ beta, float *__restrict__ Q,
-                                                           double *__restrict__ partial, int pts_per_group)
+                                                           double *__restrict__ partial, int pts_per_group,
+                                                           const float4 *__restrict__ rev_dp)
 {
     constexpr int GROUPS = CSR_BS / CT;  // point groups per workgroup
     __shared__ double red[GROUPS][CT][5];
@@ -152,12 +153,22 @@ __global__ __launch_bounds__(CSR_BS) void csr_collapse_kernel(int C, int n, long
         for (int j0 = s; j0 < e; j0 += 8) {  // eight edges at a time: their loads are independent, one latency for all
             int p[8];
             float e0[8], e1[8], e2[8], d[8];
+            if (rev_dp) {  // (dp, position) of the edges in list order: one 16-byte stream instead of an id + three gathers
 #pragma unroll
-            for (int u = 0; u < 8; ++u) p[u] = rev_edge[min(j0 + u, e - 1)];
+                for (int u = 0; u < 8; ++u) {
+                    const float4 ed = rev_dp[min(j0 + u, e - 1)];
+                    e0[u] = ed.x; e1[u] = ed.y; e2[u] = ed.z; p[u] = __float_as_int(ed.w);
+                }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                e0[u] = d0[p[u]]; e1[u] = d1[p[u]]; e2[u] = d2[p[u]];
-                d[u] = xrow[(long)p[u] * C];
+                for (int u = 0; u < 8; ++u) d[u] = xrow[(long)p[u] * C];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p[u] = rev_edge[min(j0 + u, e - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    e0[u] = d0[p[u]]; e1[u] = d1[p[u]]; e2[u] = d2[p[u]];
+                    d[u] = xrow[(long)p[u] * C];
+                }
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -372,6 +383,31 @@ AMC_API int amc3d_group_csr(int b, int n, int npoints, int nsample, const int *i
 
 // Loss stage: rev (m + 1 + m*k) int32 = [rev_start (m+1) | rev_edge]: rev_edge[rev_start[n] .. rev_start[n+1]) are the
 // positions i*k + j, ascending, of the SELECTED anchors i (list sel of amc3d_select_anchors) whose neighbour j is n.
+namespace amc {
+__global__ void csr_edge_dp_kernel(long P, long E, const int *__restrict__ rev_edge, const float *__restrict__ dp,
+                                   float4 *__restrict__ rev_dp)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const long b = e / P;  // every position is one edge: cloud b's lists fill [b * P, (b + 1) * P)
+    const int p = rev_edge[e];
+    const float *d = dp + (size_t)b * 3 * P;
+    rev_dp[e] = make_float4(d[p], d[P + p], d[2 * P + p], __int_as_float(p));
+}
+}  // namespace amc
+
+// rev_dp (b*npoints*nsample, 4) fp32: for every edge of the reverse lists of amc3d_group_csr, in list order, the relative
+// position dp (b,3,npoints,nsample) of its position p and p itself (its int32 bits in the fourth float) -- what the collapse
+// of amc3d_grouped_conv_bn_backward_csr then reads as ONE 16-byte stream instead of an edge id and three 4-byte gathers
+AMC_API int amc3d_group_csr_dp(int b, int npoints, int nsample, const int *rev_edge, const float *dp, float *rev_dp, void *stream)
+{
+    const long P = (long)npoints * nsample, E = (long)b * P;
+    if (E <= 0) return 0;
+    if (!rev_edge || !dp || !rev_dp || ((uintptr_t)rev_dp & 15) || E >= (1L << 31)) return bad_arg("amc3d_group_csr_dp: bad argument");
+    hipLaunchKernelGGL(csr_edge_dp_kernel, dim3(div_up(E, 256)), dim3(256), 0, (hipStream_t)stream, P, E, rev_edge, dp, (float4 *)rev_dp);
+    return launch_status("amc3d_group_csr_dp");
+}
+
 AMC_API size_t amc3d_contrast_csr_workspace_bytes(int m)
 {
     if (m <= 0) return 0;
@@ -486,9 +522,9 @@ size_t csr_partials(int b, int cout, int n)
 // finalize / apply kernels of lagg.hip (amc3d_grouped_conv_bn_backward does all of it when given rev lists)
 namespace amc {
 int csr_collapse(int b, int cout, int n, int npoints, int nsample, int relu, const float *dx1_pm, const float *g_pm,
-                 const int *rev_start, const int *rev_edge, const float *dp, const float *w_dp, const float *mean,
-                 const float *invstd, const float *gamma, const float *beta, float *Q, double *partial, int *nparts,
-                 hipStream_t stream)
+                 const int *rev_start, const int *rev_edge, const float *rev_dp, const float *dp, const float *w_dp,
+                 const float *mean, const float *invstd, const float *gamma, const float *beta, float *Q, double *partial,
+                 int *nparts, hipStream_t stream)
 {
     const long P = (long)npoints * nsample, G = (long)b * n;
     const int ct = cout < 64 ? cout : 64;
@@ -498,7 +534,7 @@ int csr_collapse(int b, int cout, int n, int npoints, int nsample, int relu, con
     *nparts = wgs;
 #define AMC_CSR(CTV)                                                                                                          \
     hipLaunchKernelGGL(csr_collapse_kernel<CTV>, dim3(wgs, cout / ct), dim3(CSR_BS), 0, stream, cout, n, P, G, relu, dx1_pm, g_pm, \
-                       rev_start, rev_edge, dp, w_dp, mean, invstd, gamma, beta, Q, partial, per)
+                       rev_start, rev_edge, dp, w_dp, mean, invstd, gamma, beta, Q, partial, per, (const float4 *)rev_dp)
     switch (ct) { case 8: AMC_CSR(8); break; case 16: AMC_CSR(16); break; case 32: AMC_CSR(32); break; default: AMC_CSR(64); }
 #undef AMC_CSR
     return launch_status("csr_collapse");

@@ -921,9 +921,9 @@ AMC_API int amc3d_grouped_conv_bn_backward(int b, int cout, int n, int npoints, 
 // (csrc/csr.hip): deterministic, and ~2.5x faster than the atomic scatter.  workspace: amc3d_grouped_conv_bn_csr_workspace_bytes
 namespace amc {
 int csr_collapse(int b, int cout, int n, int npoints, int nsample, int relu, const float *dx1_pm, const float *g_pm,
-                 const int *rev_start, const int *rev_edge, const float *dp, const float *w_dp, const float *mean,
-                 const float *invstd, const float *gamma, const float *beta, float *Q, double *partial, int *nparts,
-                 hipStream_t stream);
+                 const int *rev_start, const int *rev_edge, const float *rev_dp, const float *dp, const float *w_dp,
+                 const float *mean, const float *invstd, const float *gamma, const float *beta, float *Q, double *partial,
+                 int *nparts, hipStream_t stream);
 size_t csr_partials(int b, int cout, int n);
 }
 
@@ -937,7 +937,8 @@ AMC_API size_t amc3d_grouped_conv_bn_csr_workspace_bytes(int b, int cout, int n,
 }
 
 AMC_API int amc3d_grouped_conv_bn_backward_csr(int b, int cout, int n, int npoints, int nsample, int relu, const float *dx1,
-                                               int dx1_position_major, const float *g_pm, const int *rev_start, const int *rev_edge, const float *dp,
+                                               int dx1_position_major, const float *g_pm, const int *rev_start, const int *rev_edge,
+                                               const float *rev_dp, const float *dp,
                                                const float *w_dp, const void *moments, const double *gd, const float *mean,
                                                const float *invstd, const float *gamma, const float *beta, float *dg_cm,
                                                float *dw_dp, float *dgamma, float *dbeta, int phase, double *dsums,
@@ -966,7 +967,8 @@ AMC_API int amc3d_grouped_conv_bn_backward_csr(int b, int cout, int n, int npoin
             if ((uintptr_t)dx1 & 15) return bad_arg("amc3d_grouped_conv_bn_backward_csr: position-major dx1 must be 16-byte aligned");
             dx1_pm = const_cast<float *>(dx1);  // read only
         } else if (int st = amc3d_transpose_cn(b, cout, (int)P, dx1, dx1_pm, stream_)) return st;
-        if (int st = csr_collapse(b, cout, n, npoints, nsample, relu, dx1_pm, g_pm, rev_start, rev_edge, dp, w_dp, mean, invstd,
+        if (rev_dp && ((uintptr_t)rev_dp & 15)) return bad_arg("amc3d_grouped_conv_bn_backward_csr: rev_dp must be 16-byte aligned");
+        if (int st = csr_collapse(b, cout, n, npoints, nsample, relu, dx1_pm, g_pm, rev_start, rev_edge, rev_dp, dp, w_dp, mean, invstd,
                                   gamma, beta, Q, partial, &nparts, stream))
             return st;
     }

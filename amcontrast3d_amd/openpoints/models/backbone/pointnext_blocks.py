@@ -37,7 +37,7 @@ def _moments(convs, feature_type, idx, dp, n_support, csr=None):
     return ops.group_moments(idx, dp, n_support)
 
 
-def _csr(convs, feature_type, idx, n_support):
+def _csr(convs, feature_type, idx, n_support, dp=None):
     """reverse adjacency of the query for layers whose backward sums dense per-position gradients into the source points
     (the multi-layer SetAbstraction MLP of PointNeXt-S): gathers over sorted edge lists instead of float atomics"""
     import os
@@ -45,7 +45,10 @@ def _csr(convs, feature_type, idx, n_support):
         return None
     from amcontrast3d_amd import ops
     start, edge = ops.group_csr(idx, n_support)
-    return {'start': start, 'edge': edge}
+    csr = {'start': start, 'edge': edge}
+    if dp is not None and dp.dtype == torch.float32 and not os.environ.get("AMC3D_NO_CSR_DP"):
+        csr['edge_dp'] = ops.group_csr_dp(idx, dp, edge)  # (dp, position) per edge in list order: one stream for the backward's gather
+    return csr
 
 
 def get_reduction_fn(reduction):
@@ -167,7 +170,7 @@ class SetAbstraction(nn.Module):
         if not self.is_head and hasattr(self.grouper, 'query'):
             g['idx'] = self.grouper.query(g['new_p'], p)
             g['dp'] = self.grouper.relative_positions(g['idx'], g['new_p'], p)
-            g['csr'] = _csr(self.convs, self.feature_type, g['idx'], p.shape[1])
+            g['csr'] = _csr(self.convs, self.feature_type, g['idx'], p.shape[1], g['dp'])
             g['mom'] = _moments(self.convs, self.feature_type, g['idx'], g['dp'], p.shape[1], g['csr'])
         return g
 

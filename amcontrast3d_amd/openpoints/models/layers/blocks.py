@@ -378,7 +378,7 @@ def fused_first_block(blocks, f, geom, feature_type):
         return None
     csr = geom.get('csr')
     if csr is not None:
-        csr = (csr['start'], csr['edge'])
+        csr = (csr['start'], csr['edge'], csr.get('edge_dp'))
     return ops.GroupedConvBN.apply(f, geom['dp'], idx, geom['mom'], conv.weight, bn.weight, bn.bias, bn.eps, True, bn, csr,
                                    group)
 

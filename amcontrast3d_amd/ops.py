@@ -1174,6 +1174,22 @@ def group_csr(idx, n_support):
 
 
 @torch.no_grad()
+@torch.no_grad()
+def group_csr_dp(idx, dp, rev_edge):
+    """(dp, position) of every edge of group_csr's lists in list order, (B*M*K, 4) fp32 (the position as int32 bits in the
+    fourth float): the stream the gathering backward of GroupedConvBN reads instead of an edge id + three scattered floats"""
+    _need_gpu(idx, dp, rev_edge)
+    _need_dtype(torch.float32, dp=dp)
+    _need_dtype(torch.int32, rev_edge=rev_edge)
+    B, M, K = idx.shape
+    dp = dp.contiguous()
+    assert dp.numel() == B * 3 * M * K and rev_edge.numel() == B * M * K and rev_edge.is_contiguous()
+    out = torch.empty(B * M * K, 4, dtype=torch.float32, device=idx.device)
+    with torch.cuda.device(idx.device):
+        _lib.check(_lib.load().amc3d_group_csr_dp(B, M, K, _ptr(rev_edge), _ptr(dp), _ptr(out), _stream(idx)), "group_csr_dp")
+    return out
+
+
 def group_moments_csr(idx, dp, n_support, csr):
     """group_moments from the reverse lists: exact in-degree, dp sums in list order, no scattered atomics"""
     _need_gpu(idx, dp)
@@ -1323,7 +1339,7 @@ class GroupedConvBN(Function):
         assert weight.numel() == C * (Cin + 3)
         dev = f.device
         lib = _lib.load()
-        ctx.csr = csr  # (rev_start, rev_edge) of ops.group_csr, or None: backward then scatters with float atomics
+        ctx.csr = csr  # (rev_start, rev_edge[, group_csr_dp's stream]) of ops.group_csr, or None: backward then scatters with float atomics
         w2 = weight.reshape(C, Cin + 3)
         w_dp, w_f = _split_columns(w2, 3)
         g_cm = torch.empty(B, C, N, dtype=torch.float32, device=dev)
@@ -1392,7 +1408,8 @@ class GroupedConvBN(Function):
         def call(phase):
             if csr is not None:
                 _lib.check(lib.amc3d_grouped_conv_bn_backward_csr(
-                    B, C, N, M, K, int(ctx.relu), _ptr(dx1), int(dx1_pm), _ptr(g_pm), _ptr(csr[0]), _ptr(csr[1]), _ptr(dp), _ptr(w_dp),
+                    B, C, N, M, K, int(ctx.relu), _ptr(dx1), int(dx1_pm), _ptr(g_pm), _ptr(csr[0]), _ptr(csr[1]),
+                    _ptr(csr[2]) if len(csr) > 2 and csr[2] is not None else None, _ptr(dp), _ptr(w_dp),
                     _ptr(moments), _ptr(gd), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(dg_cm), _ptr(dw_dp),
                     _ptr(dgamma), _ptr(dbeta), phase, _ptr(dsums), count, _ptr(work), wb, _stream(f)),
                     "grouped_conv_bn_backward_csr")

@@ -427,6 +427,11 @@ int amc3d_grouped_conv_bn_backward(int b, int cout, int n, int npoints, int nsam
 size_t amc3d_group_csr_workspace_bytes(int b, int npoints, int nsample);
 int amc3d_group_csr(int b, int n, int npoints, int nsample, const int *idx, int *rev_start, int *rev_edge, void *workspace,
                     size_t workspace_bytes, void *stream);
+/* rev_dp (b*npoints*nsample, 4) fp32, 16-byte aligned: per edge of the lists, in list order, the relative position
+ * dp[b, :, p] of its position p and p itself (its int32 bits in the fourth float): what the gather of
+ * amc3d_grouped_conv_bn_backward_csr reads as one 16-byte stream instead of an edge id and three scattered floats.
+ * Coordinates only: part of the plan. */
+int amc3d_group_csr_dp(int b, int npoints, int nsample, const int *rev_edge, const float *dp, float *rev_dp, void *stream);
 /* the moments buffer of amc3d_group_moments from the lists (no scattered atomics) */
 int amc3d_group_moments_csr(int b, int n, int npoints, int nsample, const int *rev_start, const int *rev_edge,
                             const float *dp, void *moments, size_t moments_bytes, void *stream);
@@ -435,8 +440,8 @@ int amc3d_group_moments_csr(int b, int n, int npoints, int nsample, const int *r
  * writes it that way) and is read in place. */
 size_t amc3d_grouped_conv_bn_csr_workspace_bytes(int b, int cout, int n, int npoints, int nsample);
 int amc3d_grouped_conv_bn_backward_csr(int b, int cout, int n, int npoints, int nsample, int relu, const float *dx1,
-                                       int dx1_position_major, const float *g_pm, const int *rev_start, const int *rev_edge, const float *dp,
-                                       const float *w_dp, const void *moments, const double *gd, const float *mean,
+                                       int dx1_position_major, const float *g_pm, const int *rev_start, const int *rev_edge,
+                                       const float *rev_dp /* amc3d_group_csr_dp, or NULL */, const float *dp, const float *w_dp, const void *moments, const double *gd, const float *mean,
                                        const float *invstd, const float *gamma, const float *beta, float *dg_cm, float *dw_dp,
                                        float *dgamma, float *dbeta, int phase, double *dsums, const double *count,
                                        void *workspace, size_t workspace_bytes, void *stream);

@@ -193,6 +193,18 @@ def test_reverse_lists_moments_and_gather_backward():
     x1 = ops.GroupedConvBN.apply(fr, dp, idx, ops.group_moments(idx, dp, N), wr, gr, br, 1e-5, True, None, (start, edge))
     x1.backward(go)
     assert all(torch.equal(a, t.grad) for a, t in zip(grads[1], (fr, wr, gr, br)))
+    # with the (dp, position) stream of the edges in list order (ops.group_csr_dp: what the plan adds since round 3) the
+    # gather reads one 16-byte record per edge instead of an id and three scattered floats: the same bits
+    edge_dp = ops.group_csr_dp(idx, dp, edge)
+    ed = edge_dp.cpu().numpy()
+    assert np.array_equal(ed[:, 3].copy().view(np.int32), e)
+    dpn = dp.reshape(B, 3, P).cpu().numpy()
+    for g in (0, 5, P + 9, B * P - 1):
+        assert np.array_equal(ed[g, :3], dpn[g // P][:, e[g]])
+    fr, wr, gr, br = (t.clone().requires_grad_(True) for t in (f, w, gamma, beta))
+    x1 = ops.GroupedConvBN.apply(fr, dp, idx, ops.group_moments(idx, dp, N), wr, gr, br, 1e-5, True, None, (start, edge, edge_dp))
+    x1.backward(go)
+    assert all(torch.equal(a, t.grad) for a, t in zip(grads[1], (fr, wr, gr, br)))
     # ... and reads a gradient that arrives as position-major rows (the layout SATailActivated writes) in place
     fr, wr, gr, br = (t.clone().requires_grad_(True) for t in (f, w, gamma, beta))
     x1 = ops.GroupedConvBN.apply(fr, dp, idx, ops.group_moments(idx, dp, N), wr, gr, br, 1e-5, True, None, (start, edge))
