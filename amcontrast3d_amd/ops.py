@@ -1737,13 +1737,23 @@ class LibraryGemmConv(Function):
         Cout = weight.shape[0]
         w2 = weight.reshape(Cout, Cin)
         timing.note("library_gemm_conv")
+        import os
+        # under bf16 autocast (use_amp, main_AA.py:389): bf16 operands for the three library GEMMs, fp32 accumulation inside the
+        # library, fp32 tensors outside -- cfg 5 (XL + ++, 1 x 120000): 20.7 -> 19.7 ms per step (fp32: 20.2); AMC3D_LIB_FP32=1 keeps fp32
+        ctx.bf16 = bool(torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+                        and not os.environ.get("AMC3D_LIB_FP32"))
         # bmm with the weight expanded along the batch (stride 0): torch.matmul(2-d, 3-d) would fold the batch into one
-        # GEMM by way of a transposed copy of x.  (Under autocast this fp32 route is chosen for layers where bf16 does
-        # not pay: keep the library GEMM in fp32, tensors stay fp32.)
+        # GEMM by way of a transposed copy of x.
         with torch.autocast("cuda", enabled=False):
-            y = torch.bmm(w2.unsqueeze(0).expand(B, Cout, Cin), x.view(B, Cin, -1))
-        ctx.save_for_backward(x, w2)
+            if ctx.bf16:  # bf16 operands (fp32 accumulation inside the library), fp32 tensors outside
+                x16, w16 = x.view(B, Cin, -1).to(torch.bfloat16), w2.to(torch.bfloat16)
+                y = torch.bmm(w16.unsqueeze(0).expand(B, Cout, Cin), x16).float()
+                ctx.save_for_backward(x16, w16)
+            else:
+                y = torch.bmm(w2.unsqueeze(0).expand(B, Cout, Cin), x.view(B, Cin, -1))
+                ctx.save_for_backward(x, w2)
         ctx.wshape = tuple(weight.shape)
+        ctx.xshape = tuple(x.shape)
         return y.view((B, Cout) + tuple(x.shape[2:]))
 
     @staticmethod
@@ -1751,6 +1761,13 @@ class LibraryGemmConv(Function):
         x, w2 = ctx.saved_tensors
         B, Cin = x.shape[0], x.shape[1]
         dy3 = dy.contiguous().view(B, w2.shape[0], -1)
+        if ctx.bf16:
+            with torch.autocast("cuda", enabled=False):
+                dy16 = dy3.to(torch.bfloat16)
+                dx = (torch.bmm(w2.t().unsqueeze(0).expand(B, Cin, w2.shape[0]), dy16).float().view(ctx.xshape)
+                      if ctx.needs_input_grad[0] else None)
+                dw = (torch.bmm(dy16, x.transpose(1, 2)).float().sum(0).view(ctx.wshape) if ctx.needs_input_grad[1] else None)
+            return dx, dw
         with torch.autocast("cuda", enabled=False):
             dx = (torch.bmm(w2.t().unsqueeze(0).expand(B, Cin, w2.shape[0]), dy3).view(x.shape)
                   if ctx.needs_input_grad[0] else None)
