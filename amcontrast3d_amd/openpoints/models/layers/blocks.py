@@ -176,7 +176,7 @@ def conv1x1_weight(x, w):
     cin, cout = w.shape[1], w.shape[0]
     positions = x.numel() // x.shape[1]
     w3 = w.reshape(cout, cin, 1)
-    if ops.mixed_precision() and min(cin, cout) >= 64 and positions >= 4096:
+    if ops.mixed_precision() and min(cin, cout) >= 64 and positions >= _BF16_MIN_POSITIONS:
         return ops.pointwise_conv(x, w3, None, True)
     if (min(cin, cout) >= 64 and positions < 65536 and cin % 4 == 0 and torch.is_grad_enabled()
             and not os.environ.get("AMC3D_NO_LIBRARY_GEMM")):
@@ -214,11 +214,16 @@ def feature_propagation_first_block(blk, f1, f2, geom):
     return blk[2](bn(y))
 
 
+# (round 3, cfg 5 = XL + ++ at 1 x 120000: threshold 4096 -> 19.8 ms per step, 16384 -> 19.1, 65536 -> 19.4, never -> 19.3; the
+# shorter deep layers take the library GEMMs, which run on bf16 operands under autocast: ops.LibraryGemmConv)
+_BF16_MIN_POSITIONS = int(os.environ.get("AMC3D_BF16_MIN_POSITIONS", 16384))
+
+
 def _bf16_pays(conv, x):
-    """Under autocast the 1x1 convs with >= 64 channels on both sides over >= 4096 positions run on the bf16 MFMA
+    """Under autocast the 1x1 convs with >= 64 channels on both sides over >= 16384 positions run on the bf16 MFMA
     (scratch/gemm_bench.py: 1.2-2x the fp32 kernels there).  Narrower layers are HBM-bound and shorter ones fill a fraction
     of the chip with 128 x 128 tiles: both keep their fp32 route, which is at least as accurate as what autocast asks for."""
-    return min(conv.in_channels, conv.out_channels) >= 64 and x.numel() // x.shape[1] >= 4096
+    return min(conv.in_channels, conv.out_channels) >= 64 and x.numel() // x.shape[1] >= _BF16_MIN_POSITIONS
 
 
 def _pw_pays(conv, x):
