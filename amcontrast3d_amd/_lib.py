@@ -114,8 +114,8 @@ SIGNATURES = {
     "amc3d_sa_tail_supported": (_i, [_i, _i, _i]),
     "amc3d_sa_tail_pays": (_i, [_i, _i]),
     "amc3d_sa_tail_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "amc3d_sa_tail_forward": (_i, [_i, _i, _i, _i, _i] + [_vp] * 8 + [_f, _f, _i] + [_vp] * 8 + [_sz, _vp]),
-    "amc3d_sa_tail_backward": (_i, [_i, _i, _i, _i, _i] + [_vp] * 10 + [_i, _vp, _vp, _i] + [_vp] * 5 + [_sz, _vp]),
+    "amc3d_sa_tail_forward": (_i, [_i, _i, _i, _i, _i] + [_vp] * 8 + [_f, _f, _i] + [_vp] * 10 + [_sz, _vp]),
+    "amc3d_sa_tail_backward": (_i, [_i, _i, _i, _i, _i] + [_vp] * 10 + [_i, _vp, _vp, _vp, _vp, _i] + [_vp] * 5 + [_sz, _vp]),
     "amc3d_bn_workspace_bytes": (_sz, [_i]),
     "amc3d_bn_stats": (_i, [_i, _i, _l, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_bn_forward": (_i, [_i, _i, _l, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -1861,6 +1861,9 @@ class SATail(Function):
         mean2 = torch.empty(C2, dtype=torch.float32, device=dev)
         invstd2, var2 = torch.empty_like(mean2), torch.empty_like(mean2)
         pooled = torch.empty(B, C2, M, dtype=torch.float32, device=dev)
+        # the raw extreme the pool selected and the neighbour that held it: the backward then recomputes nothing (csrc/sa_tail.hip)
+        zext = torch.empty(B, C2, M, dtype=torch.float32, device=dev)
+        arg = torch.empty(B, C2, M, dtype=torch.uint8, device=dev)
         work1, wb1 = _bn_ws(C1, dev)
         wb = int(lib.amc3d_sa_tail_workspace_bytes(B, C1, C2, M))
         work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
@@ -1872,19 +1875,19 @@ class SATail(Function):
             _lib.check(lib.amc3d_sa_tail_forward(B, C1, C2, M, K, _ptr(y1), _ptr(mean1), _ptr(invstd1), _ptr(g1), _ptr(b1),
                                                  _ptr(w2f), _ptr(g2), _ptr(b2), float(eps2), mom2, int(bool(relu2)),
                                                  _ptr(pooled), _ptr(mean2), _ptr(invstd2), _ptr(var2), rm2, rv2,
-                                                 nbt2, _ptr(work), wb, _stream(y1)), "sa_tail_forward")
+                                                 nbt2, _ptr(zext), _ptr(arg), _ptr(work), wb, _stream(y1)), "sa_tail_forward")
         if bn1 is not None and bn1.track_running_stats and bn1.running_mean is not None:
             bn_update_running(bn1, mean1, var1)
         if bn2 is not None and bn2.track_running_stats and bn2.running_mean is not None and bn2.momentum is None:
             bn_update_running(bn2, mean2, var2)  # cumulative average: its own launch
-        ctx.save_for_backward(y1, g1, b1, w2f, g2, b2, mean1, invstd1, mean2, invstd2)
+        ctx.save_for_backward(y1, g1, b1, w2f, g2, b2, mean1, invstd1, mean2, invstd2, zext, arg)
         ctx.relu2, ctx.wshape = bool(relu2), tuple(w2.shape)
         ctx.pool_seq = _next_pool_seq() if _pool_log is not None else None
         return pooled
 
     @staticmethod
     def backward(ctx, dpooled):
-        y1, g1, b1, w2f, g2, b2, mean1, invstd1, mean2, invstd2 = ctx.saved_tensors
+        y1, g1, b1, w2f, g2, b2, mean1, invstd1, mean2, invstd2, zext, arg_ext = ctx.saved_tensors
         B, C1, M, K = y1.shape
         C2 = w2f.shape[0]
         dev = y1.device
@@ -1905,7 +1908,7 @@ class SATail(Function):
         with torch.cuda.device(dev), timing.span("sa_tail_backward", y1.numel() * 4 * 2 + dpooled.numel() * 10, flops, moved=y1.numel() * 4 * 6 + dpooled.numel() * 10):
             _lib.check(lib.amc3d_sa_tail_backward(B, C1, C2, M, K, _ptr(y1), _ptr(mean1), _ptr(invstd1), _ptr(g1), _ptr(b1),
                                                   _ptr(w2f), _ptr(mean2), _ptr(invstd2), _ptr(g2), _ptr(b2), int(ctx.relu2),
-                                                  _ptr(dpooled), _ptr(dx1), 0, _ptr(dw2), _ptr(dg2), _ptr(db2),
+                                                  _ptr(dpooled), _ptr(zext), _ptr(arg_ext), _ptr(dx1), 0, _ptr(dw2), _ptr(dg2), _ptr(db2),
                                                   _ptr(arg) if arg is not None else None,
                                                   _ptr(work), wb, _stream(y1)), "sa_tail_backward")
             # BN1 + ReLU backward on the raw y1 (csrc/bn.hip)
@@ -1939,24 +1942,26 @@ class SATailActivated(Function):
         mean2 = torch.empty(C2, dtype=torch.float32, device=dev)
         invstd2, var2 = torch.empty_like(mean2), torch.empty_like(mean2)
         pooled = torch.empty(B, C2, M, dtype=torch.float32, device=dev)
+        zext = torch.empty(B, C2, M, dtype=torch.float32, device=dev)
+        arg = torch.empty(B, C2, M, dtype=torch.uint8, device=dev)
         wb = int(lib.amc3d_sa_tail_workspace_bytes(B, C1, C2, M))
         work = torch.empty(max(wb, 8), dtype=torch.uint8, device=dev)
         mom2, rm2, rv2, nbt2 = _bn_running_args(bn2)
-        with torch.cuda.device(dev), timing.span("sa_tail_forward", x1.numel() * 4 + pooled.numel() * 5, 2.0 * B * M * K * C1 * C2):
+        with torch.cuda.device(dev), timing.span("sa_tail_forward", x1.numel() * 4 + pooled.numel() * 10, 2.0 * B * M * K * C1 * C2):
             _lib.check(lib.amc3d_sa_tail_forward(B, C1, C2, M, K, _ptr(x1), _ptr(zeros), _ptr(ones), _ptr(ones), _ptr(zeros),
                                                  _ptr(w2f), _ptr(g2), _ptr(b2), float(eps2), mom2, int(bool(relu2)),
                                                  _ptr(pooled), _ptr(mean2), _ptr(invstd2), _ptr(var2), rm2, rv2,
-                                                 nbt2, _ptr(work), wb, _stream(x1)), "sa_tail_forward")
+                                                 nbt2, _ptr(zext), _ptr(arg), _ptr(work), wb, _stream(x1)), "sa_tail_forward")
         if bn2 is not None and bn2.track_running_stats and bn2.running_mean is not None and bn2.momentum is None:
             bn_update_running(bn2, mean2, var2)
-        ctx.save_for_backward(x1, w2f, g2, b2, mean2, invstd2, zeros, ones)
+        ctx.save_for_backward(x1, w2f, g2, b2, mean2, invstd2, zeros, ones, zext, arg)
         ctx.relu2, ctx.wshape = bool(relu2), tuple(w2.shape)
         ctx.pool_seq = _next_pool_seq() if _pool_log is not None else None
         return pooled
 
     @staticmethod
     def backward(ctx, dpooled):
-        x1, w2f, g2, b2, mean2, invstd2, zeros, ones = ctx.saved_tensors
+        x1, w2f, g2, b2, mean2, invstd2, zeros, ones, zext, arg_ext = ctx.saved_tensors
         B, C1, M, K = x1.shape
         C2 = w2f.shape[0]
         dev = x1.device
@@ -1982,7 +1987,7 @@ class SATailActivated(Function):
                                                  2.0 * B * M * K * C1 * C2 * 4, moved=x1.numel() * 4 * 3 + dpooled.numel() * 10):
             _lib.check(lib.amc3d_sa_tail_backward(B, C1, C2, M, K, _ptr(x1), _ptr(zeros), _ptr(ones), _ptr(ones), _ptr(zeros),
                                                   _ptr(w2f), _ptr(mean2), _ptr(invstd2), _ptr(g2), _ptr(b2), int(ctx.relu2),
-                                                  _ptr(dpooled), _ptr(dx1_buf), int(pm), _ptr(dw2), _ptr(dg2), _ptr(db2),
+                                                  _ptr(dpooled), _ptr(zext), _ptr(arg_ext), _ptr(dx1_buf), int(pm), _ptr(dw2), _ptr(dg2), _ptr(db2),
                                                   _ptr(arg) if arg is not None else None,
                                                   _ptr(work), wb, _stream(x1)), "sa_tail_backward")
         return dx1, dw2.view(ctx.wshape), dg2, db2, None, None, None

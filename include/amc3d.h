@@ -464,7 +464,13 @@ int amc3d_sa_tail_forward(int B, int C1, int C2, int M, int K, const float *y1, 
                           const float *gamma2, const float *beta2, float eps2, float momentum2, int relu2,
                           float *pooled, float *mean2, float *invstd2, float *var_unbiased2,
                           float *running_mean2, float *running_var2, long long *num_batches_tracked2,
-                          void *workspace, size_t workspace_bytes, void *stream);
+                          float *zext_out, unsigned char *arg_out, void *workspace, size_t workspace_bytes, void *stream);
+/* zext_out (B,C2,M) fp32 and arg_out (B,C2,M) bytes -- both or neither: per (b, c2, centroid) the raw extreme of conv2's output
+ * over the 32 neighbours that BN2 + max-pool select (the maximum for gamma2 >= 0, the minimum otherwise) and the first
+ * neighbour attaining it (torch.max's rule on the raw values).  Handed to amc3d_sa_tail_backward they replace its two
+ * recomputation passes by the algebraic form: q is sparse (one neighbour per pooled element) and BatchNorm's backward adds
+ * terms affine in z = W2 x1, so  dx1 = W2^T Dq q - (W2^T E W2) x1 - c  and  dW2 = Dq q x1^T - E W2 (x1 x1^T) - t (x1 1)^T
+ * (csrc/sa_tail.hip): one pass over x1 with a C1 x C1 product and the Gram matrix on the MFMA and C2 rank-1 terms per centroid. */
 /* dx1 (B,C1,M,32) = gradient w.r.t. relu(bn1(y1)) -- written as (B,M,32,C1) rows when dx1_position_major
  * (C1 % 4 == 0), the layout amc3d_grouped_conv_bn_backward_csr gathers from; dw2 (C2,C1) deterministic; dgamma2, dbeta2 (C2);
  * arg_out (B,C2,M) bytes or NULL: the neighbour each pooled gradient was routed to (what torch.max returns as
@@ -472,8 +478,9 @@ int amc3d_sa_tail_forward(int B, int C1, int C2, int M, int K, const float *y1, 
 int amc3d_sa_tail_backward(int B, int C1, int C2, int M, int K, const float *y1, const float *mean1,
                            const float *invstd1, const float *gamma1, const float *beta1, const float *w2,
                            const float *mean2, const float *invstd2, const float *gamma2, const float *beta2,
-                           int relu2, const float *dpooled, float *dx1, int dx1_position_major, float *dw2,
-                           float *dgamma2, float *dbeta2, unsigned char *arg_out, void *workspace,
+                           int relu2, const float *dpooled, const float *zext /* of the forward, or NULL */,
+                           const unsigned char *arg_ext /* of the forward, or NULL */, float *dx1, int dx1_position_major,
+                           float *dw2, float *dgamma2, float *dbeta2, unsigned char *arg_out, void *workspace,
                            size_t workspace_bytes, void *stream);
 
 /* ---- training-mode BatchNorm fused with ReLU / neighbourhood max-pool ---------------------------
