@@ -168,6 +168,26 @@ __global__ __launch_bounds__(256, (MODE == 0 && NCT <= 2) ? 3 : 1) void sat_kern
         sat_f32x16 acc[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) acc[ct] = sat_f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if ((C1 & 7) == 0) {  // four steps at a time, their LDS reads (unconditional: clamped index + select) ahead of the products
+            for (int k0 = 0; k0 < C1; k0 += 8) {
+                float av[4], bv[NCT][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + 2 * u + kh;
+                    av[u] = xs[k * SAT_XS + wave * 32 + pl];
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        const int c2 = ct * 32 + pl;
+                        const float t = ws[(c2 < C2 ? c2 : 0) * WS + k];
+                        bv[ct][u] = c2 < C2 ? t : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[ct][u], acc[ct], 0, 0, 0);
+            }
+        } else
         for (int k = 0; k < C1; k += 2) {
             const float av = xs[(k + kh) * SAT_XS + wave * 32 + pl];
 #pragma unroll
@@ -525,7 +545,9 @@ struct SatAlgArgs {
 };
 
 // WR = C1 * C2 / 256: dW2 entries a lane owns (lane = (channel c2 of the wave's quarter, chunk of WR input channels))
-template <int NIT, int WR>
+// FULL: C1 == 32 * NIT and C2 % 16 == 0 -- every range guard below is then constant (a guarded LDS read is a branch of its own:
+// the eight reads ahead of eight products would not be issued together)
+template <int NIT, int WR, bool FULL>
 __global__ __launch_bounds__(256, NIT == 1 ? SAT_ALG_WGS : 1) void sat_bwd_alg_kernel(SatAlgArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float sat_smem[];
@@ -572,7 +594,7 @@ __global__ __launch_bounds__(256, NIT == 1 ? SAT_ALG_WGS : 1) void sat_bwd_alg_k
             const int i = threadIdx.x + j * 256;
             const int k = i / (SAT_TP / 4), c4 = i - k * (SAT_TP / 4);
             const long p = q0 + c4 * 4;
-            pre[j] = (k < C1 && tile_ < ntiles && p < P) ? *reinterpret_cast<const float4 *>(a.y1 + ((size_t)b * C1 + k) * P + p)
+            pre[j] = ((FULL || k < C1) && tile_ < ntiles && p < P) ? *reinterpret_cast<const float4 *>(a.y1 + ((size_t)b * C1 + k) * P + p)
                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -600,7 +622,7 @@ __global__ __launch_bounds__(256, NIT == 1 ? SAT_ALG_WGS : 1) void sat_bwd_alg_k
         for (int j = 0; j < NIT * 4; ++j) {
             const int i = threadIdx.x + j * 256;
             const int k = i / (SAT_TP / 4), c4 = i - k * (SAT_TP / 4);
-            if (k < C1) {
+            if (FULL || k < C1) {
                 float4 v = pre[j];
                 if (p0 + c4 * 4 < P) {  // P is a multiple of 32: the four elements are in range together
                     const float mu = bn1[k], is = bn1[C1 + k], g = bn1[2 * C1 + k], bt = bn1[3 * C1 + k];
@@ -628,9 +650,15 @@ __global__ __launch_bounds__(256, NIT == 1 ? SAT_ALG_WGS : 1) void sat_bwd_alg_k
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int k = k0 + 2 * u + kh;
-                bv[u] = k < C1 ? xs[k * SAT_XS + wave * 32 + pl] : 0.f;
+                const int kc = (FULL || k < C1) ? k : 0;  // (clamped index + select: the read itself is unconditional)
+                const float xb = xs[kc * SAT_XS + wave * 32 + pl];
+                bv[u] = (FULL || k < C1) ? xb : 0.f;
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) av[it][u] = (k < C1 && it * 32 + pl < C1) ? as[k * WS + it * 32 + pl] : 0.f;
+                for (int it = 0; it < NIT; ++it) {
+                    const bool in = FULL || (k < C1 && it * 32 + pl < C1);
+                    const float t = as[kc * WS + (in ? it * 32 + pl : 0)];
+                    av[it][u] = in ? t : 0.f;
+                }
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
@@ -643,10 +671,15 @@ __global__ __launch_bounds__(256, NIT == 1 ? SAT_ALG_WGS : 1) void sat_bwd_alg_k
             for (int u = 0; u < 8; ++u) {
                 const int k = k0 + 2 * u + kh;
                 // the sparse Dq q tile is never stored: channel k of this wave's centroid has ONE entry, at its routed neighbour
-                const float2 r = va[wave * C2 + (k < C2 ? k : 0)];
-                bv[u] = (k < C2 && __float_as_int(r.y) == pl) ? r.x : 0.f;
+                const int kc = (FULL || k < C2) ? k : 0;
+                const float2 r = va[wave * C2 + kc];
+                bv[u] = ((FULL || k < C2) && __float_as_int(r.y) == pl) ? r.x : 0.f;
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) av[it][u] = (k < C2 && it * 32 + pl < C1) ? ws[k * WS + it * 32 + pl] : 0.f;
+                for (int it = 0; it < NIT; ++it) {
+                    const bool in = FULL || (k < C2 && it * 32 + pl < C1);
+                    const float t = ws[kc * WS + (in ? it * 32 + pl : 0)];
+                    av[it][u] = in ? t : 0.f;
+                }
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
@@ -658,7 +691,11 @@ __global__ __launch_bounds__(256, NIT == 1 ? SAT_ALG_WGS : 1) void sat_bwd_alg_k
             const int pp = wave * 32 + s + kh;
             float xv[NIT];
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) xv[it] = it * 32 + pl < C1 ? xs[(it * 32 + pl) * SAT_XS + pp] : 0.f;
+            for (int it = 0; it < NIT; ++it) {
+                const bool in = FULL || it * 32 + pl < C1;
+                const float t = xs[(in ? it * 32 + pl : 0) * SAT_XS + pp];
+                xv[it] = in ? t : 0.f;
+            }
 #pragma unroll
             for (int i = 0; i < NIT; ++i)
 #pragma unroll
@@ -681,7 +718,7 @@ __global__ __launch_bounds__(256, NIT == 1 ? SAT_ALG_WGS : 1) void sat_bwd_alg_k
                 float4 *row4 = reinterpret_cast<float4 *>(a.dx1 + ((size_t)b * P + p) * C1 + it * 32 + 4 * kh);
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4)
-                    if (it * 32 + 8 * q4 + 4 * kh < C1) {
+                    if (FULL || it * 32 + 8 * q4 + 4 * kh < C1) {
                         const float *cc = cv + it * 32 + 8 * q4 + 4 * kh;
                         row4[2 * q4] = make_float4(__fsub_rn(accd[it][4 * q4], cc[0]), __fsub_rn(accd[it][4 * q4 + 1], cc[1]),
                                                    __fsub_rn(accd[it][4 * q4 + 2], cc[2]), __fsub_rn(accd[it][4 * q4 + 3], cc[3]));
@@ -690,7 +727,7 @@ __global__ __launch_bounds__(256, NIT == 1 ? SAT_ALG_WGS : 1) void sat_bwd_alg_k
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = it * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    if (row < C1) a.dx1[((size_t)b * C1 + row) * P + p] = __fsub_rn(accd[it][r], cv[row]);
+                    if (FULL || row < C1) a.dx1[((size_t)b * C1 + row) * P + p] = __fsub_rn(accd[it][r], cv[row]);
                 }
             }
         }
@@ -889,15 +926,20 @@ template <int NIT>
 static int sat_alg_launch(const SatAlgArgs &a, int groups, size_t lds, hipStream_t stream)
 {
     const int wr = a.C1 * a.C2 / 256;
-#define AMC_SATA(W)                                                                                                            \
-    (void)hipFuncSetAttribute((const void *)sat_bwd_alg_kernel<NIT, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((sat_bwd_alg_kernel<NIT, W>), dim3(groups, a.B), dim3(256), lds, stream, a)
+    const bool full = a.C1 == 32 * NIT && a.C2 % 16 == 0;
+#define AMC_SATA2(W, F)                                                                                                          \
+    (void)hipFuncSetAttribute((const void *)sat_bwd_alg_kernel<NIT, W, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((sat_bwd_alg_kernel<NIT, W, F>), dim3(groups, a.B), dim3(256), lds, stream, a)
+#define AMC_SATA(W)                  \
+    if (full) { AMC_SATA2(W, true); } \
+    else { AMC_SATA2(W, false); }
     switch (wr) {
         case 1: AMC_SATA(1); break; case 2: AMC_SATA(2); break; case 4: AMC_SATA(4); break; case 8: AMC_SATA(8); break;
         case 16: AMC_SATA(16); break; case 32: AMC_SATA(32); break;
         default: return bad_arg("amc3d_sa_tail_backward: unsupported C1 * C2");
     }
 #undef AMC_SATA
+#undef AMC_SATA2
     return 0;
 }
 }  // namespace amc

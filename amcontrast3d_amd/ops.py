@@ -1740,7 +1740,7 @@ class LibraryGemmConv(Function):
         import os
         # under bf16 autocast (use_amp, main_AA.py:389): bf16 operands for the three library GEMMs, fp32 accumulation inside the
         # library, fp32 tensors outside -- cfg 5 (XL + ++, 1 x 120000): 20.7 -> 19.7 ms per step (fp32: 20.2); AMC3D_LIB_FP32=1 keeps fp32
-        ctx.bf16 = bool(torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+        ctx.bf16 = bool(torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
                         and not os.environ.get("AMC3D_LIB_FP32"))
         # bmm with the weight expanded along the batch (stride 0): torch.matmul(2-d, 3-d) would fold the batch into one
         # GEMM by way of a transposed copy of x.
