@@ -645,10 +645,11 @@ __global__ __launch_bounds__(256, NIT == 1 ? SAT_ALG_WGS : 1) void sat_bwd_alg_k
         sat_f32x16 accd[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) accd[it] = sat_f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int k0 = 0; k0 < C1; k0 += 16) {  // eight steps at a time with their LDS reads ahead of the products
-            float bv[8], av[NIT][8];
+        constexpr int UB = NIT == 1 ? 8 : 4;  // steps per batch: their LDS reads are issued ahead of the products
+        for (int k0 = 0; k0 < C1; k0 += 2 * UB) {
+            float bv[UB], av[NIT][UB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UB; ++u) {
                 const int k = k0 + 2 * u + kh;
                 const int kc = (FULL || k < C1) ? k : 0;  // (clamped index + select: the read itself is unconditional)
                 const float xb = xs[kc * SAT_XS + wave * 32 + pl];
@@ -661,14 +662,14 @@ __global__ __launch_bounds__(256, NIT == 1 ? SAT_ALG_WGS : 1) void sat_bwd_alg_k
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < UB; ++u)
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) accd[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[it][u], bv[u], accd[it], 0, 0, 0);
         }
-        for (int k0 = 0; k0 < C2; k0 += 16) {
-            float bv[8], av[NIT][8];
+        for (int k0 = 0; k0 < C2; k0 += 2 * UB) {
+            float bv[UB], av[NIT][UB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UB; ++u) {
                 const int k = k0 + 2 * u + kh;
                 // the sparse Dq q tile is never stored: channel k of this wave's centroid has ONE entry, at its routed neighbour
                 const int kc = (FULL || k < C2) ? k : 0;
@@ -682,12 +683,13 @@ __global__ __launch_bounds__(256, NIT == 1 ? SAT_ALG_WGS : 1) void sat_bwd_alg_k
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < UB; ++u)
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) accd[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[it][u], bv[u], accd[it], 0, 0, 0);
         }
         // ---- Gram matrix S[c1][c1'] += sum over this wave's 32 positions x1[c1][p] x1[c1'][p] --------------------------------
-        for (int s = 0; s < 32; s += 2) {
+#pragma unroll NIT == 1 ? 16 : 4
+        for (int s = 0; s < 32; s += 2) {  // (S is symmetric: the blocks j >= i, mirrored when the partial is written)
             const int pp = wave * 32 + s + kh;
             float xv[NIT];
 #pragma unroll
@@ -699,7 +701,7 @@ __global__ __launch_bounds__(256, NIT == 1 ? SAT_ALG_WGS : 1) void sat_bwd_alg_k
 #pragma unroll
             for (int i = 0; i < NIT; ++i)
 #pragma unroll
-                for (int j = 0; j < NIT; ++j) accS[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[i], xv[j], accS[i][j], 0, 0, 0);
+                for (int j = i; j < NIT; ++j) accS[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[i], xv[j], accS[i][j], 0, 0, 0);
         }
         // ---- dW2 (sparse part): dW2[c2][c1] += v[c2, centroid] x1[c1][its routed neighbour], four centroids of the tile ------
 #pragma unroll
@@ -747,13 +749,16 @@ __global__ __launch_bounds__(256, NIT == 1 ? SAT_ALG_WGS : 1) void sat_bwd_alg_k
 #pragma unroll
             for (int i = 0; i < NIT; ++i)
 #pragma unroll
-                for (int j = 0; j < NIT; ++j) {
+                for (int j = i; j < NIT; ++j) {
                     const int cj = j * 32 + pl;
                     if (cj < C1) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int ci = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                            if (ci < C1) red[ci * C1 + cj] += accS[i][j][r];
+                            if (ci < C1) {
+                                red[ci * C1 + cj] += accS[i][j][r];
+                                if (j > i) red[cj * C1 + ci] += accS[i][j][r];  // the mirrored block (distinct addresses per lane)
+                            }
                         }
                     }
                 }
