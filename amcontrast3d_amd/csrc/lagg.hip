@@ -237,16 +237,25 @@ __global__ __launch_bounds__(256) void lagg_pool_kernel(int C, int n, int M, int
         mu[j] = mean[c]; is[j] = invstd[c]; ga[j] = gamma[c]; be[j] = beta[c];
     }
     const long P = (long)M * K;
+    // a centroid's indices and relative positions (lane = neighbour) are fetched while the centroid before it is pooled: the
+    // gathers of a centroid wait for its indices, and a wave walks its centroids one after the other
+    int id_n = 0;
+    float n0 = 0.f, n1 = 0.f, n2 = 0.f;
+    auto fetch = [&](int m_) {
+        id_n = 0; n0 = n1 = n2 = 0.f;
+        if (lane < K && m_ < M) {
+            const size_t p = (size_t)m_ * K + lane;
+            id_n = idx[(size_t)b * P + p];
+            n0 = dp[((size_t)b * 3 + 0) * P + p]; n1 = dp[((size_t)b * 3 + 1) * P + p]; n2 = dp[((size_t)b * 3 + 2) * P + p];
+        }
+    };
+    fetch(m0 + wave * cpw);
     for (int i = 0; i < cpw; ++i) {
         const int ml = wave * cpw + i, m = m0 + ml;
         if (m >= M) break;  // wave-uniform
-        int id_l = 0;
-        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-        if (lane < K) {
-            const size_t p = (size_t)m * K + lane;
-            id_l = idx[(size_t)b * P + p];
-            d0 = dp[((size_t)b * 3 + 0) * P + p]; d1 = dp[((size_t)b * 3 + 1) * P + p]; d2 = dp[((size_t)b * 3 + 2) * P + p];
-        }
+        const int id_l = id_n;
+        const float d0 = n0, d1 = n1, d2 = n2;
+        if (i + 1 < cpw) fetch(m + 1);
         float best[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
         float by[4] = {0.f, 0.f, 0.f, 0.f};
         int bk[4] = {0, 0, 0, 0};
@@ -319,6 +328,8 @@ __global__ __launch_bounds__(256) void lagg_bwd_scatter_kernel(int C, int n, int
     float *sd = lagg_smem;                        // [ct][LAGG_MT + 1] dpooled
     float *sy = sd + ct * (LAGG_MT + 1);          // ystar
     float *sa = sy + ct * (LAGG_MT + 1);          // arg
+    int *sidx = reinterpret_cast<int *>(sa + ct * (LAGG_MT + 1));  // [LAGG_MT][K]     neighbour indices of the tile's centroids
+    float *sdp = reinterpret_cast<float *>(sidx + LAGG_MT * K);    // [3][LAGG_MT][K]  their relative positions
     const int b = blockIdx.z, c0 = blockIdx.y * LAGG_CT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long P = (long)M * K;
@@ -347,6 +358,17 @@ __global__ __launch_bounds__(256) void lagg_bwd_scatter_kernel(int C, int n, int
             }
             sd[cl * (LAGG_MT + 1) + ml] = d; sy[cl * (LAGG_MT + 1) + ml] = y; sa[cl * (LAGG_MT + 1) + ml] = __int_as_float(a);
         }
+        // the tile's rows of idx and dp (contiguous: LAGG_MT * K positions), read once for all channels -- every routed
+        // gradient used to fetch its own index and, behind it, three floats of dp: two dependent round trips per element
+        for (int t = threadIdx.x; t < LAGG_MT * K; t += 256) {
+            const long pos = (long)m0 * K + t;
+            const bool in = pos < P;
+            sidx[t] = in ? idx[(size_t)b * P + pos] : 0;
+            const size_t pd = (size_t)b * 3 * P + pos;
+            sdp[t] = in ? dp[pd] : 0.f;
+            sdp[LAGG_MT * K + t] = in ? dp[pd + P] : 0.f;
+            sdp[2 * LAGG_MT * K + t] = in ? dp[pd + 2 * P] : 0.f;
+        }
         __syncthreads();
         for (int i = 0; i < LAGG_MT / 4; ++i) {
             const int ml = wave * (LAGG_MT / 4) + i, m = m0 + ml;
@@ -361,12 +383,12 @@ __global__ __launch_bounds__(256) void lagg_bwd_scatter_kernel(int C, int n, int
                 const float xh = __fmul_rn(__fsub_rn(y, mu[h]), is[h]);
                 if (relu && !(__fadd_rn(__fmul_rn(xh, ga[h]), be[h]) > 0.f)) dq = 0.f;
                 if (dq != 0.f) {
-                    const size_t p = (size_t)b * P + (size_t)m * K + k;
-                    const int id = idx[p];
-                    const size_t pd = (size_t)b * 3 * P + (size_t)m * K + k;
+                    const int slot = ml * K + k;
+                    const int id = sidx[slot];
                     const double dd = dq;
                     acc[h][0] += dd; acc[h][1] += dd * (double)xh;
-                    acc[h][2] += dd * (double)dp[pd]; acc[h][3] += dd * (double)dp[pd + P]; acc[h][4] += dd * (double)dp[pd + 2 * P];
+                    acc[h][2] += dd * (double)sdp[slot]; acc[h][3] += dd * (double)sdp[LAGG_MT * K + slot];
+                    acc[h][4] += dd * (double)sdp[2 * LAGG_MT * K + slot];
                     atomicAdd(Q + ((size_t)b * n + id) * C + c0 + cl, dq);
                 }
             }
@@ -817,9 +839,11 @@ AMC_API int amc3d_local_aggregation_backward(int b, int cout, int n, int npoints
     const int nparts_b = div_up(div_up(npoints, LAGG_MT), stiles);
     if (phase != 2) {
         if (int st = fill_i32((int *)Q, 0, (size_t)b * n * cout, stream)) return st;
-        size_t lds = (size_t)3 * ct * (LAGG_MT + 1) * sizeof(float);
+        size_t lds = ((size_t)3 * ct * (LAGG_MT + 1) + (size_t)4 * LAGG_MT * nsample) * sizeof(float);
         const size_t red = (size_t)4 * ct * 5 * sizeof(double);
         if (lds < red) lds = red;
+        if (lds > 65536)  // (128 channels x 33 x 3 images + the idx / dp rows: 67 KB; gfx950 has 160 KB per workgroup)
+            (void)hipFuncSetAttribute((const void *)lagg_bwd_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(lagg_bwd_scatter_kernel, dim3(nparts_b, cout / ct, b), dim3(256), lds, stream, cout, n, npoints, nsample,
                            relu, dpooled, ystar, arg, idx, dp, mean, invstd, gamma, beta, Q, partial, nparts_b, stiles);
     }
