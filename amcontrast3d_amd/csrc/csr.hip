@@ -12,6 +12,8 @@
 //   amc3d_grouped_conv_bn_backward_csr   the collapse pass of the first SetAbstraction layer as a gather
 #include <hipcub/hipcub.hpp>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace amc {
@@ -121,7 +123,7 @@ __device__ __forceinline__ float csr_bn(float x, float mean, float invstd, float
 //   q[g][c] = sum_e d(e, c),  d = dx1_pm[position e][c] * [relu: bn(G[g][c] + W_dp[c] . dp_e) > 0]
 //   partial sums per channel {sum d, sum d xhat, sum d dp_j}.  dx1_pm is the POSITION-major gradient (b, P, C).
 // grid (point groups, channel chunks of 64, 1); a workgroup takes PTS consecutive source points per wave-group
-constexpr int CSR_BS = 1024;  // threads per workgroup: 1024 / CT point groups share one partial
+constexpr int CSR_BS = 512;   // threads per workgroup: 512 / CT point groups share one partial
 template <int CT>
 __global__ __launch_bounds__(CSR_BS) void csr_collapse_kernel(int C, int n, long P, long G, int relu, const float *__restrict__ dx1_pm,
                                                            const float *__restrict__ g_pm, const int *__restrict__ rev_start,
@@ -141,6 +143,75 @@ __global__ __launch_bounds__(CSR_BS) void csr_collapse_kernel(int C, int n, long
     const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
     double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
     const long g_begin = ((long)blockIdx.x * GROUPS + grp) * pts_per_group;
+    if (rev_dp) {
+        // Software pipeline over the points of this lane group: a point costs three DEPENDENT round trips (list bounds -> edge
+        // records -> gradient rows); here the rows of point i, the records of point i + 1 and the bounds of point i + 2 are in
+        // flight together (the first eight edges of a list -- the lists have ~8; longer ones finish in the plain loop below).
+        const long E = G > 0 ? (long)rev_start[G] : 0;
+        auto bounds = [&](long g_, int &s_, int &e_) {
+            const bool in = g_ < G && g_ < g_begin + pts_per_group;
+            s_ = in ? rev_start[g_] : 0;
+            e_ = in ? rev_start[g_ + 1] : 0;
+        };
+        auto records = [&](int s_, int e_, float4 *r_) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                long j = min(s_ + u, e_ - 1);
+                j = j < 0 ? 0 : (j >= E ? E - 1 : j);  // (an empty list reads a valid record it does not use)
+                r_[u] = rev_dp[j];
+            }
+        };
+        int s0, e0_, s1, e1_, s2, e2_;
+        float4 rec[8], recn[8];
+        bounds(g_begin, s0, e0_);
+        bounds(g_begin + 1, s1, e1_);
+        records(s0, e0_, rec);
+        float gv = g_begin < G ? g_pm[g_begin * C + c] : 0.f;
+        for (int i = 0; i < pts_per_group; ++i) {
+            const long g = g_begin + i;
+            if (g >= G) break;
+            const int b = (int)(g / n);
+            const float *xrow = dx1_pm + (long)b * P * C + c;
+            float d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d[u] = xrow[(long)__float_as_int(rec[u].w) * C];   // rows of point i
+            records(s1, e1_, recn);                                                          // records of point i + 1
+            bounds(g + 2, s2, e2_);                                                          // bounds of point i + 2
+            const float gvn = (g + 1 < G) ? g_pm[(g + 1) * C + c] : 0.f;
+            float q = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, q4 = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float y = __fmaf_rn(w0, rec[u].x, __fmaf_rn(w1, rec[u].y, __fmaf_rn(w2, rec[u].z, gv)));
+                const float xh = __fmul_rn(__fsub_rn(y, mu), is);
+                float dv = d[u];
+                if (s0 + u >= e0_ || (relu && !(__fadd_rn(__fmul_rn(xh, ga), be) > 0.f))) dv = 0.f;
+                q += dv;
+                q1 = __fmaf_rn(dv, xh, q1); q2 = __fmaf_rn(dv, rec[u].x, q2); q3 = __fmaf_rn(dv, rec[u].y, q3); q4 = __fmaf_rn(dv, rec[u].z, q4);
+            }
+            for (int j0 = s0 + 8; j0 < e0_; j0 += 8) {  // the rest of a long list
+                float4 r[8];
+                float dd[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) r[u] = rev_dp[min(j0 + u, e0_ - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dd[u] = xrow[(long)__float_as_int(r[u].w) * C];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float y = __fmaf_rn(w0, r[u].x, __fmaf_rn(w1, r[u].y, __fmaf_rn(w2, r[u].z, gv)));
+                    const float xh = __fmul_rn(__fsub_rn(y, mu), is);
+                    float dv = dd[u];
+                    if (j0 + u >= e0_ || (relu && !(__fadd_rn(__fmul_rn(xh, ga), be) > 0.f))) dv = 0.f;
+                    q += dv;
+                    q1 = __fmaf_rn(dv, xh, q1); q2 = __fmaf_rn(dv, r[u].x, q2); q3 = __fmaf_rn(dv, r[u].y, q3); q4 = __fmaf_rn(dv, r[u].z, q4);
+                }
+            }
+            a0 += (double)q; a1 += (double)q1; a2 += (double)q2; a3 += (double)q3; a4 += (double)q4;
+            Q[g * C + c] = q;
+            s0 = s1; e0_ = e1_; s1 = s2; e1_ = e2_; gv = gvn;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rec[u] = recn[u];
+        }
+    } else
     for (int i = 0; i < pts_per_group; ++i) {
         const long g = g_begin + i;
         if (g >= G) break;
@@ -499,10 +570,13 @@ AMC_API int amc3d_group_moments_csr(int b, int n, int npoints, int nsample, cons
 
 static int csr_pts_per_group(long G, int groups_per_wg)
 {
-    // ~2048 workgroups of 1024 threads: a group walks its points one after the other (three dependent round trips each:
+    // ~4096 workgroups of 512 threads (round 3; 2048 of 1024 before: 437 -> 399 us for the step's four launches, measured with
+    // the loop over a group's points software-pipelined -- which needs more than the 128 registers a 1024-thread workgroup
+    // leaves): a group walks its points one after the other (three dependent round trips each:
     // list bounds, edge ids, rows), so what counts is FEW points per group -- 3 at SA1 instead of 12: 265 -> 160 us -- while
     // the number of partial sums (one per workgroup) stays where the finalize kernel reads them quickly
-    long per = (G + 2048L * groups_per_wg - 1) / (2048L * groups_per_wg);
+    static const long wgs = getenv("AMC3D_CSR_WGS") ? atol(getenv("AMC3D_CSR_WGS")) : 4096L;
+    long per = (G + wgs * groups_per_wg - 1) / (wgs * groups_per_wg);
     return (int)(per < 1 ? 1 : per);
 }
 
