@@ -85,7 +85,9 @@ SIGNATURES = {
     "amc3d_bias_grad": (_i, [_i, _i, _l, _vp, _vp, _vp]),
     "amc3d_sa_residual_forward": (_i, [_i, _i, _i, _i, _i] + [_vp] * 8),
     "amc3d_sa_residual_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "amc3d_sa_residual_backward": (_i, [_i, _i, _i, _i, _i] + [_vp] * 10 + [_sz, _vp]),
+    "amc3d_sa_residual_backward": (_i, [_i, _i, _i, _i, _i] + [_vp] * 11 + [_sz, _vp]),
+    "amc3d_index_duplicates_workspace_bytes": (_sz, [_i, _i]),
+    "amc3d_index_duplicates": (_i, [_i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_augment_workspace_bytes": (_sz, [_i]),
     "amc3d_augment_clouds": (_i, [_i, _i, _i, _f, _f] + [_vp] * 10 + [_sz, _vp]),
     "amc3d_voxelize_workspace_bytes": (_sz, [_i]),

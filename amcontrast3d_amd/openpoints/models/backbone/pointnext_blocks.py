@@ -172,6 +172,11 @@ class SetAbstraction(nn.Module):
             g['dp'] = self.grouper.relative_positions(g['idx'], g['new_p'], p)
             g['csr'] = _csr(self.convs, self.feature_type, g['idx'], p.shape[1], g['dp'])
             g['mom'] = _moments(self.convs, self.feature_type, g['idx'], g['dp'], p.shape[1], g['csr'])
+            if getattr(self, 'use_res', False) and g.get('fps_idx32') is not None and g['fps_idx32'].is_cuda:
+                # do the picks of some cloud repeat an index?  (torch.gather's backward sums over repeats; the fused residual's
+                # backward scatters with plain stores when they do not: csrc/sa_res.hip)
+                from amcontrast3d_amd import ops
+                g['fps_dup'] = ops.index_duplicates(g['fps_idx32'], p.shape[1])
         return g
 
     def plan(self, p):
@@ -214,7 +219,7 @@ class SetAbstraction(nn.Module):
         if res_fused:  # gather at the FPS picks + skip conv + bias + add + ReLU as one kernel (csrc/sa_res.hip)
             from amcontrast3d_amd import ops
             conv = self.skipconv[0]
-            f = ops.sa_residual(f, pf[1], geom['fps_idx32'], conv.weight, conv.bias)
+            f = ops.sa_residual(f, pf[1], geom['fps_idx32'], conv.weight, conv.bias, geom.get('fps_dup'))
         elif self.use_res:
             f = self.act(f + identity)
         return new_p, f

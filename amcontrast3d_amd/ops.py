@@ -1643,8 +1643,11 @@ class SAResidual(Function):
     y (B,Cout,M) pooled main branch, f (B,Cin,N), fps_idx (B,M) int32, weight (Cout,Cin,1), bias (Cout) or None."""
 
     @staticmethod
-    def forward(ctx, y, f, fps_idx, weight, bias):
+    def forward(ctx, y, f, fps_idx, weight, bias, dup_flag=None):
         _need_gpu(y, f, fps_idx, weight)
+        if dup_flag is not None:
+            _need_gpu(dup_flag)
+            _need_dtype(torch.int32, dup_flag=dup_flag)
         _need_dtype(torch.float32, y=y, f=f, weight=weight, bias=bias)
         _need_dtype(torch.int32, fps_idx=fps_idx)
         y, f, fps_idx = y.contiguous(), f.contiguous(), fps_idx.contiguous()
@@ -1662,14 +1665,15 @@ class SAResidual(Function):
                                                              _ptr(bias) if bias is not None else None, _ptr(y), _ptr(out),
                                                              _ptr(fi) if keep else None, _stream(f)), "sa_residual_forward")
         if keep:
-            ctx.save_for_backward(out, fi, fps_idx, w2)
+            ctx.save_for_backward(out, fi, fps_idx, w2, *([dup_flag] if dup_flag is not None else []))
         ctx.n, ctx.wshape, ctx.has_bias = N, tuple(weight.shape), bias is not None
         ctx.mark_non_differentiable(fps_idx)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        out, fi, fps_idx, w2 = ctx.saved_tensors
+        out, fi, fps_idx, w2 = ctx.saved_tensors[:4]
+        dup_flag = ctx.saved_tensors[4] if len(ctx.saved_tensors) > 4 else None
         B, Cout, M = out.shape
         Cin, N = w2.shape[1], ctx.n
         dout = dout.contiguous()
@@ -1687,14 +1691,32 @@ class SAResidual(Function):
         with torch.cuda.device(dev), timing.span("sa_residual_backward", nbytes,
                                                  2.0 * B * M * Cin * Cout * (int(need_f) + int(need_w))):
             _lib.check(lib.amc3d_sa_residual_backward(B, Cin, Cout, N, M, _ptr(dout), _ptr(out), _ptr(fi), _ptr(fps_idx),
+                                                      _ptr(dup_flag) if dup_flag is not None else None,
                                                       _ptr(w2), _ptr(g), _ptr(df) if need_f else None,
                                                       _ptr(dw) if need_w else None, _ptr(db) if need_b else None,
                                                       _ptr(work), wb, _stream(dout)), "sa_residual_backward")
-        return g, df, None, (dw.view(ctx.wshape) if need_w else None), db
+        return g, df, None, (dw.view(ctx.wshape) if need_w else None), db, None
 
 
-def sa_residual(y, f, fps_idx, weight, bias):
-    return SAResidual.apply(y, f, fps_idx, weight, bias)
+def sa_residual(y, f, fps_idx, weight, bias, dup_flag=None):
+    """dup_flag: index_duplicates(fps_idx, N) of the plan, or None (the backward then adds with float atomics, right for any picks)"""
+    return SAResidual.apply(y, f, fps_idx, weight, bias, dup_flag)
+
+
+@torch.no_grad()
+def index_duplicates(idx, n):
+    """int32 [1] on the device: 1 if some row of idx (B, M) int32 into n points repeats an index, else 0 (no host sync)"""
+    _need_gpu(idx)
+    _need_dtype(torch.int32, idx=idx)
+    idx = idx.contiguous()
+    B, M = idx.shape
+    flag = torch.empty(1, dtype=torch.int32, device=idx.device)
+    lib = _lib.load()
+    wb = int(lib.amc3d_index_duplicates_workspace_bytes(B, int(n)))
+    work = torch.empty(max(wb, 4), dtype=torch.uint8, device=idx.device)
+    with torch.cuda.device(idx.device):
+        _lib.check(lib.amc3d_index_duplicates(B, int(n), M, _ptr(idx), _ptr(flag), _ptr(work), wb, _stream(idx)), "index_duplicates")
+    return flag
 
 
 def _library_wgrad(dy3, x3):

@@ -326,8 +326,14 @@ int amc3d_sa_residual_forward(int b, int cin, int cout, int n, int m, const floa
                               const float *weight, const float *bias, const float *y, float *out, float *fi, void *stream);
 size_t amc3d_sa_residual_workspace_bytes(int b, int cin, int cout, int m);
 int amc3d_sa_residual_backward(int b, int cin, int cout, int n, int m, const float *dout, const float *out,
-                               const float *fi, const int *fps_idx, const float *weight, float *g, float *df,
+                               const float *fi, const int *fps_idx, const int *dup_flag, const float *weight, float *g, float *df,
                                float *dweight, float *dbias, void *workspace, size_t workspace_bytes, void *stream);
+/* dup_flag: DEVICE int of amc3d_index_duplicates for these picks, or NULL.  torch.gather's backward (pointnext_AA.py:157) SUMS
+ * over repeated picks -- FPS re-picks a point when a cloud holds fewer distinct points than picks (crop_pc pads small rooms by
+ * repetition, data_util.py:161-167) -- so the scatter of df adds (float atomics) when the flag is 1 or unknown, and stores plainly
+ * when the plan found the picks distinct. */
+size_t amc3d_index_duplicates_workspace_bytes(int b, int n);
+int amc3d_index_duplicates(int b, int n, int m, const int *idx, int *flag, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- input pipeline on the device (openpoints/dataset/data_util.py:92-174; dataset/s3dis/s3dis.py:122-144) -----------
  * voxelize: floor(coord / voxel_size) in float64 -> FNV-1a 64-bit hash of the three cell coordinates (fnv_hash_vec) ->

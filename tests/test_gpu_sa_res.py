@@ -72,6 +72,39 @@ def test_sa_residual_sums_over_repeated_picks():
         assert float((a.double() - t64).abs().max()) / scale <= 1e-5, name
 
 
+def test_the_plans_duplicate_flag_selects_plain_stores_only_for_distinct_picks():
+    """ops.index_duplicates (part of the sampling plan) tells the backward whether some cloud's picks repeat an index: 0 ->
+    the scatter of df is plain stores (bit for bit the adds into the zero-filled df: one add per address), 1 -> it adds, and the
+    repeated picks sum as torch.gather's backward does."""
+    from amcontrast3d_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, Cin, Cout, N, M = 3, 32, 64, 2000, 500
+    y = torch.randn(B, Cout, M, generator=g).to(DEV)
+    f = torch.randn(B, Cin, N, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 1, generator=g) * (1.0 / Cin ** 0.5)).to(DEV)
+    b = (torch.randn(Cout, generator=g) * 0.3).to(DEV)
+    gout = torch.randn(B, Cout, M, generator=g).to(DEV)
+    distinct = torch.stack([torch.randperm(N, generator=g)[:M] for _ in range(B)]).to(torch.int32).to(DEV)
+    repeated = distinct.clone()
+    repeated[1, 7] = repeated[1, 400]  # one repeat in one cloud
+    outside = distinct.clone()
+    outside[2, 0] = N  # an index outside the cloud counts as "not distinct" (the adds are right for any picks)
+    assert int(ops.index_duplicates(distinct, N)) == 0 and int(ops.index_duplicates(repeated, N)) == 1
+    assert int(ops.index_duplicates(outside, N)) == 1
+
+    def grads(idx, flag):
+        leaves = [t.clone().requires_grad_(True) for t in (y, f, w, b)]
+        out = ops.sa_residual(leaves[0], leaves[1], idx, leaves[2], leaves[3], flag)
+        out.backward(gout)
+        return [out.detach()] + [t.grad for t in leaves]
+
+    for a, c in zip(grads(distinct, None), grads(distinct, ops.index_duplicates(distinct, N))):
+        assert torch.equal(a, c)
+    r64 = reference(y, f, repeated, w, b, gout, torch.float64)
+    for name, a, t64 in zip(("out", "dy", "df", "dw", "db"), grads(repeated, ops.index_duplicates(repeated, N)), r64):
+        assert float((a.double() - t64).abs().max()) / (float(t64.abs().max()) + 1e-30) <= 1e-5, name
+
+
 def test_sa_residual_is_deterministic_and_graph_safe():
     from amcontrast3d_amd import ops
     g = torch.Generator().manual_seed(5)
