@@ -50,14 +50,14 @@ SIGNATURES = {
     "amc3d_contrast_mutual_workspace_bytes": (_sz, [_i]),
     "amc3d_contrast_mutual": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "amc3d_contrast_backward_mutual_workspace_bytes": (_sz, [_i]),
-    "amc3d_contrast_backward_mutual": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _sz,
+    "amc3d_contrast_backward_mutual": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz,
                                             _vp, _vp]),
     "amc3d_adamw_chunk": (_i, []),
     "amc3d_adamw_step": (_i, [_vp, _vp, _i, ctypes.c_double, ctypes.c_double, _f, _f, _vp, _vp, _vp]),
     "amc3d_select_anchors_ints": (_sz, [_i]),
     "amc3d_select_anchors": (_i, [_i, _vp, _vp, _sz, _vp]),
-    "amc3d_contrast_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "amc3d_contrast_forward_cm": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_contrast_forward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "amc3d_contrast_forward_cm": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_contrast_backward": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "amc3d_grouped_conv_supported": (_i, [_i, _i]),
     "amc3d_transpose_cn": (_i, [_i, _i, _i, _vp, _vp, _vp]),

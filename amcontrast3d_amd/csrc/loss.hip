@@ -247,7 +247,7 @@ template <int LPR>
 __global__ __launch_bounds__(256) void contrast_forward_unit_kernel(
     int m, int k, int nbr_stride, const float *__restrict__ unit, const int *__restrict__ nbr,
     const unsigned char *__restrict__ posmask, const float *__restrict__ a, const int *__restrict__ sel, float mu, float nu,
-    float temperature, float *__restrict__ sim, float *__restrict__ loss_pt)
+    float temperature, float *__restrict__ sim, float *__restrict__ stats, float *__restrict__ loss_pt)
 {
     constexpr int R = 64 / LPR;  // rows per round
     constexpr int U = 4;         // rounds in flight (LPR >= U: lane q < U of a row owns the row's slot of round q)
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void contrast_forward_unit_kernel(
             s = q == t ? acc : s;
         }
         if (mine) {
-            sim[(size_t)i * k + jq] = s;
+            if (sim) sim[(size_t)i * k + jq] = s;
             const float e = expf(__fdiv_rn(pos ? __fsub_rn(s, margin) : s, temperature));
             psum += pos ? e : 0.f;
             tsum += e;
@@ -298,7 +298,10 @@ __global__ __launch_bounds__(256) void contrast_forward_unit_kernel(
         psum += __shfl_xor(psum, d, 64);
         tsum += __shfl_xor(tsum, d, 64);
     }
-    if (lane == 0) loss_pt[i] = -logf(__fadd_rn(__fdiv_rn(psum, tsum), 1e-12f));
+    if (lane == 0) {
+        loss_pt[i] = -logf(__fadd_rn(__fdiv_rn(psum, tsum), 1e-12f));
+        if (stats) { stats[(size_t)i * 2] = psum; stats[(size_t)i * 2 + 1] = tsum; }  // what the backward's records need of this pass
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -697,6 +700,27 @@ __global__ __launch_bounds__(256) void contrast_record_kernel(
 // (unit rows, see row_unit_kernel: hx = f_x / n_x is fetched, not recomputed; lane q < U of a row decodes and evaluates the
 // row's slot of round q -- index, mask, mutual count, the record of x, the two exponentials -- once, and hands x down to /
 // the finished coefficient back to the row's lanes by shuffles)
+// the same records from the two sums the forward pass kept per anchor (stats[2 i] = sum of the positives' exponentials,
+// stats[2 i + 1] = sum of all): nothing to recompute, no similarities to read; one thread per anchor
+__global__ __launch_bounds__(256) void contrast_record_stats_kernel(int m, const float *__restrict__ norm, const float *__restrict__ a,
+                                                                    float mu, float nu, float temperature,
+                                                                    const float *__restrict__ stats, const float *__restrict__ mean_cnt,
+                                                                    const float *__restrict__ grad_out, ContrastRecord *__restrict__ rec)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const float ai = a[i];
+    const bool selected = 0.f < ai && ai <= 1.f;  // (the forward visited the selected anchors only: the others' stats are unwritten)
+    const float psum = selected ? stats[(size_t)i * 2] : 0.f, tsum = selected ? stats[(size_t)i * 2 + 1] : 1.f;
+    const float scale = grad_out[0] / mean_cnt[1];
+    const float r = psum / tsum;
+    ContrastRecord o;
+    o.norm = norm[i];
+    o.coef = (selected && psum != 0.f) ? -scale / ((r + 1e-12f) * tsum * tsum * temperature) : 0.f;
+    o.tsum = tsum; o.psum = psum; o.margin = __fadd_rn(__fmul_rn(mu, ai), nu); o.pad0 = o.pad1 = o.pad2 = 0.f;
+    rec[i] = o;
+}
+
 template <int LPR>
 __global__ __launch_bounds__(256) void contrast_backward_mutual_kernel(
     int m, int k, int nbr_stride, const float *__restrict__ unit, const int *__restrict__ nbr,
@@ -940,13 +964,14 @@ AMC_API int amc3d_select_anchors(int m, const float *a, int *sel, size_t sel_int
 // cm_b > 0: f is channel-major (cm_b, C, m / cm_b) and only the unit-row kernels apply
 static int contrast_forward_launch(int cm_b, int m, int C, int k, int nbr_stride, const float *f, const int *nbr,
                                    const unsigned char *posmask, const float *a, const int *sel, float mu, float nu,
-                                   float temperature, float *norm, float *unit, float *sim, float *loss_pt, float *mean_cnt,
-                                   hipStream_t stream)
+                                   float temperature, float *norm, float *unit, float *sim, float *stats, float *loss_pt,
+                                   float *mean_cnt, hipStream_t stream)
 {
     // (the row kernels index 16-byte pieces with 32 bits: m * C / 4 < 2^32)
     const bool rows = unit && ((((uintptr_t)f) | ((uintptr_t)unit)) & 15) == 0 && amc3d_contrast_backward_csr_supported(C) &&
                       (long)m * C < (1L << 34);
     if (cm_b > 0 && !rows) return bad_arg("amc3d_contrast_forward_cm: C must be 16, 32, 64, 128 or 256; unit required, 16-byte aligned");
+    if (!sim && !(rows && stats)) return bad_arg("amc3d_contrast_forward: sim may be NULL only with the unit-row kernels and stats");
 #define AMC_FWD(LPR)                                                                                                       \
     do {                                                                                                                   \
         if (cm_b > 0) {                                                                                                    \
@@ -957,7 +982,7 @@ static int contrast_forward_launch(int cm_b, int m, int C, int k, int nbr_stride
         } else                                                                                                             \
             hipLaunchKernelGGL((row_unit_kernel<LPR>), dim3(div_up((long)m * LPR, 256)), dim3(256), 0, stream, m, f, norm, unit); \
         hipLaunchKernelGGL((contrast_forward_unit_kernel<LPR>), dim3(div_up(m, 4)), dim3(256), 0, stream, m, k, nbr_stride, \
-                           (const float *)unit, nbr, posmask, a, sel, mu, nu, temperature, sim, loss_pt);                  \
+                           (const float *)unit, nbr, posmask, a, sel, mu, nu, temperature, sim, stats, loss_pt);           \
     } while (0)
     if (rows && C == 16) AMC_FWD(4);
     else if (rows && C == 32) AMC_FWD(8);
@@ -977,29 +1002,29 @@ static int contrast_forward_launch(int cm_b, int m, int C, int k, int nbr_stride
 
 AMC_API int amc3d_contrast_forward(int m, int C, int k, int nbr_stride, const float *f, const int *nbr,
                                    const unsigned char *posmask, const float *a, const int *sel, float mu, float nu,
-                                   float temperature, float *norm, float *unit, float *sim, float *loss_pt,
+                                   float temperature, float *norm, float *unit, float *sim, float *stats, float *loss_pt,
                                    float *mean_cnt, void *stream_)
 {
     if (m <= 0) return 0;
-    if (C <= 0 || k <= 0 || nbr_stride < k || !f || !nbr || !posmask || !a || !norm || !sim || !loss_pt || !mean_cnt)
+    if (C <= 0 || k <= 0 || nbr_stride < k || !f || !nbr || !posmask || !a || !norm || !loss_pt || !mean_cnt)
         return bad_arg("amc3d_contrast_forward: bad argument");
-    return contrast_forward_launch(0, m, C, k, nbr_stride, f, nbr, posmask, a, sel, mu, nu, temperature, norm, unit, sim, loss_pt,
-                                   mean_cnt, (hipStream_t)stream_);
+    return contrast_forward_launch(0, m, C, k, nbr_stride, f, nbr, posmask, a, sel, mu, nu, temperature, norm, unit, sim, stats,
+                                   loss_pt, mean_cnt, (hipStream_t)stream_);
 }
 
 // the same on channel-major embeddings f_cm (b, C, n), m = b * n anchors in cloud-major order (the decoder's layout: no
 // point-major copy of f is made; unit receives the point-major unit rows the backward reads)
 AMC_API int amc3d_contrast_forward_cm(int b, int C, int n, int k, int nbr_stride, const float *f_cm, const int *nbr,
                                       const unsigned char *posmask, const float *a, const int *sel, float mu, float nu,
-                                      float temperature, float *norm, float *unit, float *sim, float *loss_pt,
+                                      float temperature, float *norm, float *unit, float *sim, float *stats, float *loss_pt,
                                       float *mean_cnt, void *stream_)
 {
     if (b <= 0 || n <= 0) return 0;
-    if ((long)b * n > 0x7fffffffL || C <= 0 || k <= 0 || nbr_stride < k || !f_cm || !nbr || !posmask || !a || !norm || !unit || !sim ||
+    if ((long)b * n > 0x7fffffffL || C <= 0 || k <= 0 || nbr_stride < k || !f_cm || !nbr || !posmask || !a || !norm || !unit ||
         !loss_pt || !mean_cnt)
         return bad_arg("amc3d_contrast_forward_cm: bad argument");
     return contrast_forward_launch(b, b * n, C, k, nbr_stride, f_cm, nbr, posmask, a, sel, mu, nu, temperature, norm, unit, sim,
-                                   loss_pt, mean_cnt, (hipStream_t)stream_);
+                                   stats, loss_pt, mean_cnt, (hipStream_t)stream_);
 }
 
 AMC_API int amc3d_contrast_backward(int m, int C, int k, int nbr_stride, const float *f, const float *norm,
@@ -1061,19 +1086,23 @@ AMC_API size_t amc3d_contrast_backward_mutual_workspace_bytes(int m) { return (s
 AMC_API int amc3d_contrast_backward_mutual(int m, int C, int k, int nbr_stride, const float *unit, const float *norm,
                                            const int *nbr, const unsigned char *posmask, const float *a,
                                            const unsigned char *mutual, const int *rev, float mu, float nu, float temperature,
-                                           const float *sim, const float *mean_cnt, const float *grad_out, void *workspace,
-                                           size_t workspace_bytes, float *grad_f, void *stream_)
+                                           const float *sim, const float *stats, const float *mean_cnt, const float *grad_out,
+                                           void *workspace, size_t workspace_bytes, float *grad_f, void *stream_)
 {
     if (m <= 0) return 0;
     if (!amc3d_contrast_backward_csr_supported(C) || k <= 0 || nbr_stride < k || !unit || !norm || !nbr || !posmask || !a || !mutual ||
-        !rev || !sim || !mean_cnt || !grad_out || !grad_f || !workspace ||
+        !rev || (!sim && !stats) || !mean_cnt || !grad_out || !grad_f || !workspace ||
         workspace_bytes < amc3d_contrast_backward_mutual_workspace_bytes(m) || (long)m * C >= (1L << 34) ||
         (((uintptr_t)unit | (uintptr_t)grad_f | (uintptr_t)workspace) & 15))
         return bad_arg("amc3d_contrast_backward_mutual: bad argument (C must be 16, 32, 64, 128 or 256; 16-byte aligned rows)");
     hipStream_t stream = (hipStream_t)stream_;
     ContrastRecord *rec = (ContrastRecord *)workspace;
-    hipLaunchKernelGGL(contrast_record_kernel, dim3(div_up((long)m * 32, 256)), dim3(256), 0, stream, m, k, norm, posmask, a, mu, nu,
-                       temperature, sim, mean_cnt, grad_out, rec);
+    if (stats)
+        hipLaunchKernelGGL(contrast_record_stats_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, m, norm, a, mu, nu, temperature, stats,
+                           mean_cnt, grad_out, rec);
+    else
+        hipLaunchKernelGGL(contrast_record_kernel, dim3(div_up((long)m * 32, 256)), dim3(256), 0, stream, m, k, norm, posmask, a, mu, nu,
+                           temperature, sim, mean_cnt, grad_out, rec);
 #define AMC_BWD(LPR)                                                                                                    \
     hipLaunchKernelGGL((contrast_backward_mutual_kernel<LPR>), dim3(div_up(m, 4)), dim3(256), 0, stream, m, k, nbr_stride, unit, \
                        nbr, posmask, mutual, rev, (const ContrastRecord *)rec, temperature, grad_f)

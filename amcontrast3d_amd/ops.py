@@ -595,7 +595,7 @@ class ContrastStage(Function):
                                                   _ptr(anchors) if anchors is not None else None,
                                                   float(mu), float(nu), float(temperature), _ptr(norm),
                                                   _ptr(unit) if unit is not None else None,
-                                                  _ptr(sim), _ptr(loss_pt), _ptr(mean_cnt), _stream(f)),
+                                                  _ptr(sim), None, _ptr(loss_pt), _ptr(mean_cnt), _stream(f)),
                        "contrast_forward")
         if rev is not None:
             _need_dtype(torch.int32, rev=rev)
@@ -622,7 +622,7 @@ class ContrastStage(Function):
             with torch.cuda.device(f.device), timing.span("contrast_backward", m * C * 8 + m * k * 10 + m * 8,
                                                           moved=m * C * 4 * (2 + k) + m * k * 42 + m * 40):
                 _lib.check(lib.amc3d_contrast_backward_mutual(m, C, k, stride, _ptr(unit), _ptr(norm), nptr, _ptr(posmask), _ptr(a),
-                                                              _ptr(mutual), _ptr(rev), mu, nu, temperature, _ptr(sim),
+                                                              _ptr(mutual), _ptr(rev), mu, nu, temperature, _ptr(sim), None,
                                                               _ptr(mean_cnt), _ptr(g), _ptr(work), wb, _ptr(grad_f), _stream(f)),
                            "contrast_backward_mutual")
             return (grad_f,) + (None,) * 9
@@ -671,21 +671,23 @@ class ContrastStageChannelMajor(Function):
         dev = f_cm.device
         norm = torch.empty(m, dtype=torch.float32, device=dev)
         unit = torch.empty(m, C, dtype=torch.float32, device=dev)
-        sim = torch.empty(m, k, dtype=torch.float32, device=dev)
+        # the two sums of exponentials per anchor, kept for the backward's records; the cosines themselves are not stored (the
+        # mutual-edge backward recomputes the ones it needs from the unit rows it fetches anyway)
+        stats = torch.empty(m, 2, dtype=torch.float32, device=dev)
         loss_pt = torch.empty(m, dtype=torch.float32, device=dev)
         mean_cnt = torch.empty(2, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), timing.span("contrast_forward", m * C * 4 + m * k * 9 + m * 12, moved=m * C * 4 * (2 + k) + m * k * 9 + m * 12):
+        with torch.cuda.device(dev), timing.span("contrast_forward", m * C * 4 + m * k * 5 + m * 20, moved=m * C * 4 * (2 + k) + m * k * 5 + m * 20):
             _lib.check(_lib.load().amc3d_contrast_forward_cm(B, C, n, k, stride, _ptr(f_cm), nptr, _ptr(posmask), _ptr(a), _ptr(anchors),
                                                              float(mu), float(nu), float(temperature), _ptr(norm), _ptr(unit),
-                                                             _ptr(sim), _ptr(loss_pt), _ptr(mean_cnt), _stream(f_cm)),
+                                                             None, _ptr(stats), _ptr(loss_pt), _ptr(mean_cnt), _stream(f_cm)),
                        "contrast_forward_cm")
-        ctx.save_for_backward(norm, keep, posmask, a, sim, mean_cnt, rev, mutual, unit)
+        ctx.save_for_backward(norm, keep, posmask, a, stats, mean_cnt, rev, mutual, unit)
         ctx.args = (float(mu), float(nu), float(temperature), k, stride, B, C, n)
         return mean_cnt[0].clone()
 
     @staticmethod
     def backward(ctx, grad_out):
-        norm, nbr, posmask, a, sim, mean_cnt, rev, mutual, unit = ctx.saved_tensors
+        norm, nbr, posmask, a, stats, mean_cnt, rev, mutual, unit = ctx.saved_tensors
         mu, nu, temperature, k, stride, B, C, n = ctx.args
         m = B * n
         g = grad_out.detach().to(torch.float32).reshape(1).contiguous()
@@ -697,7 +699,7 @@ class ContrastStageChannelMajor(Function):
         with torch.cuda.device(unit.device), timing.span("contrast_backward", m * C * 8 + m * k * 10 + m * 8,
                                                          moved=m * C * 4 * (4 + k) + m * k * 42 + m * 40):
             _lib.check(lib.amc3d_contrast_backward_mutual(m, C, k, stride, _ptr(unit), _ptr(norm), _ptr(nbr), _ptr(posmask), _ptr(a),
-                                                          _ptr(mutual), _ptr(rev), mu, nu, temperature, _ptr(sim),
+                                                          _ptr(mutual), _ptr(rev), mu, nu, temperature, None, _ptr(stats),
                                                           _ptr(mean_cnt), _ptr(g), _ptr(work), wb, _ptr(grad_rows), _stream(unit)),
                        "contrast_backward_mutual")
             # (B, n, C) -> (B, C, n)

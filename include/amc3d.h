@@ -195,16 +195,19 @@ int amc3d_select_anchors(int m, const float *a, int *sel, size_t sel_ints, void 
  * takes the same buffer; NULL: the generic kernel on f and norm. */
 int amc3d_contrast_forward(int m, int C, int k, int nbr_stride, const float *f, const int *nbr,
                            const unsigned char *posmask, const float *a, const int *sel, float mu, float nu,
-                           float temperature, float *norm, float *unit, float *sim, float *loss_pt, float *mean_cnt,
-                           void *stream);
+                           float temperature, float *norm, float *unit, float *sim, float *stats, float *loss_pt,
+                           float *mean_cnt, void *stream);
+/* stats (m,2) or NULL: with the unit-row kernels the pass leaves, per visited anchor, the two sums of exponentials its loss is made
+ * of -- amc3d_contrast_backward_mutual builds its per-anchor records from them instead of re-reading sim, and sim may then be NULL
+ * (the cosines are not stored: the mutual-edge backward recomputes the ones it needs from the unit rows it fetches anyway). */
 
 /* The same on CHANNEL-major embeddings f_cm (b, C, n) -- the decoder's layout; pointnext_AA.py:518-519 makes the point-major
  * copy with flatten(transpose) -- m = b * n anchors in cloud-major order.  C in {16, 32, 64, 128, 256}; unit (b*n, C) is required
  * and receives the point-major unit rows (what amc3d_contrast_backward_mutual reads); no point-major copy of f is made. */
 int amc3d_contrast_forward_cm(int b, int C, int n, int k, int nbr_stride, const float *f_cm, const int *nbr,
                               const unsigned char *posmask, const float *a, const int *sel, float mu, float nu,
-                              float temperature, float *norm, float *unit, float *sim, float *loss_pt, float *mean_cnt,
-                              void *stream);
+                              float temperature, float *norm, float *unit, float *sim, float *stats, float *loss_pt,
+                              float *mean_cnt, void *stream);
 
 /* grad_f (m,C) += grad_out[0] * d(stage loss)/d f; the caller zero-initialises grad_f.
  * grad_out is a DEVICE scalar (no host sync).  C <= 512.  sel as in the forward. */
@@ -245,8 +248,9 @@ int amc3d_contrast_mutual(int m, int k, int nbr_stride, const int *nbr, const fl
 size_t amc3d_contrast_backward_mutual_workspace_bytes(int m);
 int amc3d_contrast_backward_mutual(int m, int C, int k, int nbr_stride, const float *unit, const float *norm, const int *nbr,
                                    const unsigned char *posmask, const float *a, const unsigned char *mutual, const int *rev,
-                                   float mu, float nu, float temperature, const float *sim, const float *mean_cnt,
-                                   const float *grad_out, void *workspace, size_t workspace_bytes, float *grad_f, void *stream);
+                                   float mu, float nu, float temperature, const float *sim, const float *stats /* or NULL */,
+                                   const float *mean_cnt, const float *grad_out, void *workspace, size_t workspace_bytes,
+                                   float *grad_f, void *stream);
 
 /* ---- grouped 1x1 convolution fused with its gather (fp32 MFMA) ------------------------------------
  * Replaces, for the first layer of a SetAbstraction / LocalAggregation MLP, the chain

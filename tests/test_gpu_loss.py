@@ -211,9 +211,9 @@ def test_contrast_backward_over_mutual_edges_on_a_real_knn_graph():
 
 @pytest.mark.parametrize("B,n", [(2, 6000), (3, 1000), (1, 77)])
 def test_contrast_stage_on_channel_major_embeddings(B, n):
-    """ops.contrast_stage_cm reads the decoder's (B, C, n) tensor as it is; loss and gradient are bit for bit those of
-    contrast_stage on flatten(f.transpose(1, 2)) (pointnext_AA.py:518-519) with the mutual-edge plan: same unit rows, same
-    kernels after them, the gradient rows through one tiled transpose.  n = 77, 1000: tiles that end inside a cloud."""
+    """ops.contrast_stage_cm reads the decoder's (B, C, n) tensor as it is; the loss is bit for bit that of contrast_stage on
+    flatten(f.transpose(1, 2)) (pointnext_AA.py:518-519) with the mutual-edge plan (same unit rows, same forward kernel), the
+    gradient equal to rounding and bit-reproducible.  n = 77, 1000: tiles that end inside a cloud."""
     from amcontrast3d_amd import ops, synthetic
     nb = synthetic.make_batch(B, n, first_id=5)
     p = torch.from_numpy(nb["pos"]).reshape(-1, 3).contiguous().to(DEV)
@@ -238,7 +238,13 @@ def test_contrast_stage_on_channel_major_embeddings(B, n):
         lb = ops.contrast_stage(torch.flatten(fb.transpose(1, 2), 0, 1).contiguous(), nidx, posmask, a, -1.0, 0.5, 0.3, anchors, rev, mutual)
         (lb * 0.7).backward()
         assert torch.equal(la, lb), (C, float(la), float(lb))
-        assert torch.equal(fa.grad, fb.grad), (C, float((fa.grad - fb.grad).abs().max()))
+        # (the channel-major stage builds the backward's per-anchor records from the two sums the forward pass kept, the row
+        #  stage re-sums the stored cosines in another order: the gradients agree to rounding, not to the bit)
+        err = float((fa.grad - fb.grad).abs().max()) / float(fb.grad.abs().max())
+        assert err <= 2e-6, (C, err)
+        fa2 = f_cm.clone().requires_grad_(True)
+        (ops.contrast_stage_cm(fa2, nidx, posmask, a, -1.0, 0.5, 0.3, anchors, rev, mutual) * 0.7).backward()
+        assert torch.equal(fa.grad, fa2.grad), "bit-reproducible"
     assert not ops.contrast_stage_supported_cm(torch.randn(B, 20, n, device=DEV), anchors, rev, mutual)  # width without row kernels
 
 
