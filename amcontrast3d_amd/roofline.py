@@ -30,13 +30,15 @@ GEOMETRY_OPS = ("furthest_point_sampling", "ball_query", "three_nn", "knnquery",
                 "select_anchors", "group_csr", "group_moments", "group_points", "contrast_csr")
 # C-ABI operator -> substrings of the kernels it launches (names as rocprofv3 prints them)
 OPERATOR_KERNELS = {
-    "contrast_backward": ("contrast_backward_kernel", "contrast_backward_mutual_kernel", "contrast_record_kernel"),
+    "contrast_backward": ("contrast_backward_kernel", "contrast_backward_mutual_kernel", "contrast_record_kernel",
+                          "contrast_record_stats_kernel"),
     "contrast_backward_csr": ("contrast_backward_rows_kernel", "contrast_coef_kernel"),
     "contrast_forward": ("contrast_forward_unit_kernel", "contrast_forward_kernel", "row_norm_kernel", "row_unit_kernel",
                          "row_unit_cm_kernel", "masked_mean_kernel"),
     "pointwise_conv_forward": ("pw_gemm_kernel", "gm_gemm_kernel", "gb_gemm_kernel", "gm_split_reduce"),
     "pointwise_conv_backward": ("pw_gemm_kernel", "pw_wgrad_kernel", "gw_wgrad_kernel", "gm_gemm_kernel", "gcc_reduce", "gb_gemm_kernel"),
-    "sa_tail_forward": ("sat_kernel", "sat_finalize"), "sa_tail_backward": ("sat_kernel", "sat_bwd"),
+    "sa_tail_forward": ("sat_kernel", "sat_finalize"),
+    "sa_tail_backward": ("sat_kernel", "sat_bwd", "sat_pool_grad", "sat_alg_reduce", "sat_alg_dw"),
     "grouped_conv_bn_forward": ("lagg_stats", "lagg_expand", "lagg_finalize"),
     "grouped_conv_bn_backward": ("csr_collapse", "lagg_collapse", "lagg_bwd"),
     "local_aggregation_forward": ("lagg_stats", "lagg_pool", "lagg_finalize"),
