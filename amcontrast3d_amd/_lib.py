@@ -21,6 +21,7 @@ SIGNATURES = {
     "amc3d_stream_create_masked": (_i, [_vp, _i, _i]),
     "amc3d_stream_create_cu_mask": (_i, [_vp, _vp, _i]),
     "amc3d_probe_xcc_ids": (_i, [_i, _vp, _vp]),
+    "amc3d_reserve_scratch": (_i, [_i, _vp, _vp]),
     "amc3d_stream_destroy": (_i, [_vp]),
     "amc3d_grid_search_workspace_bytes": (_sz, [_i, _i, _i]),
     "amc3d_ball_query": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -91,6 +91,37 @@ AMC_API int amc3d_probe_xcc_ids(int nblocks, int *out, void *stream)
     return amc::launch_status("amc3d_probe_xcc_ids");
 }
 
+// ---- scratch (private segment) high-water mark ---------------------------------------------------------------------------
+// The runtime sizes the device's scratch memory by the largest per-lane request it has seen and re-allocates it when a kernel
+// asks for more.  Graph nodes instantiated before such a re-allocation keep pointing at the old one (ROCm 7.2, measured: a
+// hipGraph with scratch-using kernels -- rocprim's radix sort, 80 bytes per lane -- faults at its next replay once another
+// stream has run, for the first time, a library kernel with a larger private segment: MIOpen's find mode at a new shape does).
+// amc3d_reserve_scratch raises the mark BEFORE graphs are captured: one launch of a kernel with `bytes_per_lane` of private
+// array (256, 1024, 4096 or 16384).
+namespace amc {
+template <int WORDS>
+__global__ void scratch_reserve_kernel(int *__restrict__ out, int salt)
+{
+    volatile int a[WORDS];  // dynamically indexed: stays in scratch
+    for (int i = 0; i < WORDS; ++i) a[i] = i * salt;
+    int s = 0;
+    for (int i = 0; i < WORDS; i += 97) s += a[(i + salt) % WORDS];
+    if (s == 0x7fffffff) out[0] = s;  // (never: keeps the array alive)
+}
+}  // namespace amc
+
+AMC_API int amc3d_reserve_scratch(int bytes_per_lane, int *scratch_out, void *stream)
+{
+    if (!scratch_out) return amc::bad_arg("amc3d_reserve_scratch: needs a device int to (never) write");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(256 * 8), block(256);  // every CU, full occupancy: the runtime sizes scratch for the resident waves
+    if (bytes_per_lane <= 256) hipLaunchKernelGGL(amc::scratch_reserve_kernel<64>, grid, block, 0, st, scratch_out, 3);
+    else if (bytes_per_lane <= 1024) hipLaunchKernelGGL(amc::scratch_reserve_kernel<256>, grid, block, 0, st, scratch_out, 3);
+    else if (bytes_per_lane <= 4096) hipLaunchKernelGGL(amc::scratch_reserve_kernel<1024>, grid, block, 0, st, scratch_out, 3);
+    else hipLaunchKernelGGL(amc::scratch_reserve_kernel<4096>, grid, block, 0, st, scratch_out, 3);
+    return amc::launch_status("amc3d_reserve_scratch");
+}
+
 AMC_API int amc3d_stream_destroy(void *stream)
 {
     if (!stream) return 0;

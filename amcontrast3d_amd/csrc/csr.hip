@@ -10,7 +10,7 @@
 //   amc3d_group_csr            idx (b,m,k) -> rev_start (b*n + 1), rev_edge (b*m*k) positions ordered by (target, position)
 //   amc3d_group_moments_csr    the geometry moments of lagg.hip from the lists (no scattered atomics, exact in-degree)
 //   amc3d_grouped_conv_bn_backward_csr   the collapse pass of the first SetAbstraction layer as a gather
-#include <hipcub/hipcub.hpp>
+#include "cub_kernel_memset.h"  // hipCUB with its memsets as kernels (graph-safe)
 
 #include <stdlib.h>
 
@@ -46,6 +46,90 @@ __global__ void csr_keys_kernel(int n, long P, long E, const int *__restrict__ i
     const int id = idx[e];
     key[e] = (unsigned)(b * n + (id >= 0 && id < n ? id : 0));
     val[e] = (int)(e - b * P);
+}
+
+// ---- the same lists by a counting sort (AMC3D_CSR_COUNTING_SORT=1; 0.43 ms per step against the radix sort's 0.36) ---------
+// Written when the radix sort turned out to be unsafe inside captured graphs (its hipMemsetAsync calls: cub_kernel_memset.h, which
+// is what fixed it); kept as the alternative that needs no library sort.
+__global__ void csr_degree_kernel(int n, long P, long E, const int *__restrict__ idx, int *__restrict__ deg)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const long b = e / P;
+    const int id = idx[e];
+    atomicAdd(deg + b * n + (id >= 0 && id < n ? id : 0), 1);
+}
+
+__global__ void csr_fill_kernel(int n, long P, long E, const int *__restrict__ idx, const int *__restrict__ rev_start,
+                                int *__restrict__ cursor, int *__restrict__ rev_edge)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const long b = e / P;
+    const int id = idx[e];
+    const long g = b * n + (id >= 0 && id < n ? id : 0);
+    rev_edge[rev_start[g] + atomicAdd(cursor + g, 1)] = (int)(e - b * P);
+}
+
+// every list in ascending order of its positions (distinct): lists of up to CSR_SORT_SHORT entries by insertion in place,
+// longer ones (hubs of a ball query) by ranks -- a wave per list, through `temp` -- so that the gathers that walk the lists
+// sum in a fixed order whatever order the fill's atomics produced
+constexpr int CSR_SORT_SHORT = 16;
+__global__ void csr_order_kernel(long G, const int *__restrict__ rev_start, int *__restrict__ rev_edge)
+{
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const int e0 = rev_start[g], d = rev_start[g + 1] - e0;
+    if (d < 2 || d > CSR_SORT_SHORT) return;
+    // the list in registers, padded with INT_MAX, through a bitonic network (static indices: no scratch, no dependent round trips
+    // to global memory -- an in-place insertion sort took 250-340 us per stage: a chain of up to d^2 / 2 loads and stores)
+    int r[CSR_SORT_SHORT];
+#pragma unroll
+    for (int i = 0; i < CSR_SORT_SHORT; ++i) r[i] = i < d ? rev_edge[e0 + i] : 0x7fffffff;
+#pragma unroll
+    for (int k = 2; k <= CSR_SORT_SHORT; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < CSR_SORT_SHORT; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const int lo = min(r[i], r[l]), hi = max(r[i], r[l]);
+                    r[i] = up ? lo : hi;
+                    r[l] = up ? hi : lo;
+                }
+            }
+#pragma unroll
+    for (int i = 0; i < CSR_SORT_SHORT; ++i)
+        if (i < d) rev_edge[e0 + i] = r[i];
+}
+
+__global__ __launch_bounds__(256) void csr_order_long_kernel(long G, const int *__restrict__ rev_start, int *__restrict__ rev_edge,
+                                                             int *__restrict__ temp)
+{
+    const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (g >= G) return;
+    const int e0 = rev_start[g], d = rev_start[g + 1] - e0;
+    if (d <= CSR_SORT_SHORT) return;  // (wave-uniform)
+    if (d <= 64) {  // one entry per lane, ranks by broadcasts inside the wave: no round trip through memory
+        const int v = lane < d ? rev_edge[e0 + lane] : 0x7fffffff;
+        int r = 0;
+        for (int y = 0; y < d; ++y) r += __shfl(v, y, 64) < v;
+        if (lane < d) rev_edge[e0 + r] = v;  // (every lane has loaded before any stores: the shuffles above are the barrier)
+        return;
+    }
+    const int *l = rev_edge + e0;
+    for (int x = lane; x < d; x += 64) {  // rank = number of smaller entries (the positions of a list are distinct)
+        const int v = l[x];
+        int r = 0;
+        for (int y = 0; y < d; ++y) r += l[y] < v;
+        temp[e0 + r] = v;
+    }
+    // (the wave reads back what its own lanes stored: the stores have reached L2 after the fence, and nothing of temp is in this CU's L1)
+    __threadfence();
+    for (int x = lane; x < d; x += 64) rev_edge[e0 + x] = temp[e0 + x];
 }
 
 // rev_start[g] = first sorted edge with key >= g (g = 0 .. G inclusive): binary search, no atomics
@@ -440,6 +524,27 @@ AMC_API int amc3d_group_csr(int b, int n, int npoints, int nsample, const int *i
         return bad_arg("amc3d_group_csr: bad argument");
     hipStream_t stream = (hipStream_t)stream_;
     char *w = (char *)workspace;
+    {   // counting sort on request, wherever the workspace holds its arrays: G + 1 <~ E
+        size_t scan_temp = 0;
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_temp, (const int *)nullptr, (int *)nullptr, (int)(G + 1));
+        const size_t need = 2 * csr_align((size_t)(G + 1) * 4) + csr_align(scan_temp) + csr_align((size_t)E * 4);
+        static const bool counting = getenv("AMC3D_CSR_COUNTING_SORT") != nullptr;
+        if (counting && need <= workspace_bytes) {
+            int *deg = (int *)w; w += csr_align((size_t)(G + 1) * 4);
+            int *cursor = (int *)w; w += csr_align((size_t)(G + 1) * 4);
+            void *st = (void *)w; w += csr_align(scan_temp);
+            int *tmp = (int *)w;
+            if (int s0 = fill_i32(deg, 0, (size_t)(cursor - deg) + G + 1, stream)) return s0;  // deg and cursor, one launch
+            hipLaunchKernelGGL(csr_degree_kernel, dim3(div_up(E, 256)), dim3(256), 0, stream, n, P, E, idx, deg);
+            const hipError_t es = hipcub::DeviceScan::ExclusiveSum(st, scan_temp, (const int *)deg, rev_start, (int)(G + 1), stream);
+            if (es != hipSuccess) { set_error("amc3d_group_csr: scan: %s", hipGetErrorString(es)); return (int)es; }
+            hipLaunchKernelGGL(csr_fill_kernel, dim3(div_up(E, 256)), dim3(256), 0, stream, n, P, E, idx, (const int *)rev_start, cursor,
+                               rev_edge);
+            hipLaunchKernelGGL(csr_order_kernel, dim3(div_up(G, 256)), dim3(256), 0, stream, G, (const int *)rev_start, rev_edge);
+            hipLaunchKernelGGL(csr_order_long_kernel, dim3(div_up(G, 4)), dim3(256), 0, stream, G, (const int *)rev_start, rev_edge, tmp);
+            return launch_status("amc3d_group_csr");
+        }
+    }
     unsigned *key = (unsigned *)w; w += csr_align((size_t)E * 4);
     unsigned *skey = (unsigned *)w; w += csr_align((size_t)E * 4);
     int *val = (int *)w; w += csr_align((size_t)E * 4);

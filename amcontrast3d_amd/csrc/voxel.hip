@@ -10,7 +10,7 @@
 // Arithmetic as numpy does it under numpy 2 (the container's): coord (float32) / np.array(voxel_size) is a float64
 // division (a 0-d array is not a weak scalar), floor in float64, cast to uint64; squared distances in float32 without
 // contraction, ((dx^2 + dy^2) + dz^2).
-#include <hipcub/hipcub.hpp>
+#include "cub_kernel_memset.h"  // hipCUB with its memsets as kernels (graph-safe)
 
 #include "common.h"
 

@@ -51,6 +51,10 @@ int amc3d_stream_create_masked(void **stream, int first_cu, int n_cus);
  * out[b] = the XCD (0-7) workgroup b of an nblocks-wide launch on `stream` ran on */
 int amc3d_stream_create_cu_mask(void **stream, const unsigned int *mask, int words);
 int amc3d_probe_xcc_ids(int nblocks, int *out, void *stream);
+/* Raise the device's scratch (private segment) high-water mark to bytes_per_lane (256 / 1024 / 4096 / 16384) with one launch, BEFORE
+ * graphs are captured: the runtime re-allocates scratch when a kernel asks for more than any before it, and graph nodes
+ * instantiated earlier keep the old allocation (a replay then faults).  scratch_out: any device int (not written). */
+int amc3d_reserve_scratch(int bytes_per_lane, int *scratch_out, void *stream);
 int amc3d_stream_destroy(void *stream);
 
 /* ---- pointnet2_batch surface ------------------------------------------------ */

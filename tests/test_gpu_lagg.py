@@ -151,6 +151,31 @@ def test_grouped_conv_bn_first_block(B, Cin, C, N, M):
         assert err <= 1e-4 * max(1.0, float(want.abs().max())), (name, err, float(want.abs().max()))
 
 
+def test_reverse_lists_of_a_hub_heavy_query_are_ascending():
+    """lists longer than the in-place insertion sort handles (a ball query whose centres crowd around a few points): the rank sort
+    of csr_order_long_kernel; every list ascending, every position exactly once"""
+    from amcontrast3d_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, N, M, K = 2, 3000, 1200, 32
+    idx = torch.randint(0, 12, (B, M, K), generator=g).to(torch.int32)  # twelve hubs: lists of ~3200 positions
+    idx[:, ::7, :] = torch.randint(0, N, (B, len(range(0, M, 7)), K), generator=g).to(torch.int32)
+    start, edge = ops.group_csr(idx.to("cuda:0"), N)
+    s, e, flat = start.cpu().numpy(), edge.cpu().numpy(), idx.reshape(B, -1).numpy()
+    P = M * K
+    assert s[0] == 0 and s[-1] == B * P
+    for b in range(B):
+        assert sorted(e[s[b * N]:s[(b + 1) * N]].tolist()) == list(range(P))
+    longest = 0
+    for gidx in range(B * N):
+        lst = e[s[gidx]:s[gidx + 1]]
+        if len(lst) > 1:
+            assert np.all(np.diff(lst) > 0), gidx
+        b, j = divmod(gidx, N)
+        assert np.all(flat[b][lst] == j)
+        longest = max(longest, len(lst))
+    assert longest > 1000
+
+
 def test_reverse_lists_moments_and_gather_backward():
     """csrc/csr.hip: the reverse adjacency of a ball query (every position exactly once, under its target, ascending), the
     geometry moments derived from it (identical in-degree, dp sums equal to the fixed-point atomics' up to the double
