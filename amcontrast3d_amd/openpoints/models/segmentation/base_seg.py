@@ -67,7 +67,10 @@ class BaseSeg_M_AMContrast3D(nn.Module):
 
     def forward(self, data):
         p, f, stageACE_list = self.encoder.forward(data)
-        if self.name in ('APM_pf_ConCate', 'APM_pf_CrossAtt'):
+        if self.name in ('APM_p', 'APM_p_Group', 'APM_p_Graph', 'APM_pp_SelfAtt'):
+            # position-only predictors (base_seg.py:62-68): one ambiguity per point of p[1..4], no mapped embedding
+            stageACE_list['ambiguity'] = [self.APM.forward(p[i]) for i in range(1, len(p) - 1)]
+        elif self.name in ('APM_pf_ConCate', 'APM_pf_CrossAtt'):
             a, a_map = [], []  # (B*n, 1) ambiguities [and (B*n, D) maps] of the four resolutions p[1..4]
             for i in range(1, len(p) - 1):
                 if self.linear_mapping:
@@ -78,8 +81,7 @@ class BaseSeg_M_AMContrast3D(nn.Module):
                     a.append(self.APM.forward(p[i], f[i]))
             stageACE_list['ambiguity'] = a
             stageACE_list['ambiguity_map'] = a_map
-        else:  # position-only predictors (APM_p*, base_seg.py:62-68): not part of this build
-            raise NotImplementedError(f"APM variant {self.name!r} is not provided; use APM_pf_ConCate")
+        # any other name: no 'ambiguity' entry, and the decoder fails on the missing key as the reference's does
         f, stageACE_list, refine = self.decoder.forward(p, f, stageACE_list, self.linear_mapping, self.cross_attention,
                                                         self.feat_concate, self.nsample_k, self.threshold,
                                                         self.threshold_max, self.gamma, self.fusion, self.num_classes,
