@@ -155,3 +155,15 @@ def test_wrapper_routes_the_variants_like_the_reference():
     model.linear_mapping = True
     with pytest.raises(ValueError, match="unpack"):
         model({})
+
+
+def test_an_apm_module_may_be_the_first_import():
+    """separation.py imports openpoints.models.build, whose package registers the APM classes: the cycle must close in
+    either order (a fresh interpreter, since this process has long imported both)"""
+    import subprocess
+    import sys
+    code = ("import amcontrast3d_amd; amcontrast3d_amd.activate(); "
+            "from openpoints.AMContrast3D.APM.separation import APM_p_Group; "
+            "from openpoints.models import MODELS; "
+            "assert all(MODELS.get(n) is not None for n in ('APM_p', 'APM_p_Group', 'APM_pf_ConCate', 'APM_pf_CrossAtt'))")
+    subprocess.run([sys.executable, "-c", code], check=True, timeout=300)

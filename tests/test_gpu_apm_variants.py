@@ -54,7 +54,9 @@ def test_variants_inside_the_model(name):
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     kw = {"channel": [64, 32, 16, 8, 4, 2], "dropout": [0.2, 0, 0, 0, 0, 0]} if name in ("APM_p", "APM_p_Group") else {}
-    model = build_model_from_cfg(easy(configs.model_cfg_mm("S", dropout=0, width=8, threshold=0.5, NAME=name, **kw))).to(dev).train()
+    cfg = configs.model_cfg_mm("S", dropout=0, width=8, threshold=0.5, NAME=name)
+    cfg["APM_args"].update(kw)  # (the six-entry lists are separation.py's defaults; the yaml block carries ConCate's five)
+    model = build_model_from_cfg(easy(cfg)).to(dev).train()
     criterion = build_criterion_from_cfg(easy(configs.criterion_cfg_mm())).to(dev)
     aa = easy(configs.ambiguity_args_mm("s3dis"))
     data = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.make_batch(2, 2048, first_id=9).items()}
