@@ -207,9 +207,19 @@ __device__ __forceinline__ float csr_bn(float x, float mean, float invstd, float
 //   q[g][c] = sum_e d(e, c),  d = dx1_pm[position e][c] * [relu: bn(G[g][c] + W_dp[c] . dp_e) > 0]
 //   partial sums per channel {sum d, sum d xhat, sum d dp_j}.  dx1_pm is the POSITION-major gradient (b, P, C).
 // grid (point groups, channel chunks of 64, 1); a workgroup takes PTS consecutive source points per wave-group
-constexpr int CSR_BS = 512;   // threads per workgroup: 512 / CT point groups share one partial
-template <int CT>
-__global__ __launch_bounds__(CSR_BS) void csr_collapse_kernel(int C, int n, long P, long G, int relu, const float *__restrict__ dx1_pm,
+// Workgroup shape (BS threads, MINW = the compiler's waves-per-SIMD target).  The software pipeline below wants ~142 registers;
+// a 512-thread workgroup is two waves per SIMD, so at 142 registers only ONE fits a CU (two would need four waves per SIMD =
+// 128 registers): 8 waves per CU for a kernel that is a chain of memory round trips -- found at the end of round 3 by listing
+// registers x workgroup size for every kernel (the occupancy the compiler prints, 3, is per wave, not per workgroup).
+// AMC3D_CSR_SHAPE (measured on PointNeXt-S' four launches, real room-like neighbourhoods, 4096 workgroups; SA1 / SA2-4 avg):
+//   0: this kernel, 512 threads, 142 registers -> 8 waves per CU                                   210 / 61 us  (step 6.10 ms)
+//   1: 512 threads capped at 128 registers (15 spilled) -> 16 waves per CU                          slower than 0
+//   2: 256 threads, 142 registers, three per CU -> 12 waves per CU                                  (synthetic lists: 182 -> 128)
+//   3: csr_collapse_shfl_kernel: records distributed over the lanes, 104 registers -> 16 waves     164 / 46 us  (step 5.985)
+//   5: csr_collapse_stream_kernel: the group's edge range as one stream                            153 / 55 us  (step 6.008)
+//   6 (default): the stream kernel below 64 channels, the shfl kernel from 64 up                    153 / 46 us  (step 5.97)
+template <int CT, int CSR_BS, int MINW>
+__global__ __launch_bounds__(CSR_BS, MINW) void csr_collapse_kernel(int C, int n, long P, long G, int relu, const float *__restrict__ dx1_pm,
                                                            const float *__restrict__ g_pm, const int *__restrict__ rev_start,
                                                            const int *__restrict__ rev_edge, const float *__restrict__ dp,
                                                            const float *__restrict__ w_dp, const float *__restrict__ mean,
@@ -341,6 +351,198 @@ __global__ __launch_bounds__(CSR_BS) void csr_collapse_kernel(int C, int n, long
     red[grp][cl][0] = a0; red[grp][cl][1] = a1; red[grp][cl][2] = a2; red[grp][cl][3] = a3; red[grp][cl][4] = a4;
     __syncthreads();
     for (int t = threadIdx.x; t < CT * 5; t += CSR_BS) {
+        const int k = t / 5, v = t - k * 5;
+        double sum = 0.0;
+        for (int gq = 0; gq < GROUPS; ++gq) sum += red[gq][k][v];
+        partial[((size_t)blockIdx.x * C + c0 + k) * 5 + v] = sum;
+    }
+}
+
+
+// The same pass with the edge records DISTRIBUTED over the lanes of a group instead of replicated in every lane: the 32 (16, 64)
+// lanes of a group all held the same eight float4 records of this point and of the next one -- 64 registers of the 142.  Here
+// lane l keeps record (l & 7) of each, and the group reads a record's fields by a lane shuffle when it uses them (32 shuffles
+// per point on the otherwise idle LDS pipe): ~90 registers, five waves per SIMD instead of three for a kernel whose time is
+// round trips per wave.  Same sums in the same order as csr_collapse_kernel (bit-identical Q and partials for an equal shape).
+template <int CT, int MINW>
+__global__ __launch_bounds__(256, MINW) void csr_collapse_shfl_kernel(int C, int n, long P, long G, int relu, const float *__restrict__ dx1_pm,
+                                                                     const float *__restrict__ g_pm, const int *__restrict__ rev_start,
+                                                                     const float *__restrict__ w_dp, const float *__restrict__ mean,
+                                                                     const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                                     const float *__restrict__ beta, float *__restrict__ Q,
+                                                                     double *__restrict__ partial, int pts_per_group,
+                                                                     const float4 *__restrict__ rev_dp)
+{
+    constexpr int BS = 256, GROUPS = BS / CT;
+    __shared__ double red[GROUPS][CT][5];
+    const int c0 = blockIdx.y * 64;
+    const int cl = threadIdx.x % CT, grp = threadIdx.x / CT;
+    const int c = c0 + cl;
+    const int slot = cl & 7;  // the record of a batch of eight that this lane keeps
+    const float w0 = w_dp[c * 3 + 0], w1 = w_dp[c * 3 + 1], w2 = w_dp[c * 3 + 2];
+    const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+    const long g_begin = ((long)blockIdx.x * GROUPS + grp) * pts_per_group;
+    const long E = G > 0 ? (long)rev_start[G] : 0;
+    auto bounds = [&](long g_, int &s_, int &e_) {
+        const bool in = g_ < G && g_ < g_begin + pts_per_group;
+        s_ = in ? rev_start[g_] : 0;
+        e_ = in ? rev_start[g_ + 1] : 0;
+    };
+    auto record = [&](int j0, int e_) {  // record j0 + slot of a list that ends at e_ (clamped: unused slots read a valid record)
+        long j = min(j0 + slot, e_ - 1);
+        j = j < 0 ? 0 : (j >= E ? E - 1 : j);
+        return E > 0 ? rev_dp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    int s0, e0_, s1, e1_, s2, e2_;
+    bounds(g_begin, s0, e0_);
+    bounds(g_begin + 1, s1, e1_);
+    float4 rec = record(s0, e0_);
+    float gv = g_begin < G ? g_pm[g_begin * C + c] : 0.f;
+    for (int i = 0; i < pts_per_group; ++i) {
+        const long g = g_begin + i;
+        if (g >= G) break;  // uniform over the group (g does not depend on the lane), and a group never straddles two waves
+        const int b = (int)(g / n);
+        const float *xrow = dx1_pm + (long)b * P * C + c;
+        float d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d[u] = xrow[(long)__shfl(__float_as_int(rec.w), u, CT) * C];   // rows of point i
+        const float4 recn = record(s1, e1_);                                                          // records of point i + 1
+        bounds(g + 2, s2, e2_);                                                                       // bounds of point i + 2
+        const float gvn = (g + 1 < G) ? g_pm[(g + 1) * C + c] : 0.f;
+        float q = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, q4 = 0.f;
+        auto edge = [&](float rx, float ry, float rz, float dv, bool live) {
+            const float y = __fmaf_rn(w0, rx, __fmaf_rn(w1, ry, __fmaf_rn(w2, rz, gv)));
+            const float xh = __fmul_rn(__fsub_rn(y, mu), is);
+            if (!live || (relu && !(__fadd_rn(__fmul_rn(xh, ga), be) > 0.f))) dv = 0.f;
+            q += dv;
+            q1 = __fmaf_rn(dv, xh, q1); q2 = __fmaf_rn(dv, rx, q2); q3 = __fmaf_rn(dv, ry, q3); q4 = __fmaf_rn(dv, rz, q4);
+        };
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            edge(__shfl(rec.x, u, CT), __shfl(rec.y, u, CT), __shfl(rec.z, u, CT), d[u], s0 + u < e0_);
+        for (int j0 = s0 + 8; j0 < e0_; j0 += 8) {  // the rest of a long list
+            const float4 r = record(j0, e0_);
+            float dd[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dd[u] = xrow[(long)__shfl(__float_as_int(r.w), u, CT) * C];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                edge(__shfl(r.x, u, CT), __shfl(r.y, u, CT), __shfl(r.z, u, CT), dd[u], j0 + u < e0_);
+        }
+        a0 += (double)q; a1 += (double)q1; a2 += (double)q2; a3 += (double)q3; a4 += (double)q4;
+        Q[g * C + c] = q;
+        s0 = s1; e0_ = e1_; s1 = s2; e1_ = e2_; gv = gvn;
+        rec = recn;
+    }
+    red[grp][cl][0] = a0; red[grp][cl][1] = a1; red[grp][cl][2] = a2; red[grp][cl][3] = a3; red[grp][cl][4] = a4;
+    __syncthreads();
+    for (int t = threadIdx.x; t < CT * 5; t += BS) {
+        const int k = t / 5, v = t - k * 5;
+        double sum = 0.0;
+        for (int gq = 0; gq < GROUPS; ++gq) sum += red[gq][k][v];
+        partial[((size_t)blockIdx.x * C + c0 + k) * 5 + v] = sum;
+    }
+}
+
+
+// The same pass as a STREAM over the edges of a lane group.  The lists of a group's consecutive points are one contiguous range
+// of rev_dp, so the group walks that range in chunks of eight edges whatever the lengths of the lists: a ball query pads a
+// sparse neighbourhood with repeats of its first point, which makes hubs (lists of 20-200 edges among lists of ~8), and the
+// point-by-point kernels above serve everything past a list's first eight edges with two dependent round trips per eight
+// edges (SA1 of PointNeXt-S on room-like clouds: 250 us against 110 us on lists of even length, tools/csr_bench.py).
+// Here chunk k is multiplied while the rows of chunk k + 1 and the records of chunk k + 2 are in flight; which point an edge
+// belongs to is a walk over the group's list ends (LDS), and a point's sums are closed when the walk leaves it.  The cloud of
+// edge j is j / P (every position of a cloud appears in exactly one list), tracked by comparison.
+// Sums, their order and the partials' layout are those of csr_collapse_kernel.  pts_per_group <= CSR_STREAM_PMAX.
+constexpr int CSR_STREAM_PMAX = 16;
+template <int CT>
+__global__ __launch_bounds__(256) void csr_collapse_stream_kernel(int C, long P, long G, int relu, const float *__restrict__ dx1_pm,
+                                                                  const float *__restrict__ g_pm, const int *__restrict__ rev_start,
+                                                                  const float *__restrict__ w_dp, const float *__restrict__ mean,
+                                                                  const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                                  const float *__restrict__ beta, float *__restrict__ Q,
+                                                                  double *__restrict__ partial, int pts_per_group,
+                                                                  const float4 *__restrict__ rev_dp)
+{
+    constexpr int BS = 256, GROUPS = BS / CT;
+    __shared__ double red[GROUPS][CT][5];
+    __shared__ float s_gv[GROUPS][CSR_STREAM_PMAX][CT];
+    __shared__ int s_bnd[GROUPS][CSR_STREAM_PMAX + 1];
+    const int c0 = blockIdx.y * 64;
+    const int cl = threadIdx.x % CT, grp = threadIdx.x / CT;
+    const int c = c0 + cl;
+    const int slot = cl & 7;
+    const float w0 = w_dp[c * 3 + 0], w1 = w_dp[c * 3 + 1], w2 = w_dp[c * 3 + 2];
+    const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+    const long g_begin = ((long)blockIdx.x * GROUPS + grp) * pts_per_group;
+    const int npts = (int)max(0L, min((long)pts_per_group, G - g_begin));
+    const long E = G > 0 ? (long)rev_start[G] : 0;
+    if (npts > 0)
+        for (int i = cl; i <= npts; i += CT) s_bnd[grp][i] = rev_start[g_begin + i];
+    for (int i = 0; i < npts; ++i) s_gv[grp][i][cl] = g_pm[(g_begin + i) * C + c];
+    __syncthreads();
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+    if (npts > 0) {  // (uniform over the group; a group never straddles two waves)
+        const int e_first = s_bnd[grp][0], e_last = s_bnd[grp][npts];
+        const int nchunks = (e_last - e_first + 7) >> 3;
+        auto record = [&](int k_) {  // record slot of chunk k_ (clamped: a slot past the range reads a valid record it does not use)
+            long j = min((long)e_first + 8L * k_ + slot, (long)e_last - 1);
+            j = j < 0 ? 0 : (j >= E ? E - 1 : j);
+            return E > 0 ? rev_dp[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        // cloud of the edges, at the row-issue stage (one chunk ahead of the sums)
+        // (a group of trailing points without edges starts at e_first = E: it has no chunk and must not form an address there)
+        const long cloud0 = (long)e_first / P < (E - 1) / P ? (long)e_first / P : (E - 1) / P;
+        long cloud_end = (cloud0 + 1) * P;               // first edge of the next cloud
+        const float *xbase = dx1_pm + cloud0 * P * C + c;
+        auto rows = [&](const float4 &r_, int k_, float *d_) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long j = (long)e_first + 8L * k_ + u;
+                while (j >= cloud_end && j < e_last) { cloud_end += P; xbase += P * C; }
+                d_[u] = xbase[(long)__shfl(__float_as_int(r_.w), u, CT) * C];
+            }
+        };
+        // the point whose sums are open, at the summing stage
+        int pi = 0, cur_end = s_bnd[grp][1];
+        float gv = s_gv[grp][0][cl];
+        float q = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, q4 = 0.f;
+        auto close_point = [&]() {
+            a0 += (double)q; a1 += (double)q1; a2 += (double)q2; a3 += (double)q3; a4 += (double)q4;
+            Q[(g_begin + pi) * C + c] = q;
+            q = q1 = q2 = q3 = q4 = 0.f;
+            ++pi;
+            if (pi < npts) { gv = s_gv[grp][pi][cl]; cur_end = s_bnd[grp][pi + 1]; }
+        };
+        float4 rec0 = record(0), rec1 = record(1);
+        float d0[8], d1[8];
+        if (nchunks > 0) rows(rec0, 0, d0);
+        for (int k = 0; k < nchunks; ++k) {
+            const float4 rec2 = record(k + 2);
+            if (k + 1 < nchunks) rows(rec1, k + 1, d1);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = e_first + 8 * k + u;
+                const bool live = j < e_last;
+                while (live && j >= cur_end) close_point();  // (also steps over points with no edges: their Q is 0)
+                const float rx = __shfl(rec0.x, u, CT), ry = __shfl(rec0.y, u, CT), rz = __shfl(rec0.z, u, CT);
+                const float y = __fmaf_rn(w0, rx, __fmaf_rn(w1, ry, __fmaf_rn(w2, rz, gv)));
+                const float xh = __fmul_rn(__fsub_rn(y, mu), is);
+                float dv = d0[u];
+                if (!live || (relu && !(__fadd_rn(__fmul_rn(xh, ga), be) > 0.f))) dv = 0.f;
+                q += dv;
+                q1 = __fmaf_rn(dv, xh, q1); q2 = __fmaf_rn(dv, rx, q2); q3 = __fmaf_rn(dv, ry, q3); q4 = __fmaf_rn(dv, rz, q4);
+            }
+            rec0 = rec1; rec1 = rec2;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d0[u] = d1[u];
+        }
+        while (pi < npts) close_point();  // the open point and the empty ones behind it
+    }
+    red[grp][cl][0] = a0; red[grp][cl][1] = a1; red[grp][cl][2] = a2; red[grp][cl][3] = a3; red[grp][cl][4] = a4;
+    __syncthreads();
+    for (int t = threadIdx.x; t < CT * 5; t += BS) {
         const int k = t / 5, v = t - k * 5;
         double sum = 0.0;
         for (int gq = 0; gq < GROUPS; ++gq) sum += red[gq][k][v];
@@ -673,13 +875,18 @@ AMC_API int amc3d_group_moments_csr(int b, int n, int npoints, int nsample, cons
     return launch_status("amc3d_group_moments_csr");
 }
 
+static int csr_shape()
+{
+    static const int v = getenv("AMC3D_CSR_SHAPE") ? atoi(getenv("AMC3D_CSR_SHAPE")) : 6;
+    return v;
+}
+static int csr_bs() { return csr_shape() >= 2 ? 256 : 512; }
+
 static int csr_pts_per_group(long G, int groups_per_wg)
 {
-    // ~4096 workgroups of 512 threads (round 3; 2048 of 1024 before: 437 -> 399 us for the step's four launches, measured with
-    // the loop over a group's points software-pipelined -- which needs more than the 128 registers a 1024-thread workgroup
-    // leaves): a group walks its points one after the other (three dependent round trips each:
-    // list bounds, edge ids, rows), so what counts is FEW points per group -- 3 at SA1 instead of 12: 265 -> 160 us -- while
-    // the number of partial sums (one per workgroup) stays where the finalize kernel reads them quickly
+    // ~4096 workgroups (round 3; 2048 of 1024 threads before): a group walks its points one after the other, so what counts is
+    // FEW points per group -- 3-6 at SA1 instead of 12 -- while the number of partial sums (one per workgroup) stays where the
+    // finalize kernel reads them quickly (2048: 13 us per finalize instead of 19, but the step is 0.05 ms slower; 8192: slower)
     static const long wgs = getenv("AMC3D_CSR_WGS") ? atol(getenv("AMC3D_CSR_WGS")) : 4096L;
     long per = (G + wgs * groups_per_wg - 1) / (wgs * groups_per_wg);
     return (int)(per < 1 ? 1 : per);
@@ -689,7 +896,7 @@ namespace amc {
 size_t csr_partials(int b, int cout, int n)
 {
     const int ct = cout < 64 ? cout : 64;
-    const int groups = CSR_BS / ct;
+    const int groups = csr_bs() / ct;
     const long G = (long)b * n;
     const int per = csr_pts_per_group(G, groups);
     return (size_t)div_up(G, (long)groups * per);
@@ -707,15 +914,36 @@ int csr_collapse(int b, int cout, int n, int npoints, int nsample, int relu, con
 {
     const long P = (long)npoints * nsample, G = (long)b * n;
     const int ct = cout < 64 ? cout : 64;
-    const int groups = CSR_BS / ct;
+    const int bs = csr_bs(), shape = csr_shape();
+    const int groups = bs / ct;
     const int per = csr_pts_per_group(G, groups);
     const int wgs = div_up(G, (long)groups * per);
     *nparts = wgs;
+#define AMC_CSR_(CTV, BS, MINW)                                                                                               \
+    hipLaunchKernelGGL((csr_collapse_kernel<CTV, BS, MINW>), dim3(wgs, cout / ct), dim3(BS), 0, stream, cout, n, P, G, relu,    \
+                       dx1_pm, g_pm, rev_start, rev_edge, dp, w_dp, mean, invstd, gamma, beta, Q, partial, per,                \
+                       (const float4 *)rev_dp)
 #define AMC_CSR(CTV)                                                                                                          \
-    hipLaunchKernelGGL(csr_collapse_kernel<CTV>, dim3(wgs, cout / ct), dim3(CSR_BS), 0, stream, cout, n, P, G, relu, dx1_pm, g_pm, \
-                       rev_start, rev_edge, dp, w_dp, mean, invstd, gamma, beta, Q, partial, per, (const float4 *)rev_dp)
+    do {                                                                                                                      \
+        if ((shape == 5 || (shape == 6 && CTV < 64)) && rev_dp && per <= CSR_STREAM_PMAX)                                     \
+            hipLaunchKernelGGL((csr_collapse_stream_kernel<CTV>), dim3(wgs, cout / ct), dim3(256), 0, stream, cout, P, G, relu, \
+                               dx1_pm, g_pm, rev_start, w_dp, mean, invstd, gamma, beta, Q, partial, per,                      \
+                               (const float4 *)rev_dp);                                                                       \
+        else if (shape == 4 && rev_dp)                                                                                        \
+            hipLaunchKernelGGL((csr_collapse_shfl_kernel<CTV, 5>), dim3(wgs, cout / ct), dim3(256), 0, stream, cout, n, P, G,  \
+                               relu, dx1_pm, g_pm, rev_start, w_dp, mean, invstd, gamma, beta, Q, partial, per,                \
+                               (const float4 *)rev_dp);                                                                       \
+        else if (shape >= 3 && rev_dp)                                                                                        \
+            hipLaunchKernelGGL((csr_collapse_shfl_kernel<CTV, 1>), dim3(wgs, cout / ct), dim3(256), 0, stream, cout, n, P, G,  \
+                               relu, dx1_pm, g_pm, rev_start, w_dp, mean, invstd, gamma, beta, Q, partial, per,                \
+                               (const float4 *)rev_dp);                                                                       \
+        else if (shape == 1) AMC_CSR_(CTV, 512, 4);                                                                           \
+        else if (shape >= 2) AMC_CSR_(CTV, 256, 1);                                                                           \
+        else AMC_CSR_(CTV, 512, 1);                                                                                           \
+    } while (0)
     switch (ct) { case 8: AMC_CSR(8); break; case 16: AMC_CSR(16); break; case 32: AMC_CSR(32); break; default: AMC_CSR(64); }
 #undef AMC_CSR
+#undef AMC_CSR_
     return launch_status("csr_collapse");
 }
 }  // namespace amc

@@ -151,6 +151,38 @@ def test_grouped_conv_bn_first_block(B, Cin, C, N, M):
         assert err <= 1e-4 * max(1.0, float(want.abs().max())), (name, err, float(want.abs().max()))
 
 
+@pytest.mark.parametrize("B,Cin,C,N,M,radius", [(3, 8, 8, 1111, 277, 0.06), (2, 16, 16, 2000, 500, 0.05), (3, 32, 32, 1501, 375, 0.07),
+                                                (2, 32, 32, 6000, 1500, 0.35), (3, 64, 64, 1203, 300, 0.06), (2, 128, 128, 640, 160, 0.1)])
+def test_gather_backward_on_hubs_and_empty_lists(B, Cin, C, N, M, radius):
+    """GroupedConvBN's backward over reverse lists (csrc/csr.hip: the streaming kernel below 64 channels, the point-by-point one
+    with lane-distributed records from 64 up) against its float-atomic form, on neighbourhoods as a ball query makes them in a
+    sparse cloud: balls with a handful of points are padded with repeats of their first point (lists of 30-200 edges among
+    lists of a few) and many points are in no ball at all (empty lists); cloud sizes that no group size divides.  Every
+    channel width that selects another kernel instance; with and without the (dp, position) records in list order."""
+    from amcontrast3d_amd import ops
+    K = 32
+    p, idx, dp, f, w, gamma, beta, _ = _case(B, Cin, C, N, M, K, 5 + C + N, True, radius=radius)
+    start, edge = ops.group_csr(idx, N)
+    deg = np.diff(start.cpu().numpy())
+    if radius < 0.2:
+        assert deg.max() >= 30 and (deg == 0).mean() > 0.2, (deg.max(), (deg == 0).mean())
+    go = torch.randn(B, C, M, K, generator=torch.Generator().manual_seed(4)).to(f.device)
+    mom = ops.group_moments(idx, dp, N)
+    edge_dp = ops.group_csr_dp(idx, dp, edge)
+    grads = []
+    for csr in (None, (start, edge), (start, edge, edge_dp)):
+        fr, wr, gr, br = (t.clone().requires_grad_(True) for t in (f, w, gamma, beta))
+        x1 = ops.GroupedConvBN.apply(fr, dp, idx, mom, wr, gr, br, 1e-5, True, None, csr)
+        x1.backward(go)
+        grads.append([t.grad.clone() for t in (fr, wr, gr, br)])
+    for a, b_ in zip(grads[0], grads[2]):
+        assert float((a - b_).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
+    assert all(torch.equal(a, b_) for a, b_ in zip(grads[1], grads[2]))  # the two list formats: the same sums in the same order
+    # empty lists: exactly zero feature gradient there, in every form
+    none = torch.from_numpy((deg == 0).reshape(B, N)).to(f.device)
+    assert float(grads[2][0].transpose(1, 2)[none].abs().max()) == 0.0
+
+
 def test_reverse_lists_of_a_hub_heavy_query_are_ascending():
     """lists longer than the in-place insertion sort handles (a ball query whose centres crowd around a few points): the rank sort
     of csr_order_long_kernel; every list ascending, every position exactly once"""
