@@ -213,7 +213,7 @@ __device__ __forceinline__ float csr_bn(float x, float mean, float invstd, float
 // registers x workgroup size for every kernel (the occupancy the compiler prints, 3, is per wave, not per workgroup).
 // AMC3D_CSR_SHAPE (measured on PointNeXt-S' four launches, real room-like neighbourhoods, 4096 workgroups; SA1 / SA2-4 avg):
 //   0: this kernel, 512 threads, 142 registers -> 8 waves per CU                                   210 / 61 us  (step 6.10 ms)
-//   1: 512 threads capped at 128 registers (15 spilled) -> 16 waves per CU                          slower than 0
+//   (512 threads capped at 128 registers -- 15 spilled, 16 waves per CU -- and the shfl kernel capped at 96: slower, removed)
 //   2: 256 threads, 142 registers, three per CU -> 12 waves per CU                                  (synthetic lists: 182 -> 128)
 //   3: csr_collapse_shfl_kernel: records distributed over the lanes, 104 registers -> 16 waves     164 / 46 us  (step 5.985)
 //   5: csr_collapse_stream_kernel: the group's edge range as one stream                            153 / 55 us  (step 6.008)
@@ -364,8 +364,8 @@ __global__ __launch_bounds__(CSR_BS, MINW) void csr_collapse_kernel(int C, int n
 // lane l keeps record (l & 7) of each, and the group reads a record's fields by a lane shuffle when it uses them (32 shuffles
 // per point on the otherwise idle LDS pipe): ~90 registers, five waves per SIMD instead of three for a kernel whose time is
 // round trips per wave.  Same sums in the same order as csr_collapse_kernel (bit-identical Q and partials for an equal shape).
-template <int CT, int MINW>
-__global__ __launch_bounds__(256, MINW) void csr_collapse_shfl_kernel(int C, int n, long P, long G, int relu, const float *__restrict__ dx1_pm,
+template <int CT>
+__global__ __launch_bounds__(256) void csr_collapse_shfl_kernel(int C, int n, long P, long G, int relu, const float *__restrict__ dx1_pm,
                                                                      const float *__restrict__ g_pm, const int *__restrict__ rev_start,
                                                                      const float *__restrict__ w_dp, const float *__restrict__ mean,
                                                                      const float *__restrict__ invstd, const float *__restrict__ gamma,
@@ -929,15 +929,10 @@ int csr_collapse(int b, int cout, int n, int npoints, int nsample, int relu, con
             hipLaunchKernelGGL((csr_collapse_stream_kernel<CTV>), dim3(wgs, cout / ct), dim3(256), 0, stream, cout, P, G, relu, \
                                dx1_pm, g_pm, rev_start, w_dp, mean, invstd, gamma, beta, Q, partial, per,                      \
                                (const float4 *)rev_dp);                                                                       \
-        else if (shape == 4 && rev_dp)                                                                                        \
-            hipLaunchKernelGGL((csr_collapse_shfl_kernel<CTV, 5>), dim3(wgs, cout / ct), dim3(256), 0, stream, cout, n, P, G,  \
-                               relu, dx1_pm, g_pm, rev_start, w_dp, mean, invstd, gamma, beta, Q, partial, per,                \
-                               (const float4 *)rev_dp);                                                                       \
         else if (shape >= 3 && rev_dp)                                                                                        \
-            hipLaunchKernelGGL((csr_collapse_shfl_kernel<CTV, 1>), dim3(wgs, cout / ct), dim3(256), 0, stream, cout, n, P, G,  \
+            hipLaunchKernelGGL((csr_collapse_shfl_kernel<CTV>), dim3(wgs, cout / ct), dim3(256), 0, stream, cout, n, P, G,  \
                                relu, dx1_pm, g_pm, rev_start, w_dp, mean, invstd, gamma, beta, Q, partial, per,                \
                                (const float4 *)rev_dp);                                                                       \
-        else if (shape == 1) AMC_CSR_(CTV, 512, 4);                                                                           \
         else if (shape >= 2) AMC_CSR_(CTV, 256, 1);                                                                           \
         else AMC_CSR_(CTV, 512, 1);                                                                                           \
     } while (0)
