@@ -78,6 +78,14 @@ class ConfusionMatrix:
             self.invalid = torch.zeros(1, dtype=torch.int64, device=logits.device) + self.invalid
         ops.confusion_update(self._full, self.invalid, logits, true, self.ignore_index)
 
+    @torch.no_grad()
+    def add_counts(self, full, invalid):
+        """counts collected elsewhere in update_from_logits' layout -- full (v, v) int64 with the ignore row / column last,
+        invalid (1) int64 -- e.g. by the captured training step (amcontrast3d_amd/train.py); the tensors are not kept"""
+        self.value = self.value + full[:self.num_classes, :self.num_classes]
+        self.invalid = self.invalid + invalid.sum()
+        self._full = None
+
     def check(self):
         """raise if update() met a label / prediction outside the class range (reads one scalar back)"""
         n = int(self.invalid)

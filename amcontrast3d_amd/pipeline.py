@@ -189,9 +189,13 @@ class GraphPipeline:
 
     def __init__(self, model, step_loss, head, optimizer, example, num_classes, ignore_index, ambiguity_args, *,
                  lanes=0, max_grad_norm=None, flat_grads=None, sync_bn=False, keep_state=True, geometry_cus=None,
-                 amp_dtype=None, verbose=False):
+                 amp_dtype=None, verbose=False, tail=None):
         from . import ops
         self.model, self.step_loss, self.head, self.opt = model, step_loss, head, optimizer
+        # tail(out, data): the caller's per-iteration bookkeeping on device (confusion matrix, loss sums: train.py) recorded as the
+        # tail of the feature graph, into tensors the caller owns -- eager launches between two replays cost the training stream
+        # more than their kernels (0.11 ms per step for two small ones).  It also runs in the warm-up passes: reset afterwards.
+        self.tail = tail
         self.ncls, self.ignore, self.aargs = num_classes, ignore_index, ambiguity_args
         self.clip, self.flatg, self.sync_bn, self.amp_dtype = max_grad_norm, flat_grads, sync_bn, amp_dtype
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -246,6 +250,9 @@ class GraphPipeline:
         if self.flatg is not None:
             self.flatg.gather()
         out.update(logits=logits, loss=loss, parts=parts)
+        if self.tail is not None:
+            with torch.no_grad():
+                self.tail(out, data)
 
     def _update(self):
         if type(self.opt).__name__ == "FusedAdamW":  # clip_grad_norm_ + AdamW as two launches (csrc/optim.hip)

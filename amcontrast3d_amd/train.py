@@ -91,10 +91,10 @@ def _cfg(cfg, key, default=None):
     return cfg.get(key, default) if hasattr(cfg, "get") else getattr(cfg, key, default)
 
 
-def _graph_pipeline(model, criterion, optimizer, cfg, step_loss, first, clip):
+def _graph_pipeline(model, criterion, optimizer, cfg, step_loss, first, clip, extras=0):
     """the GraphPipeline of this (model, optimizer, criterion, batch shape), built from batch `first` at first use"""
     import torch.distributed as tdist
-    key = (id(model), id(optimizer), id(criterion), tuple(first["pos"].shape), tuple(sorted(k for k, v in first.items() if torch.is_tensor(v))))
+    key = (id(model), id(optimizer), id(criterion), tuple(first["pos"].shape), tuple(sorted(k for k, v in first.items() if torch.is_tensor(v))), extras)
     hit = _PIPELINES.get(key)
     if hit is None:
         dev = first["pos"].device
@@ -105,11 +105,24 @@ def _graph_pipeline(model, criterion, optimizer, cfg, step_loss, first, clip):
             from .dist import FlatGradients
             flat = FlatGradients([p for p in model.parameters() if p.requires_grad], accumulate=False)
             sync_bn = any(isinstance(m, torch.nn.SyncBatchNorm) for m in model.modules())
+        # the epoch's device-side bookkeeping (main_AA.py:414-416: cm.update, loss_meter.update) as the tail of the captured step
+        from . import ops
+        v = cfg.num_classes + (1 if cfg.ignore_index is not None else 0)
+        book = {"cm": torch.zeros(v, v, dtype=torch.int64, device=dev), "invalid": torch.zeros(1, dtype=torch.int64, device=dev),
+                "loss": torch.zeros(1 + extras, dtype=torch.float64, device=dev)}
+
+        def tail(out, data):
+            ops.confusion_update(book["cm"], book["invalid"], out["logits"], data["y"], cfg.ignore_index)
+            terms = [out["loss"].detach().reshape(1)] + [t.detach().reshape(1) for t in out["parts"]]
+            book["loss"].add_(terms[0] if len(terms) == 1 else torch.cat(terms))  # one launch (fp32 -> fp64 inside it)
+        if v > 64 or os.environ.get("AMC3D_EAGER_BOOKKEEPING"):  # (ops.confusion_update's histogram holds 64 x 64 bins)
+            tail = None
         with torch.cuda.stream(main):
             pipe = GraphPipeline(model, lambda data: step_loss(data, data["y"]), criterion.contrast_head, optimizer, first,
                                  cfg.num_classes, cfg.ignore_index, cfg.ambiguity_args, max_grad_norm=clip, flat_grads=flat,
-                                 sync_bn=sync_bn, lanes=int(_cfg(cfg, "fps_lanes", 0) or 0))
-        hit = _PIPELINES[key] = (pipe, main)
+                                 sync_bn=sync_bn, lanes=int(_cfg(cfg, "fps_lanes", 0) or 0),
+                                 tail=tail)
+        hit = _PIPELINES[key] = (pipe, main, book)
     return hit
 
 
@@ -136,7 +149,7 @@ def _run_epoch(model, train_loader, criterion, optimizer, scheduler, scaler, epo
             graphs_ok = False
             batches = iter(())
     if graphs_ok:
-        pipe, main = _graph_pipeline(model, criterion, optimizer, cfg, step_loss, first, clip)
+        pipe, main, book = _graph_pipeline(model, criterion, optimizer, cfg, step_loss, first, clip, extras)
         shape = tuple(first["pos"].shape)
         odd = []  # batches of another shape (a ragged last batch): trained eagerly after the pipeline has drained
 
@@ -149,15 +162,24 @@ def _run_epoch(model, train_loader, criterion, optimizer, scheduler, scaler, epo
         cur = torch.cuda.current_stream(device)
         main.wait_stream(cur)
         with torch.cuda.stream(main):
+            in_graph = pipe.tail is not None
+            if in_graph:  # the captured step keeps the books (warm-up passes and earlier epochs have written to them)
+                book["cm"].zero_()
+                book["invalid"].zero_()
+                book["loss"].zero_()
             for out in pipe.run(same_shape(itertools.chain([first], batches))):
                 if not cfg.sched_on_epoch:
                     scheduler.step(epoch)
-                cm.update_from_logits(out["logits"], out["target"])
-                if extras:
-                    loss_sum.add_(torch.stack([out["loss"].detach()] + [v.detach() for v in out["parts"]]))
-                else:
-                    loss_sum.add_(out["loss"].detach().reshape(1))  # one launch (the fp32 -> fp64 promotion happens in it)
+                if not in_graph:
+                    cm.update_from_logits(out["logits"], out["target"])
+                    if extras:
+                        loss_sum.add_(torch.stack([out["loss"].detach()] + [v.detach() for v in out["parts"]]))
+                    else:
+                        loss_sum.add_(out["loss"].detach().reshape(1))  # one launch (the fp32 -> fp64 promotion happens in it)
                 n_batches += 1
+            if in_graph and n_batches:
+                cm.add_counts(book["cm"], book["invalid"])
+                loss_sum.add_(book["loss"][:loss_sum.numel()])
         cur.wait_stream(main)
         batches = iter(odd)
     elif head is not None and prefetch_depth > 0 and not use_amp:
