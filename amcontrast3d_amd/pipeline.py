@@ -209,12 +209,14 @@ class GraphPipeline:
         self.lanes = J = max(2, lanes if lanes > 0 else self._choose_lanes(example, verbose))
         # hardware queues of their own for the two background chains (ordinary streams share four queues round-robin and
         # whatever shares a queue with a running FPS kernel waits milliseconds for it); the geometry queue is confined
-        # to 10/16 of the CUs for clouds the register-resident FPS kernel handles (<= 24576 points; measured: its kernels
+        # to 11/16 of the CUs for clouds the register-resident FPS kernel handles (<= 24576 points; measured: its kernels
         # are background work with slack and slow the feature half more than they gain when they spread over the chip)
         ncu = torch.cuda.get_device_properties(self.dev).multi_processor_count
         if geometry_cus is None:
             import os
-            sixteenths = int(os.environ.get("AMC3D_GEO_CUS_16THS", "10"))  # (sweeps)
+            # (sweeps.  End of round 3, feature graph 4.84 ms: 9/16 6.47 ms -- the next batch's geometry becomes the critical path --
+            # 10/16 6.02-6.03, 11/16 6.03, 12/16 6.04: one sixteenth of margin to that cliff for a box whose geometry runs slower)
+            sixteenths = int(os.environ.get("AMC3D_GEO_CUS_16THS", "11"))
             geometry_cus = sixteenths * ncu // 16 if self.N <= 24576 else 0
         self.s_fps, self.s_geo = _dedicated_queues(self.dev, geometry_cus)
         self.geometry_cus = geometry_cus
