@@ -150,3 +150,32 @@ class SegmentedGraph:
     @property
     def collectives(self):
         return len(self.items) - self.segments
+
+
+# ---- what a captured graph is made of ---------------------------------------------------------------------------------
+_NODE_TYPES = ("kernel", "memcpy", "memset", "host", "graph", "empty", "wait_event", "event_record", "ext_semaphore_signal",
+               "ext_semaphore_wait", "mem_alloc", "mem_free", "memcpy_from_symbol", "memcpy_to_symbol", "batch_mem_op")
+
+
+def node_type_counts(graph):
+    """{node type: count} of a captured torch.cuda.CUDAGraph made with keep_graph=True (hipGraphGetNodes / hipGraphNodeGetType;
+    child graphs are not descended into).  What it is for: on ROCm 7.2 a MEMSET node is not reliably ordered before the kernel
+    nodes behind it at replay -- rocPRIM's radix sort and torch's multi-block reductions both zero their
+    counters with hipMemsetAsync -- so the product's graphs must hold none (GraphPipeline(audit=True), tests)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    raw = ctypes.c_void_p(graph.raw_cuda_graph())
+    n = ctypes.c_size_t(0)
+    if hip.hipGraphGetNodes(raw, None, ctypes.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    nodes = (ctypes.c_void_p * max(1, n.value))()
+    if n.value and hip.hipGraphGetNodes(raw, nodes, ctypes.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    counts = {}
+    for i in range(n.value):
+        t = ctypes.c_int(-1)
+        if hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t)) != 0:
+            raise RuntimeError("hipGraphNodeGetType failed")
+        name = _NODE_TYPES[t.value] if 0 <= t.value < len(_NODE_TYPES) else f"type_{t.value}"
+        counts[name] = counts.get(name, 0) + 1
+    return counts

@@ -27,6 +27,24 @@ def _cross_entropy(crit, logit, target):
     return crit(logit.transpose(1, 2).reshape(-1, logit.shape[1]), target), target
 
 
+def _l1_mean(crit, pred, target, rows=1024):
+    """nn.L1Loss()(pred, target) in two small reduction stages on the GPU.  torch reduces a long vector to one number with a
+    multi-block kernel whose arrival counters it zeroes with cudaMemsetAsync; recorded into a graph that is a memset NODE, and
+    ROCm 7.2 does not reliably order a memset node before the kernel nodes behind it at replay (the fault
+    the radix sort's memsets caused) -- here the counters of a reduction, i.e. a sum that may silently come out wrong.  Rows
+    of `rows` elements summed per row, then the row sums: neither stage crosses workgroups.  Same value up to the order of the
+    fp32 additions (1e-7 relative); anything but the plain mean on CUDA tensors goes to the module itself."""
+    if not (type(crit) is torch.nn.L1Loss and crit.reduction == 'mean' and pred.is_cuda and pred.dim() == 1
+            and pred.shape == target.shape and pred.numel() > rows):
+        return crit(pred, target)
+    d = (pred - target).abs()
+    n = d.numel()
+    pad = (-n) % rows
+    if pad:
+        d = torch.nn.functional.pad(d, (0, pad))
+    return d.view(-1, rows).sum(1).sum() / n
+
+
 @LOSS.register_module()
 class CrossEntropyAce(torch.nn.Module):
     """w1 * CE(logits, target) + w2 * sum_stage contrast(stage).  Like the reference, the
@@ -62,7 +80,7 @@ class CrossEntropyAcePre(torch.nn.Module):
         contrast, target_ai, _ = self.contrast_head(logit, target, stageACE_list, num_classes, ignore_index,
                                                     ambiguity_args)
         logits_ai = torch.cat(stageACE_list['ambiguity']).flatten()
-        regression = self.MAE(logits_ai, target_ai)
+        regression = _l1_mean(self.MAE, logits_ai, target_ai)
         ce = ambiguity_args.w1 * ce
         contrast = ambiguity_args.w2 * contrast
         regression = ambiguity_args.w3 * regression

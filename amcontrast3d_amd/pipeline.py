@@ -189,13 +189,18 @@ class GraphPipeline:
 
     def __init__(self, model, step_loss, head, optimizer, example, num_classes, ignore_index, ambiguity_args, *,
                  lanes=0, max_grad_norm=None, flat_grads=None, sync_bn=False, keep_state=True, geometry_cus=None,
-                 amp_dtype=None, verbose=False, tail=None):
+                 amp_dtype=None, verbose=False, tail=None, audit=None):
         from . import ops
         self.model, self.step_loss, self.head, self.opt = model, step_loss, head, optimizer
         # tail(out, data): the caller's per-iteration bookkeeping on device (confusion matrix, loss sums: train.py) recorded as the
         # tail of the feature graph, into tensors the caller owns -- eager launches between two replays cost the training stream
         # more than their kernels (0.11 ms per step for two small ones).  It also runs in the warm-up passes: reset afterwards.
         self.tail = tail
+        # audit: keep every captured graph's node list and record its node types in self.graph_nodes {name: [counts per graph]}
+        # (graphs.node_type_counts) -- the product's graphs must hold no memset node; AMC3D_AUDIT_GRAPHS=1 turns it on and raises
+        import os as _os
+        self.audit = bool(_os.environ.get("AMC3D_AUDIT_GRAPHS")) if audit is None else bool(audit)
+        self.graph_nodes = {}
         self.ncls, self.ignore, self.aargs = num_classes, ignore_index, ambiguity_args
         self.clip, self.flatg, self.sync_bn, self.amp_dtype = max_grad_norm, flat_grads, sync_bn, amp_dtype
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -360,12 +365,26 @@ class GraphPipeline:
             self.opt.zero_grad(set_to_none=True)
         mode = "thread_local" if dist_on else "global"
         self.mode = mode
-        G = torch.cuda.CUDAGraph
+        audit = self.audit
+
+        def G():
+            return torch.cuda.CUDAGraph(keep_graph=True) if audit else torch.cuda.CUDAGraph()
+
+        def audited(g, name):
+            if not audit:
+                return
+            counts = _graphs_mod.node_type_counts(g)
+            self.graph_nodes.setdefault(name, []).append(counts)
+            g.instantiate()
+            if counts.get("memset") and os.environ.get("AMC3D_AUDIT_GRAPHS"):
+                raise RuntimeError(f"GraphPipeline: the {name} graph holds {counts['memset']} memset node(s): {counts}")
+        from . import graphs as _graphs_mod
         # geometry variants: their own output tensors are the two result sets
         self.g_geo, self.rest = [G() for _ in range(S)], []
         for v in range(S):
             with torch.cuda.graph(self.g_geo[v], stream=self.s_geo, capture_error_mode=mode):
                 self.rest.append(geometry.split(self._rest(self.set_in[v], self.set_fps[v]))[1])
+            audited(self.g_geo[v], "geometry")
         for v, r in enumerate(self.rest):  # a result set may only alias the inputs of its own variant
             other = set()
             geometry._walk([[self.set_fps[u], self.set_in[u]] for u in range(S) if u != v] + [self.in_J, self.fps_J],
@@ -425,6 +444,7 @@ class GraphPipeline:
                 kw = {"pool": self.g_feat[0].pool()} if v else {}  # the variants never run at the same time
                 with torch.cuda.graph(g, stream=self.main, capture_error_mode=mode, **kw):
                     body()
+                audited(g, "features")
             self.g_feat.append(g)
             if v == 0:
                 self.collectives_in_graph = _graphs.captured_collectives - n_coll0
@@ -438,6 +458,7 @@ class GraphPipeline:
             self.g_update = G()
             with torch.cuda.graph(self.g_update, stream=self.main, capture_error_mode=mode):
                 self._update()
+            audited(self.g_update, "update")
         # hand-down on the geometry queue, one graph per tick of the period 2J: lane (buffer jc, lane l) -> input set v1
         self.g_side = []
         for t in range(schedule.period(J)):
@@ -447,11 +468,13 @@ class GraphPipeline:
             with torch.cuda.graph(g, stream=self.s_geo, capture_error_mode=mode):
                 geometry.copy_into(self.set_fps[v1], self.fps_lane[jc][l])
                 self._copy_batch(self.set_in[v1], self.in_lane[jc][l])
+            audited(g, "hand_down")
             self.g_side.append(g)
         self.g_fps = [G(), G()]
         for j in range(2):
             with torch.cuda.graph(self.g_fps[j], stream=self.s_fps, capture_error_mode=mode):
                 geometry.copy_into(self.fps_J[j], self._fps_all(self.in_J[j]))
+            audited(self.g_fps[j], "sampling")
         torch.cuda.synchronize()
 
     # -- running ------------------------------------------------------------------------------------------------------

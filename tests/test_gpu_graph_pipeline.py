@@ -172,3 +172,49 @@ def test_endless_feed_and_describe():
     assert d["launch"].startswith("hipGraph") and d["batches_per_joint_fps_launch"] == 2 and d["update"].startswith("captured")
     parts = pipe.parts_alone(reps=2)
     assert parts["features_ms"] > 0 and pipe.serial_ms(reps=2) > 0
+
+
+@pytest.mark.parametrize("mm", [False, True])
+def test_no_memset_node_in_any_graph_of_the_pipeline(mm):
+    """On ROCm 7.2 a memset NODE is not reliably ordered before the kernel nodes behind it when a graph is replayed (the GPU
+    fault of DESIGN.md section 0: rocPRIM's radix sort zeroes its counters with hipMemsetAsync; torch's multi-block reductions do
+    the same -- AMContrast3D++'s L1 regression term was one).  GraphPipeline(audit=True) keeps every captured graph's node list:
+    the geometry, feature (+ update), hand-down and sampling graphs of both model families hold kernels and copies only, and
+    the audited pipeline still trains."""
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from openpoints.loss import build_criterion_from_cfg
+    from openpoints.models import build_model_from_cfg
+    from openpoints.optim import build_optimizer_from_cfg
+    from openpoints.utils import EasyConfig
+    if mm:
+        torch.manual_seed(0)
+        c = EasyConfig(); c.update(configs.model_cfg_mm("S", dropout=0, width=16, threshold=0.5))
+        model = build_model_from_cfg(c).to(DEV).train()
+        cc = EasyConfig(); cc.update(configs.criterion_cfg_mm())
+        crit = build_criterion_from_cfg(cc).to(DEV)
+        aa = EasyConfig(); aa.update(configs.ambiguity_args_mm("s3dis"))
+        opt = build_optimizer_from_cfg(model, NAME="adamw", lr=1e-3, weight_decay=1e-4)
+
+        def step_loss(data):
+            logits, stage, rate = model(data)
+            seg, ce, am, reg = crit(logits, data["y"], stage, 13, None, aa)
+            return logits, seg + reg, (seg, ce, am, reg)
+        from amcontrast3d_amd.pipeline import GraphPipeline
+        batches = _batches(5)
+        main = torch.cuda.Stream()
+        main.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(main):
+            pipe = GraphPipeline(model, step_loss, crit.contrast_head, opt, batches[0], 13, None, aa, lanes=2, max_grad_norm=10, audit=True)
+    else:
+        model, crit, aa, opt = _setup(1e-3)
+        batches = _batches(5)
+        pipe, main = _pipeline(model, crit, aa, opt, batches[0], 2, audit=True)
+    assert set(pipe.graph_nodes) >= {"geometry", "features", "hand_down", "sampling"}, pipe.graph_nodes.keys()
+    for name, graphs_ in pipe.graph_nodes.items():
+        for counts in graphs_:
+            assert counts.get("kernel", 0) + counts.get("memcpy", 0) > 0 and not counts.get("memset"), (name, counts)
+            assert set(counts) <= {"kernel", "memcpy", "empty", "event_record", "wait_event"}, (name, counts)
+    with torch.cuda.stream(main):
+        losses = [float(out["loss"]) for out in pipe.run(iter(batches))]
+    assert len(losses) == 5 and all(l == l and l < 1e3 for l in losses)

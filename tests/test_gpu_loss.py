@@ -312,3 +312,37 @@ def test_confusion_matrix_from_logits_is_update_of_the_argmax(B, C, N, ignore):
     a.update(logits.argmax(dim=1), target)
     b.update_from_logits(logits, target)
     assert torch.equal(a.value, b.value) and int(a.invalid) == int(b.invalid) == 1
+
+
+def test_regression_term_as_a_two_stage_mean():
+    """loss/build.py _l1_mean: nn.L1Loss's value and gradient (the AMContrast3D++ regression term over ~255000 predicted
+    ambiguities) without torch's multi-block reduction, whose counters are zeroed by a memset -- a memset NODE under graph
+    capture; capturable, and equal replay after replay"""
+    import amcontrast3d_amd
+    amcontrast3d_amd.activate()
+    from openpoints.loss.build import _l1_mean
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    for n in (255000, 4097, 1000):
+        a = torch.rand(n, generator=g).to(dev).requires_grad_(True)
+        b = torch.rand(n, generator=g).to(dev)
+        got = _l1_mean(torch.nn.L1Loss(), a, b)
+        got.backward()
+        a2 = a.detach().clone().requires_grad_(True)
+        want = torch.nn.L1Loss()(a2, b)
+        want.backward()
+        assert abs(float(got) - float(want)) <= 2e-7 * float(want)
+        torch.testing.assert_close(a.grad, a2.grad, rtol=1e-6, atol=0)
+    x, y = torch.rand(255000, device=dev), torch.rand(255000, device=dev)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        _l1_mean(torch.nn.L1Loss(), x, y)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            out = _l1_mean(torch.nn.L1Loss(), x, y)
+        vals = []
+        for _ in range(5):
+            graph.replay()
+            vals.append(float(out))
+    assert len(set(vals)) == 1 and abs(vals[0] - float((x - y).abs().double().mean())) <= 1e-6
