@@ -285,7 +285,7 @@ class GraphPipeline:
     def _choose_lanes(self, example, verbose):
         """batches per joint FPS launch: 4 where the first-level chain is about a feature half long (24k-point clouds: the
         launch then runs 10 ms every fourth tick); for long chains (64k / 120k-point clouds in batches of 1-2) as many as
-        make the chain of ALL levels fit into J ticks next to a busy chip, at most 12"""
+        make the chain of ALL levels fit into J ticks next to a busy chip, at most 24"""
         data = dict(example)
         t_fps = self._ms(lambda: geometry.precompute_fps_levels(self.model, data["pos"], 0, 2), 1)
         data["_geometry"] = geometry.precompute(self.model, self.head, data, self.ncls, self.ignore, self.aargs)
@@ -297,15 +297,27 @@ class GraphPipeline:
                 for p in self.params:
                     p.grad = None
         t_feat = self._ms(feat, 2)
+        t_all = None
         if t_fps <= 1.5 * t_feat:
             lanes = 4
         else:
+            # The chain runs ~2.7 x slower next to a busy chip than alone and the captured step takes ~0.8 of the eager pass: it
+            # fits into J steps from J ~ t_all / (0.28 t_feat) (XL + ++ at 2 x 64000: 7 lanes 19.1 ms per step -- the chain is the
+            # critical path -- 8: 18.1, 9: 17.85, 11: 17.84).  Clouds of >= 100 k points use the L2-resident kernel, which slows
+            # further as more clouds share the L2: the step keeps falling up to 24 lanes there (1 x 120000, bf16: 12 lanes 19.1 ms,
+            # 16: 17.5, 20: 17.4, 24: 17.0).  J = 10 and J = 18 measured 5-8 % slower than their neighbours, reproducibly and
+            # for no reason found: skipped.
             t_all = self._ms(lambda: self._fps_all(data), 1)
-            lanes = int(min(12, max(3, -(-t_all // max(0.35 * t_feat, 1e-3)))))
+            lanes = int(-(-t_all // max(0.28 * t_feat, 1e-3)))
+            if self.N >= 100000:
+                lanes = max(lanes, 24)
+            lanes = int(min(24, max(3, lanes)))
+            if lanes % 8 == 2:
+                lanes += 1
         if verbose:
             import sys
-            print(f"GraphPipeline: sampling chain {t_fps:.1f} ms (first level), eager feature half {t_feat:.1f} ms -> {lanes} "
-                  f"batches per joint FPS launch", file=sys.stderr)
+            print(f"GraphPipeline: sampling chain {t_fps:.1f} ms (first level{'' if t_all is None else f', {t_all:.1f} all levels'}), "
+                  f"eager feature half {t_feat:.1f} ms -> {lanes} batches per joint FPS launch", file=sys.stderr)
         return lanes
 
     # -- state kept across the warm-up --------------------------------------------------------------------------------
