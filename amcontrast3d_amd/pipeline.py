@@ -302,18 +302,15 @@ class GraphPipeline:
             lanes = 4
         else:
             # The chain runs ~2.7 x slower next to a busy chip than alone and the captured step takes ~0.8 of the eager pass: it
-            # fits into J steps from J ~ t_all / (0.28 t_feat) (XL + ++ at 2 x 64000: 7 lanes 19.1 ms per step -- the chain is the
-            # critical path -- 8: 18.1, 9: 17.85, 11: 17.84).  Clouds of >= 100 k points use the L2-resident kernel, which slows
-            # further as more clouds share the L2: the step keeps falling up to 24 lanes there (1 x 120000, bf16: 12 lanes 19.1 ms,
-            # 16: 17.5, 20: 17.4, 24: 17.0).  J = 10 and J = 18 measured 5-8 % slower than their neighbours, reproducibly and
-            # for no reason found: skipped.
+            # fits into J steps from J ~ t_all / (0.28 t_feat).  Measured over whole launch periods (a window that is not a multiple
+            # of J counts the joint launches unevenly and moves the average by up to 5 %): XL + ++ at 2 x 64000 -- 7 lanes 19.1 ms
+            # per step, 8: 18.8, 9: 18.55, 10: 18.54, 11: 18.33; 1 x 120000 bf16 (the L2-resident kernel, slower still as more
+            # clouds share the L2) -- 12 lanes 19.1, 16: 17.5, 20: 17.4.
             t_all = self._ms(lambda: self._fps_all(data), 1)
             lanes = int(-(-t_all // max(0.28 * t_feat, 1e-3)))
             if self.N >= 100000:
                 lanes = max(lanes, 24)
             lanes = int(min(24, max(3, lanes)))
-            if lanes % 8 == 2:
-                lanes += 1
         if verbose:
             import sys
             print(f"GraphPipeline: sampling chain {t_fps:.1f} ms (first level{'' if t_all is None else f', {t_all:.1f} all levels'}), "
